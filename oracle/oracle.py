@@ -1,0 +1,146 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/ansfm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Never imported by the product package `archnemesis_dist_amd`.
+Function names/arguments mirror the reference seams they restate (file:line in the C source).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_d = np.float64
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libansfm_oracle.so")
+    src = os.path.join(_HERE, "ansfm_oracle.c")
+    if force or (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libansfm_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_num_threads.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype=_d):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(C.c_int(int(n)))
+
+
+def calc_k(K, PRESS, TEMP, press, temp, grad=False):
+    """Spectroscopy_0.calc_k / calc_kg.  K (W,G,NP,NT,S) -> k (W,G,L,S) [, dkdT]."""
+    K = _c(K); PRESS = _c(PRESS); TEMP = _c(TEMP); press = _c(press); temp = _c(temp)
+    W, G, NP, NT, S = K.shape
+    L = press.shape[0]
+    k = np.zeros((W, G, L, S)); dk = np.zeros((W, G, L, S)) if grad else None
+    lib().orc_calc_k(W, G, NP, NT, S, _p(K), _p(PRESS), _p(TEMP), L, _p(press), _p(temp), _p(k), _p(dk))
+    return (k, dk) if grad else k
+
+
+def rank(weight, cont, del_g):
+    weight = _c(weight); cont = _c(cont); del_g = _c(del_g)
+    ng = del_g.shape[0]
+    assert weight.size == ng * ng == cont.size
+    out = np.zeros(ng)
+    lib().orc_rank(ng, _p(weight), _p(cont), _p(del_g), _p(out))
+    return out
+
+
+def k_overlap(del_g, k_w_g_l_gas, amount_layer):
+    del_g = _c(del_g); k = _c(k_w_g_l_gas); am = _c(amount_layer)
+    W, G, L, S = k.shape
+    assert am.shape == (S, L)
+    tau = np.zeros((W, G, L))
+    lib().orc_k_overlap(W, G, L, S, _p(del_g), _p(k), None, _p(am), _p(tau), None)
+    return tau
+
+
+def k_overlapg(del_g, k_w_g_l_gas, dkdT_w_g_l_gas, amount_layer):
+    del_g = _c(del_g); k = _c(k_w_g_l_gas); dkdT = _c(dkdT_w_g_l_gas); am = _c(amount_layer)
+    W, G, L, S = k.shape
+    tau = np.zeros((W, G, L)); dk = np.zeros((W, G, L, S + 1))
+    lib().orc_k_overlap(W, G, L, S, _p(del_g), _p(k), _p(dkdT), _p(am), _p(tau), _p(dk))
+    return tau, dk
+
+
+def planck(ispace, wave, temp):
+    wave, temp = np.broadcast_arrays(_c(wave), _c(temp))
+    wave = _c(wave); temp = _c(temp)
+    bb = np.zeros(wave.shape)
+    lib().orc_planck(int(ispace), wave.size, _p(wave), _p(temp), _p(bb), None)
+    return bb
+
+
+def planckg(ispace, wave, temp):
+    wave, temp = np.broadcast_arrays(_c(wave), _c(temp))
+    wave = _c(wave); temp = _c(temp)
+    bb = np.zeros(wave.shape); db = np.zeros(wave.shape)
+    lib().orc_planck(int(ispace), wave.size, _p(wave), _p(temp), _p(bb), _p(db))
+    return bb, db
+
+
+def calc_thermal_emission_spectrum(ISPACE, WAVE, TAUTOT_PATH, EMITOT_PATH, TEMP, PRESS, TSURF,
+                                   EMISSIVITY, SOLFLUX, REFLECTANCE, SOL_ANG, EMISS_ANG):
+    WAVE = _c(WAVE); TAU = _c(TAUTOT_PATH); EMI = _c(EMITOT_PATH); TEMP = _c(TEMP); PRESS = _c(PRESS)
+    W, G, Li = TAU.shape
+    out = np.zeros((W, G))
+    lib().orc_thermal_emission(int(ISPACE), W, G, Li, _p(WAVE), _p(TAU), _p(EMI), _p(TEMP), _p(PRESS),
+                               C.c_double(TSURF), _p(_c(EMISSIVITY)), _p(_c(SOLFLUX)),
+                               _p(_c(REFLECTANCE)), C.c_double(SOL_ANG), C.c_double(EMISS_ANG), _p(out))
+    return out
+
+
+def calc_thermal_emission_spectrumg(ISPACE, WAVE, TAUTOT_PATH, dTAUTOT_PATH, NVMR, TEMP, PRESS, TSURF,
+                                    EMISSIVITY):
+    WAVE = _c(WAVE); TAU = _c(TAUTOT_PATH); dTAU = _c(dTAUTOT_PATH); TEMP = _c(TEMP); PRESS = _c(PRESS)
+    W, G, NPAR, Li = dTAU.shape
+    spec = np.zeros((W, G)); dspec = np.zeros((W, G, NPAR, Li)); dts = np.zeros((W, G))
+    lib().orc_thermal_emissiong(int(ISPACE), W, G, NPAR, Li, _p(WAVE), _p(TAU), _p(dTAU), int(NVMR),
+                                _p(TEMP), _p(PRESS), C.c_double(TSURF), _p(_c(EMISSIVITY)), _p(spec),
+                                _p(dspec), _p(dts))
+    return spec, dspec, dts
+
+
+def cirsrad_ck_thermal(ISPACE, K, TPRESS, TTEMP, WAVE, DELG, lay_press_pa, lay_temp, amount,
+                       TAUCONT, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None, SOLFLUX=None,
+                       REFLECTANCE=None, SOL_ANG=None, EMISS_ANG=None, xfac=None, return_taugas=False):
+    """CIRSrad (ILBL=K_TABLES, IMOD=THERMAL_EMISSION).  ForwardModel_0.py:4376-4511."""
+    K = _c(K); W, G, NP, NT, S = K.shape
+    lay_press_pa = _c(lay_press_pa); L = lay_press_pa.shape[0]
+    patm = _c(lay_press_pa / 101325.0)
+    amount = _c(amount); assert amount.shape == (S, L)
+    LAYINC = _c(LAYINC, np.int32); SCALE = _c(SCALE); EMTEMP = _c(EMTEMP)
+    NLAYIN = _c(NLAYIN, np.int32)
+    LIMAX, P = LAYINC.shape
+    out = np.zeros((W, P))
+    tg = np.zeros((W, G, L)) if return_taugas else None
+    lib().orc_cirsrad_ck_thermal(
+        int(ISPACE), W, G, NP, NT, S, _p(K), _p(_c(TPRESS)), _p(_c(TTEMP)), _p(_c(WAVE)), _p(_c(DELG)),
+        L, _p(patm), _p(_c(lay_temp)), _p(lay_press_pa), _p(amount), _p(_c(TAUCONT)), P, LIMAX,
+        _p(NLAYIN), _p(LAYINC), _p(SCALE), _p(EMTEMP), C.c_double(TSURF), _p(_c(EMISSIVITY)),
+        _p(_c(SOLFLUX)), _p(_c(REFLECTANCE)), _p(_c(SOL_ANG)), _p(_c(EMISS_ANG)), _p(_c(xfac)),
+        _p(out), _p(tg))
+    return (out, tg) if return_taugas else out
