@@ -1,0 +1,93 @@
+"""ctypes loader for libansfm.so (the HIP/gfx950 engine behind include/ansfm.h).
+
+The library is built in-tree (archnemesis_dist_amd/lib/libansfm.so) by `build()` /
+`__graft_entry__.build()`.  There is NO CPU fallback: if the library is missing or no HIP device
+is usable, this module raises -- product code never routes through the CPU oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libansfm.so")
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+ANSFM_OK = 0
+ERR_NAMES = {1: "ANSFM_ERR_INVALID", 2: "ANSFM_ERR_HIP", 3: "ANSFM_ERR_NOTABLE", 4: "ANSFM_ERR_UNSORTED",
+             5: "ANSFM_ERR_UNSUPPORTED"}
+
+# every symbol include/ansfm.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "ansfm_abi_version", "ansfm_create", "ansfm_destroy", "ansfm_last_error", "ansfm_set_stream",
+    "ansfm_synchronize", "ansfm_upload_ktable", "ansfm_upload_ktable_dev", "ansfm_ktable_info",
+    "ansfm_calc_k", "ansfm_k_overlap", "ansfm_thermal_emission", "ansfm_cirsrad_ck_thermal",
+    "ansfm_cirsrad_ck_thermal_dev", "ansfm_get_taugas", "ansfm_last_kernel_ms",
+]
+
+_lib = None
+
+
+class AnsfmError(RuntimeError):
+    pass
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into lib/libansfm.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, "ansfm_api.hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "ansfm.h")]
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(d) for d in deps)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+           "-fvisibility=hidden", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    """dlopen libansfm.so and declare prototypes.  Raises AnsfmError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AnsfmError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    lib.ansfm_abi_version.restype = ci
+    lib.ansfm_create.argtypes = [ci, C.POINTER(vp)]
+    lib.ansfm_destroy.argtypes = [vp]
+    lib.ansfm_destroy.restype = None
+    lib.ansfm_last_error.argtypes = [vp]
+    lib.ansfm_last_error.restype = C.c_char_p
+    lib.ansfm_set_stream.argtypes = [vp, vp]
+    lib.ansfm_synchronize.argtypes = [vp]
+    lib.ansfm_upload_ktable.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+    lib.ansfm_upload_ktable_dev.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+    lib.ansfm_ktable_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(ci)]
+    lib.ansfm_calc_k.argtypes = [vp, ci, vp, vp, vp, vp]
+    lib.ansfm_k_overlap.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp]
+    lib.ansfm_thermal_emission.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, cd, vp, vp, vp, cd, cd, vp]
+    cirs = [vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ansfm_cirsrad_ck_thermal.argtypes = cirs
+    lib.ansfm_cirsrad_ck_thermal_dev.argtypes = cirs
+    lib.ansfm_get_taugas.argtypes = [vp, ci, vp]
+    lib.ansfm_last_kernel_ms.argtypes = [vp, C.POINTER(cd), C.POINTER(ci), C.POINTER(cd), C.POINTER(ci)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("ansfm_destroy", "ansfm_last_error"):
+            fn.restype = ci
+    _lib = lib
+    return lib

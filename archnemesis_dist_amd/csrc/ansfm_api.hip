@@ -1,0 +1,585 @@
+// ansfm_api.hip -- C-ABI of libansfm.so (include/ansfm.h): context, HBM buffers, launches.
+// gfx950 only.  No CPU fallback: every entry point needs a live HIP device.
+#include "ansfm_kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#pragma GCC visibility push(default)
+#include "../../include/ansfm.h"
+#pragma GCC visibility pop
+
+using namespace ansfm;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct ansfm_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int num_cus = 256;
+
+    // k-table
+    int W = 0, Wpad = 0, G = 0, NP = 0, NT = 0, S = 0;
+    int monotone = 0;
+    bool have_table = false;
+    DevBuf lnK, d_press, d_temp, d_wave, d_delg, d_flag;
+    std::vector<double> h_delg;
+
+    // workspaces
+    DevBuf li, tau, scratch, cont_t, tmp_in, tmp_out, misc;
+    DevBuf hb[24];  // staging buffers of the host-pointer entry points
+    int last_n = 0, last_L = 0;
+
+    // timing of the last cirsrad call
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double overlap_ms = 0, rt_ms = 0;
+    int overlap_launches = 0, rt_launches = 0;
+};
+
+#define CHECK_CTX(ctx) do { if (!(ctx)) return ANSFM_ERR_INVALID; } while (0)
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            char b__[512];                                                                    \
+            snprintf(b__, sizeof b__, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,           \
+                     hipGetErrorString(e__));                                                 \
+            ctx->err = b__;                                                                   \
+            return ANSFM_ERR_HIP;                                                             \
+        }                                                                                     \
+    } while (0)
+#define FAIL(code, msg) do { ctx->err = (msg); return (code); } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline unsigned nblk(size_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+static void loser_tree_init(int G, unsigned char *init_loser, int *depth)
+{
+    // heap layout: internal nodes 1..G-1, leaf y = G + row.  At the start every row's head is
+    // a_row + b_0 and a is ascending, so the winner of any subtree is its smallest row index.
+    int m[2 * kMaxG];
+    for (int y = G; y < 2 * G; ++y) m[y] = y - G;
+    for (int x = 0; x < kMaxG; ++x) init_loser[x] = 0;
+    for (int x = G - 1; x >= 1; --x) {
+        int a = m[2 * x], b = m[2 * x + 1];
+        m[x] = a < b ? a : b;
+        init_loser[x] = (unsigned char)(a < b ? b : a);
+    }
+    int d = 0;
+    for (int x = (2 * G - 1) >> 1; x >= 1; x >>= 1) ++d;
+    *depth = d;
+}
+
+extern "C" {
+
+int ansfm_abi_version(void) { return ANSFM_ABI_VERSION; }
+
+int ansfm_create(int device, ansfm_ctx **out)
+{
+    if (!out) return ANSFM_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return ANSFM_ERR_HIP;  // no GPU: there is deliberately no CPU fallback
+    ansfm_ctx *ctx = new ansfm_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return ANSFM_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return ANSFM_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return ANSFM_ERR_HIP; }
+    *out = ctx;
+    return ANSFM_OK;
+}
+
+void ansfm_destroy(ansfm_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->lnK, &ctx->d_press, &ctx->d_temp, &ctx->d_wave, &ctx->d_delg, &ctx->d_flag,
+                      &ctx->li, &ctx->tau, &ctx->scratch, &ctx->cont_t, &ctx->tmp_in, &ctx->tmp_out,
+                      &ctx->misc};
+    for (auto *b : bufs) b->release();
+    for (auto &b : ctx->hb) b.release();
+    for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *ansfm_last_error(const ansfm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int ansfm_set_stream(ansfm_ctx *ctx, void *hip_stream)
+{
+    CHECK_CTX(ctx);
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ANSFM_OK;
+}
+
+int ansfm_synchronize(ansfm_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k-table                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+int ansfm_upload_ktable_dev(ansfm_ctx *ctx, int W, int G, int NP, int NT, int S, const double *K_dev,
+                            const double *PRESS, const double *TEMP, const double *WAVE,
+                            const double *DELG)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || G <= 0 || G > ANSFM_MAX_NG || NP < 2 || NT < 2 || S <= 0 || !K_dev || !PRESS || !TEMP ||
+        !WAVE || !DELG)
+        FAIL(ANSFM_ERR_INVALID, "upload_ktable: bad dims (need 1<=G<=32, NP>=2, NT>=2) or null pointer");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int Wpad = round_up(W, kWave);
+    const size_t total = (size_t)NP * NT * S * G * Wpad;
+    HIPCHK(ctx->lnK.reserve(total * sizeof(double)));
+    HIPCHK(ctx->d_press.reserve(NP * sizeof(double)));
+    HIPCHK(ctx->d_temp.reserve(NT * sizeof(double)));
+    HIPCHK(ctx->d_wave.reserve((size_t)W * sizeof(double)));
+    HIPCHK(ctx->d_delg.reserve(kMaxG * sizeof(double)));
+    HIPCHK(ctx->d_flag.reserve(4 * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(ctx->d_press.p, PRESS, NP * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_temp.p, TEMP, NT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_wave.p, WAVE, (size_t)W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_delg.p, DELG, G * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_flag.p, 0, 4 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_table_relayout, dim3(nblk(total, 256)), dim3(256), 0, ctx->stream, K_dev,
+                       ctx->lnK.as<double>(), W, Wpad, G, NP, NT, S, ctx->d_flag.as<int>());
+    HIPCHK(hipGetLastError());
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, ctx->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->W = W; ctx->Wpad = Wpad; ctx->G = G; ctx->NP = NP; ctx->NT = NT; ctx->S = S;
+    ctx->monotone = (flag & 1) ? 0 : 1;
+    ctx->h_delg.assign(DELG, DELG + G);
+    ctx->have_table = true;
+    return ANSFM_OK;
+}
+
+int ansfm_upload_ktable(ansfm_ctx *ctx, int W, int G, int NP, int NT, int S, const double *K,
+                        const double *PRESS, const double *TEMP, const double *WAVE, const double *DELG)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || G <= 0 || NP <= 0 || NT <= 0 || S <= 0 || !K) FAIL(ANSFM_ERR_INVALID, "upload_ktable: bad dims");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)W * G * NP * NT * S;
+    HIPCHK(ctx->tmp_in.reserve(n * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->tmp_in.p, K, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rc = ansfm_upload_ktable_dev(ctx, W, G, NP, NT, S, ctx->tmp_in.as<double>(), PRESS, TEMP, WAVE, DELG);
+    ctx->tmp_in.release();  // the reference-layout copy is only needed during the re-layout
+    return rc;
+}
+
+int ansfm_ktable_info(const ansfm_ctx *ctx, int64_t dims[5], int *monotone)
+{
+    if (!ctx) return ANSFM_ERR_INVALID;
+    if (!ctx->have_table) return ANSFM_ERR_NOTABLE;
+    if (dims) { dims[0] = ctx->W; dims[1] = ctx->G; dims[2] = ctx->NP; dims[3] = ctx->NT; dims[4] = ctx->S; }
+    if (monotone) *monotone = ctx->monotone;
+    return ANSFM_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* launches                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W, int Wpad, int G, int S,
+                          int L, int n_models, const LayerInterp *li, const double *amount,
+                          const double *del_g_dev, double *tau)
+{
+    OverlapParams p;
+    memset(&p, 0, sizeof p);
+    p.lnK = ctx->lnK.as<double>();
+    p.kin = kin;
+    p.li = li;
+    p.amount = amount;
+    p.del_g = del_g_dev;
+    p.tau = tau;
+    p.err_flag = ctx->d_flag.as<int>() + 1;
+    p.W = W; p.Wpad = Wpad; p.G = G; p.NT = ctx->NT; p.S = S; p.L = L; p.n_models = n_models;
+    loser_tree_init(G, p.init_loser, &p.depth);
+    const size_t lds = (size_t)G * kWave * (3 * sizeof(double) + sizeof(uint32_t)) +
+                       (size_t)(2 * kMaxG + 2) * sizeof(double);
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    const long ntiles = (long)n_models * (Wpad / kWave) * L;
+    long grid = (long)ctx->num_cus * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    if (grid < 1) grid = 1;
+    HIPCHK(ctx->scratch.reserve((size_t)grid * 2 * G * kWave * sizeof(double)));
+    p.scratch = ctx->scratch.as<double>();
+#define LAUNCH_OV(D, FK)                                                                              \
+    hipLaunchKernelGGL((k_ck_overlap<D, FK>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p)
+    if (from_k) {
+        switch (p.depth) {
+            case 1: LAUNCH_OV(1, true); break;
+            case 2: LAUNCH_OV(2, true); break;
+            case 3: LAUNCH_OV(3, true); break;
+            case 4: LAUNCH_OV(4, true); break;
+            default: LAUNCH_OV(5, true); break;
+        }
+    } else {
+        switch (p.depth) {
+            case 1: LAUNCH_OV(1, false); break;
+            case 2: LAUNCH_OV(2, false); break;
+            case 3: LAUNCH_OV(3, false); break;
+            case 4: LAUNCH_OV(4, false); break;
+            default: LAUNCH_OV(5, false); break;
+        }
+    }
+#undef LAUNCH_OV
+    HIPCHK(hipGetLastError());
+    return ANSFM_OK;
+}
+
+static int launch_rt(ansfm_ctx *ctx, const RtParams &p, int n_models)
+{
+    dim3 grid((unsigned)(p.Wpad / kWave), (unsigned)p.P, (unsigned)n_models);
+    hipLaunchKernelGGL(k_thermal_rt, grid, dim3(kWave, kGY), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    return ANSFM_OK;
+}
+
+static int check_unsorted(ansfm_ctx *ctx)
+{
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, ctx->d_flag.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (flag & 1)
+        FAIL(ANSFM_ERR_UNSORTED, "k-distribution not non-decreasing in g: generic (unsorted) merge path not built");
+    return ANSFM_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fused CIRSrad (device pointers)                                                             */
+/* ------------------------------------------------------------------------------------------ */
+int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L,
+                                 const double *lay_press_pa, const double *lay_temp,
+                                 const double *amount, const double *taucont, int P, int LIMAX,
+                                 const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE,
+                                 const double *EMTEMP, const double *TSURF, const double *EMISSIVITY,
+                                 const double *SOLFLUX, const double *REFLECTANCE, const double *SOL_ANG,
+                                 const double *EMISS_ANG, const double *xfac, double *SPECOUT)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "cirsrad: upload a k-table first");
+    if (n_models <= 0 || L <= 0 || P <= 0 || LIMAX <= 0 || !lay_press_pa || !lay_temp || !amount || !NLAYIN ||
+        !LAYINC || !SCALE || !EMTEMP || !TSURF || !SPECOUT || (ISPACE != 0 && ISPACE != 1))
+        FAIL(ANSFM_ERR_INVALID, "cirsrad: bad argument");
+    if (!ctx->monotone)
+        FAIL(ANSFM_ERR_UNSORTED, "k-table is not non-negative and non-decreasing in g: generic merge path not built");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, S = ctx->S;
+    HIPCHK(ctx->li.reserve((size_t)n_models * L * sizeof(LayerInterp)));
+    HIPCHK(ctx->tau.reserve((size_t)n_models * L * G * Wpad * sizeof(double)));
+    HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_layer_prep, dim3(nblk((size_t)n_models * L, 128)), dim3(128), 0, ctx->stream,
+                       n_models * L, lay_press_pa, lay_temp, ctx->NP, ctx->d_press.as<double>(), ctx->NT,
+                       ctx->d_temp.as<double>(), 101325.0, ctx->li.as<LayerInterp>());
+    HIPCHK(hipGetLastError());
+    const double *cont_t = nullptr;
+    if (taucont) {
+        HIPCHK(ctx->cont_t.reserve((size_t)n_models * L * Wpad * sizeof(double)));
+        for (int m = 0; m < n_models; ++m) {
+            hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256)), dim3(256), 0, ctx->stream,
+                               taucont + (size_t)m * W * L, ctx->cont_t.as<double>() + (size_t)m * L * Wpad, W,
+                               Wpad, 1, L, 0, 0.0);
+        }
+        HIPCHK(hipGetLastError());
+        cont_t = ctx->cont_t.as<double>();
+    }
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    int rc = launch_overlap(ctx, false, nullptr, W, Wpad, G, S, L, n_models, ctx->li.as<LayerInterp>(), amount,
+                            ctx->d_delg.as<double>(), ctx->tau.as<double>());
+    if (rc != ANSFM_OK) return rc;
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    RtParams r;
+    memset(&r, 0, sizeof r);
+    r.tau = ctx->tau.as<double>();
+    r.cont = cont_t;
+    r.emi = nullptr;
+    r.wave = ctx->d_wave.as<double>();
+    r.delg = ctx->d_delg.as<double>();
+    r.nlayin = NLAYIN; r.layinc = LAYINC; r.scale = SCALE; r.emtemp = EMTEMP;
+    r.lay_press = lay_press_pa; r.tsurf = TSURF;
+    r.emissivity = EMISSIVITY; r.solflux = SOLFLUX; r.reflectance = REFLECTANCE; r.xfac = xfac;
+    r.sol_ang = SOL_ANG; r.emiss_ang = EMISS_ANG;
+    r.out = SPECOUT;
+    r.W = W; r.Wpad = Wpad; r.G = G; r.L = L; r.P = P; r.LIMAX = LIMAX; r.ispace = ISPACE; r.per_g = 0;
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    rc = launch_rt(ctx, r, n_models);
+    if (rc != ANSFM_OK) return rc;
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->overlap_launches = 1;
+    ctx->rt_launches = 1;
+    ctx->overlap_ms = -1.0;  // resolved lazily in ansfm_last_kernel_ms
+    ctx->last_n = n_models; ctx->last_L = L;
+    return ANSFM_OK;
+}
+
+int ansfm_last_kernel_ms(const ansfm_ctx *cctx, double *overlap_ms, int *overlap_launches, double *rt_ms,
+                         int *rt_launches)
+{
+    ansfm_ctx *ctx = const_cast<ansfm_ctx *>(cctx);
+    CHECK_CTX(ctx);
+    if (ctx->overlap_launches == 0) FAIL(ANSFM_ERR_INVALID, "no cirsrad call recorded yet");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipEventSynchronize(ctx->ev[3]));
+    float a = 0.f, b = 0.f;
+    HIPCHK(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, ctx->ev[2], ctx->ev[3]));
+    ctx->overlap_ms = a; ctx->rt_ms = b;
+    if (overlap_ms) *overlap_ms = a;
+    if (rt_ms) *rt_ms = b;
+    if (overlap_launches) *overlap_launches = ctx->overlap_launches;
+    if (rt_launches) *rt_launches = ctx->rt_launches;
+    return ANSFM_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* host-pointer wrappers                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+static int h2d(ansfm_ctx *ctx, DevBuf &b, const void *src, size_t bytes, const void **out)
+{
+    *out = nullptr;
+    if (!src || bytes == 0) return ANSFM_OK;
+    HIPCHK(b.reserve(bytes));
+    HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *out = b.p;
+    return ANSFM_OK;
+}
+
+int ansfm_cirsrad_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L, const double *lay_press_pa,
+                             const double *lay_temp, const double *amount, const double *taucont, int P,
+                             int LIMAX, const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE,
+                             const double *EMTEMP, const double *TSURF, const double *EMISSIVITY,
+                             const double *SOLFLUX, const double *REFLECTANCE, const double *SOL_ANG,
+                             const double *EMISS_ANG, const double *xfac, double *SPECOUT)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "cirsrad: upload a k-table first");
+    if (n_models <= 0 || L <= 0 || P <= 0 || LIMAX <= 0 || !SPECOUT) FAIL(ANSFM_ERR_INVALID, "cirsrad: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int W = ctx->W, S = ctx->S;
+    const size_t D = sizeof(double);
+    const void *d[18];
+    int i = 0, rc;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(lay_press_pa, (size_t)n_models * L * D);            // 0
+    UP(lay_temp, (size_t)n_models * L * D);                // 1
+    UP(amount, (size_t)n_models * S * L * D);              // 2
+    UP(taucont, (size_t)n_models * W * L * D);             // 3
+    UP(NLAYIN, (size_t)P * sizeof(int32_t));               // 4
+    UP(LAYINC, (size_t)LIMAX * P * sizeof(int32_t));       // 5
+    UP(SCALE, (size_t)n_models * LIMAX * P * D);           // 6
+    UP(EMTEMP, (size_t)n_models * LIMAX * P * D);          // 7
+    UP(TSURF, (size_t)n_models * D);                       // 8
+    UP(EMISSIVITY, (size_t)W * D);                         // 9
+    UP(SOLFLUX, (size_t)W * D);                            // 10
+    UP(REFLECTANCE, (size_t)W * D);                        // 11
+    UP(SOL_ANG, (size_t)P * D);                            // 12
+    UP(EMISS_ANG, (size_t)P * D);                          // 13
+    UP(xfac, (size_t)W * D);                               // 14
+#undef UP
+    HIPCHK(ctx->tmp_out.reserve((size_t)n_models * W * P * D));
+    rc = ansfm_cirsrad_ck_thermal_dev(
+        ctx, ISPACE, n_models, L, (const double *)d[0], (const double *)d[1], (const double *)d[2],
+        (const double *)d[3], P, LIMAX, (const int32_t *)d[4], (const int32_t *)d[5], (const double *)d[6],
+        (const double *)d[7], (const double *)d[8], (const double *)d[9], (const double *)d[10],
+        (const double *)d[11], (const double *)d[12], (const double *)d[13], (const double *)d[14],
+        ctx->tmp_out.as<double>());
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(SPECOUT, ctx->tmp_out.p, (size_t)n_models * W * P * D, hipMemcpyDeviceToHost, ctx->stream));
+    return check_unsorted(ctx);
+}
+
+int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_table || ctx->last_n == 0) FAIL(ANSFM_ERR_INVALID, "get_taugas: no cirsrad call yet");
+    if (model < 0 || model >= ctx->last_n || !TAUGAS) FAIL(ANSFM_ERR_INVALID, "get_taugas: bad model index");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, L = ctx->last_L;
+    const size_t n = (size_t)W * G * L;
+    HIPCHK(ctx->tmp_out.reserve(n * sizeof(double)));
+    // internal [L][G][Wpad] -> reference [W][G][L]
+    hipLaunchKernelGGL(k_w_to_first, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream,
+                       ctx->tau.as<double>() + (size_t)model * L * G * Wpad, ctx->tmp_out.as<double>(), W, Wpad, L,
+                       G, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(TAUGAS, ctx->tmp_out.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+int ansfm_calc_k(ansfm_ctx *ctx, int L, const double *press, const double *temp, double *k_out, double *dkdT_out)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "calc_k: upload a k-table first");
+    if (L <= 0 || !press || !temp || !k_out) FAIL(ANSFM_ERR_INVALID, "calc_k: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, S = ctx->S;
+    const void *dp, *dt;
+    int rc;
+    if ((rc = h2d(ctx, ctx->hb[0], press, L * sizeof(double), &dp))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[1], temp, L * sizeof(double), &dt))) return rc;
+    HIPCHK(ctx->li.reserve((size_t)L * sizeof(LayerInterp)));
+    hipLaunchKernelGGL(k_layer_prep, dim3(nblk(L, 128)), dim3(128), 0, ctx->stream, L, (const double *)dp,
+                       (const double *)dt, ctx->NP, ctx->d_press.as<double>(), ctx->NT, ctx->d_temp.as<double>(),
+                       1.0, ctx->li.as<LayerInterp>());
+    const size_t n = (size_t)W * G * L * S;
+    HIPCHK(ctx->tmp_out.reserve(n * sizeof(double) * (dkdT_out ? 2 : 1)));
+    double *dk = dkdT_out ? ctx->tmp_out.as<double>() + n : nullptr;
+    hipLaunchKernelGGL(k_calc_k_seam, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, ctx->lnK.as<double>(), W, Wpad,
+                       G, ctx->NT, S, L, ctx->li.as<LayerInterp>(), ctx->tmp_out.as<double>(), dk);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(k_out, ctx->tmp_out.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (dkdT_out) HIPCHK(hipMemcpyAsync(dkdT_out, dk, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+int ansfm_k_overlap(ansfm_ctx *ctx, int W, int G, int L, int S, const double *del_g, const double *k,
+                    const double *amount, double *tau)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || G <= 0 || G > ANSFM_MAX_NG || L <= 0 || S <= 0 || !del_g || !k || !amount || !tau)
+        FAIL(ANSFM_ERR_INVALID, "k_overlap: bad argument (need 1<=G<=32)");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int Wpad = round_up(W, kWave);
+    const size_t nk = (size_t)W * G * L * S;
+    const void *dk, *dam, *ddg;
+    int rc;
+    if ((rc = h2d(ctx, ctx->hb[0], k, nk * sizeof(double), &dk))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[1], amount, (size_t)S * L * sizeof(double), &dam))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[2], del_g, (size_t)G * sizeof(double), &ddg))) return rc;
+    HIPCHK(ctx->d_flag.reserve(4 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+    const size_t nkin = (size_t)S * L * G * Wpad;
+    HIPCHK(ctx->tmp_in.reserve(nkin * sizeof(double)));
+    hipLaunchKernelGGL(k_kin_permute, dim3(nblk(nkin, 256)), dim3(256), 0, ctx->stream, (const double *)dk,
+                       ctx->tmp_in.as<double>(), W, Wpad, G, L, S);
+    HIPCHK(hipGetLastError());
+    const size_t ntau = (size_t)L * G * Wpad;
+    HIPCHK(ctx->misc.reserve(ntau * sizeof(double)));
+    rc = launch_overlap(ctx, true, ctx->tmp_in.as<double>(), W, Wpad, G, S, L, 1, nullptr, (const double *)dam,
+                        (const double *)ddg, ctx->misc.as<double>());
+    if (rc) return rc;
+    const size_t nout = (size_t)W * G * L;
+    HIPCHK(ctx->tmp_out.reserve(nout * sizeof(double)));
+    hipLaunchKernelGGL(k_w_to_first, dim3(nblk(nout, 256)), dim3(256), 0, ctx->stream, ctx->misc.as<double>(),
+                       ctx->tmp_out.as<double>(), W, Wpad, L, G, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(tau, ctx->tmp_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return check_unsorted(ctx);
+}
+
+int ansfm_thermal_emission(ansfm_ctx *ctx, int ISPACE, int W, int G, int NLAYIN, const double *WAVE,
+                           const double *TAUTOT_PATH, const double *EMITOT_PATH, const double *TEMP,
+                           const double *PRESS, double TSURF, const double *EMISSIVITY, const double *SOLFLUX,
+                           const double *REFLECTANCE, double SOL_ANG, double EMISS_ANG, double *SPECOUT)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || G <= 0 || G > ANSFM_MAX_NG || NLAYIN <= 0 || !WAVE || !TAUTOT_PATH || !TEMP || !PRESS || !SPECOUT ||
+        (ISPACE != 0 && ISPACE != 1))
+        FAIL(ANSFM_ERR_INVALID, "thermal_emission: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int Wpad = round_up(W, kWave), Li = NLAYIN;
+    const size_t D = sizeof(double);
+    const void *d[10];
+    int rc, i = 0;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(TAUTOT_PATH, (size_t)W * G * Li * D);  // 0
+    UP(EMITOT_PATH, (size_t)W * Li * D);      // 1
+    UP(TEMP, (size_t)Li * D);                 // 2  (EMTEMP[Li][P=1])
+    UP(PRESS, (size_t)Li * D);                // 3  (lay_press[L=Li])
+    UP(WAVE, (size_t)W * D);                  // 4
+    UP(EMISSIVITY, (size_t)W * D);            // 5
+    UP(SOLFLUX, (size_t)W * D);               // 6
+    UP(REFLECTANCE, (size_t)W * D);           // 7
+#undef UP
+    // small path vectors: NLAYIN[1], LAYINC[Li] = identity, SCALE[Li] = 1, TSURF, angles
+    std::vector<int32_t> hi(1 + Li);
+    hi[0] = Li;
+    for (int j = 0; j < Li; ++j) hi[1 + j] = j;
+    std::vector<double> hd(Li + 3, 1.0);
+    hd[Li] = TSURF; hd[Li + 1] = SOL_ANG; hd[Li + 2] = EMISS_ANG;
+    const void *di, *dd;
+    if ((rc = h2d(ctx, ctx->hb[8], hi.data(), hi.size() * sizeof(int32_t), &di))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[9], hd.data(), hd.size() * D, &dd))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // hi/hd are stack-lifetime host buffers
+    // TAUTOT_PATH[W][G][Li] -> tau[Li][G][Wpad]
+    const size_t ntau = (size_t)Li * G * Wpad;
+    HIPCHK(ctx->misc.reserve(ntau * D));
+    hipLaunchKernelGGL(k_w_to_last, dim3(nblk(ntau, 256)), dim3(256), 0, ctx->stream, (const double *)d[0],
+                       ctx->misc.as<double>(), W, Wpad, G, Li, 1, 0.0);
+    const double *emi_t = nullptr;
+    if (d[1]) {
+        HIPCHK(ctx->cont_t.reserve((size_t)Li * Wpad * D));
+        hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)Li * Wpad, 256)), dim3(256), 0, ctx->stream,
+                           (const double *)d[1], ctx->cont_t.as<double>(), W, Wpad, 1, Li, 0, 0.0);
+        emi_t = ctx->cont_t.as<double>();
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(ctx->tmp_out.reserve((size_t)W * G * D));
+    RtParams r;
+    memset(&r, 0, sizeof r);
+    r.tau = ctx->misc.as<double>();
+    r.cont = nullptr;
+    r.emi = emi_t;
+    r.wave = (const double *)d[4];
+    r.delg = nullptr;
+    r.nlayin = (const int32_t *)di;
+    r.layinc = (const int32_t *)di + 1;
+    r.scale = (const double *)dd;
+    r.emtemp = (const double *)d[2];
+    r.lay_press = (const double *)d[3];
+    r.tsurf = (const double *)dd + Li;
+    r.emissivity = (const double *)d[5]; r.solflux = (const double *)d[6]; r.reflectance = (const double *)d[7];
+    r.xfac = nullptr;
+    r.sol_ang = (const double *)dd + Li + 1; r.emiss_ang = (const double *)dd + Li + 2;
+    r.out = ctx->tmp_out.as<double>();
+    r.W = W; r.Wpad = Wpad; r.G = G; r.L = Li; r.P = 1; r.LIMAX = Li; r.ispace = ISPACE; r.per_g = 1;
+    rc = launch_rt(ctx, r, 1);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(SPECOUT, ctx->tmp_out.p, (size_t)W * G * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+}  // extern "C"

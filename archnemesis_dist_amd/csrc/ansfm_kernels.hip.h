@@ -1,0 +1,564 @@
+// ansfm_kernels.hip.h -- gfx950 kernels of the correlated-k thermal-emission hot path.
+//
+// Data layout in HBM (all float64, "wave fastest" so that a wavefront = 64 consecutive
+// wavenumbers reads/writes 512 contiguous bytes):
+//   lnK    [NP][NT][S][G][Wpad]   ln k for k>0; k<=0 stored NaN-boxed (see encode_lnk)
+//   tau    [n][L][G][Wpad]        vertical gas opacity per model/layer/g
+//   cont   [n][L][Wpad]           continuum opacity (TAUCIA+TAUDUST+TAURAY), transposed on upload
+// Wpad = W rounded up to 64; pad lanes carry k=0 and are never written back to the caller.
+//
+// Reference seams restated here (paths relative to the reference tree):
+//   Spectroscopy_0.calc_k/calc_kg            Spectroscopy_0.py:2298-2437 / :2147-2295
+//   ForwardModel_0.k_overlap / rank           ForwardModel_0.py:6029-6173
+//   ForwardModel_0.calculate_layer_opacity    ForwardModel_0.py:3989, :4006
+//   ForwardModel_0.calc_thermal_emission_spectrum / planck   ForwardModel_0.py:6287-6377 / :6183
+//   ForwardModel_0.CIRSrad g-quadrature       ForwardModel_0.py:4504
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ansfm {
+
+constexpr int kWave = 64;
+constexpr int kMaxG = 32;
+
+// ------------------------------------------------------------------------------------------------
+// ln-k table encoding.  k > 0  -> ln k (finite double)
+//                       k <= 0 -> quiet NaN whose 51 payload bits are the top 51 bits of k
+// (sign, exponent, 39 mantissa bits: exact for tables that were float32 on disk).  The
+// good/bad/mixed corner logic of calc_k (Spectroscopy_0.py:2391-2403) needs the sign and, for the
+// all-non-positive "bad" branch, the raw value.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double encode_lnk(double k)
+{
+    if (k > 0.0) return log(k);
+    unsigned long long b = (unsigned long long)__double_as_longlong(k);
+    unsigned long long box = 0x7FF8000000000000ULL | (b >> 13);
+    return __longlong_as_double((long long)box);
+}
+__device__ __forceinline__ bool lnk_is_boxed(double x) { return x != x; }
+__device__ __forceinline__ double lnk_unbox(double x)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return __longlong_as_double((long long)((b & 0x0007FFFFFFFFFFFFULL) << 13));
+}
+
+// Per (model, layer) interpolation constants: the nearest-then-bracket corner choice of calc_k
+// (Spectroscopy_0.py:2336-2389) is wave-uniform, so it is computed once per layer.
+struct LayerInterp {
+    int ipl, iph, itl, ith;
+    double v, u, dudt;
+};
+
+__global__ void k_layer_prep(int n_layers_total, const double *__restrict__ lay_press_pa,
+                             const double *__restrict__ lay_temp, int NP,
+                             const double *__restrict__ PRESS, int NT,
+                             const double *__restrict__ TEMP, double press_div,
+                             LayerInterp *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_layers_total) return;
+    double press1 = lay_press_pa[i] / press_div;  // LayerX.PRESS/ATM_TO_PASCAL  ForwardModel_0.py:3855
+    double temp1 = lay_temp[i];
+    int ip = 0;
+    double best = fabs(PRESS[0] - press1);
+    for (int k = 1; k < NP; ++k) {
+        double d = fabs(PRESS[k] - press1);
+        if (d < best) { best = d; ip = k; }
+    }
+    int ipl, iph;
+    if (PRESS[ip] >= press1) {
+        iph = ip;
+        if (ip == 0) { press1 = PRESS[0]; ipl = 0; iph = 1; }
+        else ipl = ip - 1;
+    } else {
+        ipl = ip;
+        if (ip == NP - 1) { press1 = PRESS[NP - 1]; iph = NP - 1; ipl = NP - 2; }
+        else iph = ip + 1;
+    }
+    int it = 0;
+    best = fabs(TEMP[0] - temp1);
+    for (int k = 1; k < NT; ++k) {
+        double d = fabs(TEMP[k] - temp1);
+        if (d < best) { best = d; it = k; }
+    }
+    int itl, ith;
+    if (TEMP[it] >= temp1) {
+        ith = it;
+        if (it == 0) { temp1 = TEMP[0]; itl = 0; ith = 1; }
+        else itl = it - 1;
+    } else {
+        itl = it;
+        if (it == NT - 1) { temp1 = TEMP[NT - 1]; ith = NT - 1; itl = NT - 2; }
+        else ith = it + 1;
+    }
+    double lpress = log(press1), plo = log(PRESS[ipl]), phi = log(PRESS[iph]);
+    double tlo = TEMP[itl], thi = TEMP[ith];
+    LayerInterp r;
+    r.ipl = ipl; r.iph = iph; r.itl = itl; r.ith = ith;
+    r.v = (lpress - plo) / (phi - plo);
+    r.u = (temp1 - tlo) / (thi - tlo);
+    r.dudt = 1. / (thi - tlo);
+    out[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Table upload: K[W][G][NP][NT][S] (reference layout) -> lnK[NP][NT][S][G][Wpad].
+// One thread per destination element; also checks k>=0 and non-decreasing in g (flag[0] |= 1).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_table_relayout(const double *__restrict__ K, double *__restrict__ lnK, int W,
+                                 int Wpad, int G, int NP, int NT, int S, int *flag)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)NP * NT * S * G * Wpad;
+    if (idx >= total) return;
+    int w = (int)(idx % Wpad);
+    size_t r = idx / Wpad;
+    int g = (int)(r % G); r /= G;
+    int s = (int)(r % S); r /= S;
+    int t = (int)(r % NT);
+    int p = (int)(r / NT);
+    double k = 0.0;
+    if (w < W) {
+        size_t src = ((((size_t)w * G + g) * NP + p) * NT + t) * S + s;
+        k = K[src];
+        bool bad = !(k >= 0.0);
+        if (g > 0) {
+            double kprev = K[src - (size_t)NP * NT * S];
+            if (k < kprev) bad = true;
+        }
+        if (bad) atomicOr(flag, 1);
+    }
+    lnK[idx] = encode_lnk(k);
+}
+
+// k for one (corner set, u, v): Spectroscopy_0.py:2391-2403 (+ dk/dT :2241-2247 when wanted)
+__device__ __forceinline__ double interp_k(double l1, double l2, double h1, double h2, double v,
+                                           double u)
+{
+    // l1 = (ip_low,it_low)  l2 = (ip_low,it_high)  h1 = (ip_high,it_low)  h2 = (ip_high,it_high)
+    bool b1 = lnk_is_boxed(l1), b2 = lnk_is_boxed(l2), b3 = lnk_is_boxed(h1), b4 = lnk_is_boxed(h2);
+    double kk = 0.0;
+    if (!(b1 | b2 | b3 | b4)) {
+        double x = (1.0 - v) * (1.0 - u) * l1 + v * (1.0 - u) * h1 + v * u * h2 + (1.0 - v) * u * l2;
+        kk = exp(x);
+    } else if (b1 & b2 & b3 & b4) {
+        double klo1 = lnk_unbox(l1), klo2 = lnk_unbox(l2), khi1 = lnk_unbox(h1), khi2 = lnk_unbox(h2);
+        kk = (1.0 - v) * (1.0 - u) * klo1 + v * (1.0 - u) * khi1 + v * u * khi2 + (1.0 - v) * u * klo2;
+    }
+    return kk;
+}
+__device__ __forceinline__ void interp_kg(double l1, double l2, double h1, double h2, double v,
+                                          double u, double dudt, double &kk, double &dk)
+{
+    bool b1 = lnk_is_boxed(l1), b2 = lnk_is_boxed(l2), b3 = lnk_is_boxed(h1), b4 = lnk_is_boxed(h2);
+    kk = 0.0; dk = 0.0;
+    if (!(b1 | b2 | b3 | b4)) {
+        double x = (1.0 - v) * (1.0 - u) * l1 + v * (1.0 - u) * h1 + v * u * h2 + (1.0 - v) * u * l2;
+        kk = exp(x);
+        double dxdt = (-l1 * (1.0 - v) - h1 * v + h2 * v + l2 * (1.0 - v)) * dudt;
+        dk = kk * dxdt;
+    } else if (b1 & b2 & b3 & b4) {
+        double klo1 = lnk_unbox(l1), klo2 = lnk_unbox(l2), khi1 = lnk_unbox(h1), khi2 = lnk_unbox(h2);
+        kk = (1.0 - v) * (1.0 - u) * klo1 + v * (1.0 - u) * khi1 + v * u * khi2 + (1.0 - v) * u * klo2;
+        dk = (-klo1 * (1.0 - v) - khi1 * v + khi2 * v + klo2 * (1.0 - v)) * dudt;
+    }
+}
+
+// Array-level seam calc_k / calc_kg: writes the reference layout k[W][G][L][S] directly.
+__global__ void k_calc_k_seam(const double *__restrict__ lnK, int W, int Wpad, int G, int NT, int S,
+                              int L, const LayerInterp *__restrict__ li, double *__restrict__ k_out,
+                              double *__restrict__ dk_out)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)L * S * G * W;
+    if (idx >= total) return;
+    int w = (int)(idx % W);
+    size_t r = idx / W;
+    int g = (int)(r % G); r /= G;
+    int s = (int)(r % S);
+    int l = (int)(r / S);
+    LayerInterp q = li[l];
+    size_t strideT = (size_t)S * G * Wpad;
+    size_t off = ((size_t)s * G + g) * Wpad + w;
+    double l1 = lnK[((size_t)q.ipl * NT + q.itl) * strideT + off];
+    double l2 = lnK[((size_t)q.ipl * NT + q.ith) * strideT + off];
+    double h1 = lnK[((size_t)q.iph * NT + q.itl) * strideT + off];
+    double h2 = lnK[((size_t)q.iph * NT + q.ith) * strideT + off];
+    double kk, dk;
+    interp_kg(l1, l2, h1, h2, q.v, q.u, q.dudt, kk, dk);
+    size_t o = (((size_t)w * G + g) * L + l) * S + s;
+    k_out[o] = kk;
+    if (dk_out) dk_out[o] = dk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1+K2 fused: (P,T) interpolation + random-overlap merge.   "ck_overlap"
+//
+// One LANE per (wavenumber, layer) cell; a wavefront = 64 consecutive wavenumbers of ONE layer, so
+// corner indices, u, v and gas amounts are wave-uniform (SGPRs) and every table access is one
+// 512-byte coalesced row.  The reference sorts the G*G sums tau_i + k_j*amount (argsort) and
+// walks the sorted list once to re-bin it (rank, ForwardModel_0.py:6117-6173).  Both inputs are
+// already sorted in g, so the sorted sequence is produced by a G-way streaming merge of the rows
+// (a_i + b_0..b_{G-1}) with a loser tree, and rank's walk consumes it on the fly: nothing of size
+// G*G is ever stored.  Per-lane state (a[G], b[G], tree nodes) lives in LDS as [index][lane], so a
+// lane-dependent index never causes a bank conflict (bank depends on the lane only).
+//
+// LDS per wave: G*64*(8+8+8+4) bytes (+ shared del_g / g_ord tables)  -> 35 KiB at G=20.
+// ------------------------------------------------------------------------------------------------
+struct OverlapParams {
+    const double *lnK;        // [NP][NT][S][G][Wpad]            (FROM_K: unused)
+    const double *kin;        // FROM_K: k[S][L][G][Wpad] (array-level k_overlap seam)
+    const LayerInterp *li;    // [n][L]
+    const double *amount;     // [n][S][L]
+    const double *del_g;      // [G]
+    double *tau;              // [n][L][G][Wpad]
+    double *scratch;          // [gridDim.x][2][G][64]
+    int *err_flag;            // bit0: unsorted input k-distribution
+    int W, Wpad, G, NT, S, L, n_models, depth;
+    unsigned char init_loser[kMaxG];
+};
+
+template <bool FROM_K>
+__device__ __forceinline__ void load_gas(const OverlapParams &p, const LayerInterp &q, int m, int l,
+                                         int s, int nu, double *DST, int lane, bool &unsorted)
+{
+    const int G = p.G;
+    const double amt = p.amount[((size_t)m * p.S + s) * p.L + l];
+    double prev = -__builtin_inf();
+    if constexpr (FROM_K) {
+        const double *src = p.kin + (((size_t)s * p.L + l) * G) * p.Wpad + nu;
+        for (int g = 0; g < G; ++g) {
+            double kk = src[(size_t)g * p.Wpad] * amt;
+            DST[g * kWave + lane] = kk;
+            unsorted |= (kk < prev);
+            prev = kk;
+        }
+    } else {
+        const size_t strideT = (size_t)p.S * G * p.Wpad;
+        const size_t off = (size_t)s * G * p.Wpad + nu;
+        const double *c1 = p.lnK + ((size_t)q.ipl * p.NT + q.itl) * strideT + off;
+        const double *c2 = p.lnK + ((size_t)q.ipl * p.NT + q.ith) * strideT + off;
+        const double *c3 = p.lnK + ((size_t)q.iph * p.NT + q.itl) * strideT + off;
+        const double *c4 = p.lnK + ((size_t)q.iph * p.NT + q.ith) * strideT + off;
+        for (int g = 0; g < G; ++g) {
+            size_t go = (size_t)g * p.Wpad;
+            double kk = interp_k(c1[go], c2[go], c3[go], c4[go], q.v, q.u) * amt;
+            DST[g * kWave + lane] = kk;
+            unsorted |= (kk < prev);
+            prev = kk;
+        }
+    }
+}
+
+template <int DEPTH, bool FROM_K>
+__global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
+{
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int G = p.G;
+    double *A = smem;
+    double *B = A + G * kWave;
+    double *NV = B + G * kWave;
+    uint32_t *NIP = reinterpret_cast<uint32_t *>(NV + G * kWave);
+    double *DG = reinterpret_cast<double *>(NIP + G * kWave);
+    double *GORD = DG + kMaxG;
+    // shared tables: del_g and g_ord = [0, cumsum(del_g)], g_ord[G] = 1   (ForwardModel_0.py:6141-6143)
+    if (lane < G) DG[lane] = p.del_g[lane];
+    if (lane == 0) {
+        double acc = 0.0;
+        GORD[0] = 0.0;
+        for (int g = 0; g < G; ++g) { acc += p.del_g[g]; GORD[g + 1] = acc; }
+        GORD[G] = 1.0;
+        GORD[G + 1] = __builtin_inf();
+    }
+    __syncthreads();
+    double wsum = 0.0;
+    for (int g = 0; g < G; ++g) wsum += DG[g];
+    const double wtot = wsum * wsum;  // stands in for gdist[-1] (python wrap at iloop==0)
+
+    double *scrK = p.scratch + (size_t)blockIdx.x * 2 * G * kWave;
+    double *scrS = scrK + G * kWave;
+    const int NVT = p.Wpad / kWave;
+    const long ntiles = (long)p.n_models * NVT * p.L;
+    const double INF = __builtin_inf();
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int l = (int)(tile % p.L);
+        const long r = tile / p.L;
+        const int vt = (int)(r % NVT);
+        const int m = (int)(r / NVT);
+        const int nu = vt * kWave + lane;
+        LayerInterp q;
+        if constexpr (!FROM_K) q = p.li[(size_t)m * p.L + l];
+        bool unsorted = false;
+
+        load_gas<FROM_K>(p, q, m, l, 0, nu, A, lane, unsorted);
+        for (int s = 1; s < p.S; ++s) {
+            load_gas<FROM_K>(p, q, m, l, s, nu, B, lane, unsorted);
+            const double alast = A[(G - 1) * kWave + lane];
+            const double blast = B[(G - 1) * kWave + lane];
+            // skip rules, cutoff = 0  (ForwardModel_0.py:6073-6102)
+            bool takeB, keepA;
+            if (s == 1) { takeB = (alast <= 0.0); keepA = !takeB && (blast <= 0.0); }
+            else { keepA = (blast <= 0.0); takeB = !keepA && (alast <= 0.0); }
+            const bool do_merge = !(takeB | keepA);
+            if (takeB)
+                for (int g = 0; g < G; ++g) A[g * kWave + lane] = B[g * kWave + lane];
+            if (do_merge) {
+                // ---- loser tree over the G rows (row i = a_i + b_j, j ascending) ----------------
+                const double b0 = B[lane];
+                for (int x = 1; x < G; ++x) {
+                    const int row = p.init_loser[x];
+                    NV[x * kWave + lane] = A[row * kWave + lane] + b0;
+                    NIP[x * kWave + lane] = (uint32_t)row;
+                }
+                NV[lane] = INF;
+                NIP[lane] = 0u;
+                for (int g = 0; g < G; ++g) { scrK[g * kWave + lane] = 0.0; scrS[g * kWave + lane] = 1.0; }
+                double cv = A[lane] + b0;  // current winner: value, row, column
+                int ci = 0, cp = 0;
+                // ---- rank() walk state -----------------------------------------------------------
+                double gd = 0.0, kacc = 0.0, sum1 = 0.0, gnext = GORD[1];
+                int ig = 0;
+                const int nloop = G * G;
+                for (int it = 0; it < nloop; ++it) {
+                    const double w = DG[ci] * DG[cp < G ? cp : G - 1];
+                    // advance the winner's row
+                    const int np = cp + 1;
+                    const int npc = np < G ? np : G - 1;
+                    const double ai = A[ci * kWave + lane];
+                    const double bn = B[npc * kWave + lane];
+                    const int x0 = (G + ci) >> 1;
+                    double tv[DEPTH];
+                    uint32_t tip[DEPTH];
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) {
+                        const int xx = x0 >> d;
+                        tv[d] = NV[xx * kWave + lane];
+                        tip[d] = NIP[xx * kWave + lane];
+                    }
+                    // rank walk on element (cv, w)        ForwardModel_0.py:6155-6170
+                    const double gdn = gd + w;
+                    const double cw = cv * w;
+                    if (ig < G) {
+                        if (gdn < gnext) {
+                            kacc += cw;
+                            sum1 += w;
+                        } else {
+                            const double gprev = (it == 0) ? wtot : gd;
+                            const double frac = (gnext - gprev) / (gdn - gprev);
+                            scrK[ig * kWave + lane] = kacc + frac * cw;
+                            scrS[ig * kWave + lane] = sum1 + frac * w;
+                            ig += 1;
+                            sum1 = (1.0 - frac) * w;
+                            kacc = (1.0 - frac) * cw;
+                            gnext = GORD[ig + 1];
+                        }
+                    }
+                    gd = gdn;
+                    // replay the tree path of leaf ci
+                    double carv = (np < G) ? (ai + bn) : INF;
+                    uint32_t carip = (uint32_t)ci | ((uint32_t)np << 8);
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) {
+                        const int xx = x0 >> d;
+                        const bool sw = (xx != 0) & (tv[d] < carv);
+                        const double nv = sw ? carv : tv[d];
+                        const uint32_t ni = sw ? carip : tip[d];
+                        carv = sw ? tv[d] : carv;
+                        carip = sw ? tip[d] : carip;
+                        NV[xx * kWave + lane] = nv;
+                        NIP[xx * kWave + lane] = ni;
+                    }
+                    cv = carv;
+                    ci = (int)(carip & 0xffu);
+                    cp = (int)(carip >> 8);
+                }
+                // trailing `if ig == ng-1` (ForwardModel_0.py:6171); an unfinished earlier bin stays
+                // un-normalised exactly like the reference leaves it
+                if (ig < G) {
+                    scrK[ig * kWave + lane] = kacc;
+                    scrS[ig * kWave + lane] = (ig == G - 1) ? sum1 : 1.0;
+                }
+                for (int g = 0; g < G; ++g)
+                    A[g * kWave + lane] = scrK[g * kWave + lane] / scrS[g * kWave + lane];
+            }
+        }
+        if (unsorted) atomicOr(p.err_flag, 1);
+        double *out = p.tau + (((size_t)m * p.L + l) * G) * p.Wpad + nu;
+        for (int g = 0; g < G; ++g) out[(size_t)g * p.Wpad] = A[g * kWave + lane];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3+K4+K5+K6 fused: total opacity, LAYINC gather * SCALE, layer loop with Planck emission,
+// ground / solar terms, unit factor and g-quadrature.   "thermal_rt"
+// Block = 64 wavenumbers x GY g-groups; thread (lane, gy) integrates g = gy, gy+GY, ...
+// ------------------------------------------------------------------------------------------------
+constexpr int kGY = 4;
+constexpr int kGPer = kMaxG / kGY;  // 8
+
+struct RtParams {
+    const double *tau;      // [n][L][G][Wpad]
+    const double *cont;     // [n][L][Wpad] or nullptr
+    const double *emi;      // [Li][Wpad] or nullptr  (array-level seam only)
+    const double *wave;     // [W]
+    const double *delg;     // [G]
+    const int32_t *nlayin;  // [P]
+    const int32_t *layinc;  // [LIMAX][P]
+    const double *scale;    // [n][LIMAX][P]
+    const double *emtemp;   // [n][LIMAX][P]
+    const double *lay_press;// [n][L]  (Pa)
+    const double *tsurf;    // [n]
+    const double *emissivity, *solflux, *reflectance, *xfac;  // [W] or nullptr
+    const double *sol_ang, *emiss_ang;                        // [P] or nullptr
+    double *out;            // per_g ? [n][W][G] : [n][W][P]
+    int W, Wpad, G, L, P, LIMAX, ispace, per_g;
+};
+
+__device__ __forceinline__ double planck_bb(double a, double c2y, double T)
+{
+    return a / (exp(c2y / T) - 1.0);  // ForwardModel_0.py:6223-6225
+}
+
+__global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
+{
+    __shared__ double red[kGY][kWave];
+    const int lane = threadIdx.x, gy = threadIdx.y;
+    const int nu = blockIdx.x * kWave + lane;
+    const int nuc = nu < p.W ? nu : p.W - 1;
+    const int ip = blockIdx.y, m = blockIdx.z;
+    const int nl = p.nlayin[ip];
+    const int G = p.G;
+    const double c1 = 1.1911e-12, c2 = 1.439;  // ForwardModel_0.py:6214-6215
+    const double wv = p.wave[nuc];
+    double y, a;
+    if (p.ispace == 0) { y = wv; a = c1 * (y * y * y); }
+    else { y = 1.0e4 / wv; a = c1 * (y * y * y * y * y) / 1.0e4; }
+    const double c2y = c2 * y;
+
+    double taud[kGPer], trold[kGPer], spec[kGPer];
+#pragma unroll
+    for (int k = 0; k < kGPer; ++k) { taud[k] = 0.0; trold[k] = 1.0; spec[k] = 0.0; }
+
+    const size_t pathbase = (size_t)m * p.LIMAX * p.P + ip;
+    for (int j = 0; j < nl; ++j) {
+        const int lay = p.layinc[(size_t)j * p.P + ip];
+        const double sc = p.scale[pathbase + (size_t)j * p.P];
+        const double T = p.emtemp[pathbase + (size_t)j * p.P];
+        const double tc = p.cont ? p.cont[((size_t)m * p.L + lay) * p.Wpad + nu] : 0.0;
+        const double bb = planck_bb(a, c2y, T);
+        const double em = p.emi ? p.emi[(size_t)j * p.Wpad + nu] : 0.0;
+        const double *trow = p.tau + (((size_t)m * p.L + lay) * G) * p.Wpad + nu;
+#pragma unroll
+        for (int k = 0; k < kGPer; ++k) {
+            const int g = gy + k * kGY;
+            if (g < G) {
+                const double t = (trow[(size_t)g * p.Wpad] + tc) * sc;  // :3989, :4006
+                taud[k] += t;
+                const double tr = exp(-taud[k]);
+                spec[k] += (trold[k] - tr) * bb;  // :6345-6348
+                if (p.emi) spec[k] += em * tr;
+                trold[k] = tr;
+            }
+        }
+    }
+    // surface / bottom-of-atmosphere term  (:6354-6365)
+    int i1 = (int)(nl / 2.0) - 1;
+    if (i1 < 0) i1 += nl;
+    const double *lp = p.lay_press + (size_t)m * p.L;
+    const double p1 = lp[p.layinc[(size_t)i1 * p.P + ip]];
+    const double p2 = lp[p.layinc[(size_t)(nl - 1) * p.P + ip]];
+    double radground = 0.0;
+    const bool ground = p2 > p1;
+    if (ground) {
+        const double ts = p.tsurf[m];
+        if (ts <= 0.0) radground = planck_bb(a, c2y, p.emtemp[pathbase + (size_t)(nl - 1) * p.P]);
+        else radground = planck_bb(a, c2y, ts) * (p.emissivity ? p.emissivity[nuc] : 0.0);
+    }
+    const double sola = p.sol_ang ? p.sol_ang[ip] : 180.0;
+    const double emia = p.emiss_ang ? p.emiss_ang[ip] : 180.0;
+    const bool solar_on = (emia < 90.) && (sola < 90.);
+    double solterm = 0.0, muratio = 0.0;
+    if (solar_on) {
+        const double PI = 3.141592653589793;
+        const double mu = cos(emia / 180. * PI), mu0 = cos(sola / 180. * PI);
+        muratio = mu / mu0;
+        solterm = (p.solflux ? p.solflux[nuc] : 0.0) * (p.reflectance ? p.reflectance[nuc] : 0.0);
+    }
+    const double xf = p.xfac ? p.xfac[nuc] : 1.0;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < kGPer; ++k) {
+        const int g = gy + k * kGY;
+        if (g < G) {
+            double s = spec[k];
+            if (ground) s += trold[k] * radground;
+            if (solar_on) s += trold[k] * exp(-taud[k] * muratio) * solterm;  // :6368-6373
+            s = s * xf;                                                       // :4244
+            if (p.per_g) {
+                if (nu < p.W) p.out[((size_t)m * p.W + nu) * G + g] = s;
+            } else {
+                acc += s * p.delg[g];                                         // :4504
+            }
+        }
+    }
+    if (!p.per_g) {
+        red[gy][lane] = acc;
+        __syncthreads();
+        if (gy == 0 && nu < p.W) {
+            double t = red[0][lane];
+#pragma unroll
+            for (int k = 1; k < kGY; ++k) t += red[k][lane];
+            p.out[((size_t)m * p.W + nu) * p.P + ip] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout helpers (host-pointer seams): src[W][X1][X2] -> dst[(x1,x2 or x2,x1)][Wpad]
+// ------------------------------------------------------------------------------------------------
+__global__ void k_w_to_last(const double *__restrict__ src, double *__restrict__ dst, int W, int Wpad,
+                            int X1, int X2, int swap12, double padval)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)X1 * X2 * Wpad;
+    if (idx >= total) return;
+    int w = (int)(idx % Wpad);
+    size_t r = idx / Wpad;
+    int x1, x2;
+    if (swap12) { x1 = (int)(r % X1); x2 = (int)(r / X1); }
+    else { x2 = (int)(r % X2); x1 = (int)(r / X2); }
+    dst[idx] = (w < W) ? src[((size_t)w * X1 + x1) * X2 + x2] : padval;
+}
+// src[X1][X2][Wpad] -> dst[W][X1][X2]  (swap12: dst[W][X2][X1])
+__global__ void k_w_to_first(const double *__restrict__ src, double *__restrict__ dst, int W, int Wpad,
+                             int X1, int X2, int swap12)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)W * X1 * X2;
+    if (idx >= total) return;
+    int w = (int)(idx / ((size_t)X1 * X2));
+    int r = (int)(idx % ((size_t)X1 * X2));
+    int x1, x2;
+    if (swap12) { x1 = r % X1; x2 = r / X1; }
+    else { x2 = r % X2; x1 = r / X2; }
+    dst[idx] = src[((size_t)x1 * X2 + x2) * Wpad + w];
+}
+// k[W][G][L][S] (reference layout) -> kin[S][L][G][Wpad]
+__global__ void k_kin_permute(const double *__restrict__ src, double *__restrict__ dst, int W, int Wpad,
+                              int G, int L, int S)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)S * L * G * Wpad;
+    if (idx >= total) return;
+    int w = (int)(idx % Wpad);
+    size_t r = idx / Wpad;
+    int g = (int)(r % G); r /= G;
+    int l = (int)(r % L);
+    int s = (int)(r / L);
+    dst[idx] = (w < W) ? src[(((size_t)w * G + g) * L + l) * S + s] : 0.0;
+}
+
+}  // namespace ansfm

@@ -1,0 +1,167 @@
+"""AnsfmEngine: one context per GPU around libansfm.so (see include/ansfm.h).
+
+Host-array methods take/return NumPy arrays in the reference's layouts (drop-in for the numba
+seams); `*_dev` methods take torch CUDA(HIP) tensors already resident in HBM and run
+asynchronously on the engine's stream.  torch is plumbing only (device memory, streams).
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+
+_f8 = np.float64
+
+
+def _np(a, dtype=_f8):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a.data_ptr())  # torch tensor
+
+
+class AnsfmEngine:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        rc = self._lib.ansfm_create(int(device), C.byref(self._ctx))
+        if rc != 0:
+            raise _lib.AnsfmError(f"ansfm_create(device={device}) failed ({_lib.ERR_NAMES.get(rc, rc)}): "
+                                  "no usable HIP device; there is no CPU fallback")
+        self.device = int(device)
+        self.dims = None
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.ansfm_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.ansfm_last_error(self._ctx)
+            msg = msg.decode() if msg else ""
+            exc = ValueError if rc in (1, 4) else (NotImplementedError if rc == 5 else _lib.AnsfmError)
+            raise exc(f"{what}: {_lib.ERR_NAMES.get(rc, rc)}: {msg}")
+
+    # ---- stream -------------------------------------------------------------------------------
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._lib.ansfm_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or 0)), "set_stream")
+
+    def synchronize(self):
+        self._check(self._lib.ansfm_synchronize(self._ctx), "synchronize")
+
+    # ---- k-table ------------------------------------------------------------------------------
+    def upload_ktable(self, K, PRESS, TEMP, WAVE, DELG):
+        """K (W,G,NP,NT,S) float64: NumPy array (host) or torch CUDA tensor (device)."""
+        PRESS = _np(PRESS); TEMP = _np(TEMP); WAVE = _np(WAVE); DELG = _np(DELG)
+        W, G, NP, NT, S = (int(x) for x in K.shape)
+        assert PRESS.shape == (NP,) and TEMP.shape == (NT,) and WAVE.shape == (W,) and DELG.shape == (G,)
+        if isinstance(K, np.ndarray):
+            K = _np(K)
+            rc = self._lib.ansfm_upload_ktable(self._ctx, W, G, NP, NT, S, _ptr(K), _ptr(PRESS), _ptr(TEMP),
+                                               _ptr(WAVE), _ptr(DELG))
+        else:
+            assert K.is_contiguous() and K.dtype.is_floating_point and K.element_size() == 8
+            rc = self._lib.ansfm_upload_ktable_dev(self._ctx, W, G, NP, NT, S, _ptr(K), _ptr(PRESS), _ptr(TEMP),
+                                                   _ptr(WAVE), _ptr(DELG))
+        self._check(rc, "upload_ktable")
+        self.dims = (W, G, NP, NT, S)
+        self.WAVE, self.DELG = WAVE, DELG
+
+    def ktable_info(self):
+        dims = (C.c_int64 * 5)()
+        mono = C.c_int()
+        self._check(self._lib.ansfm_ktable_info(self._ctx, dims, C.byref(mono)), "ktable_info")
+        return tuple(int(d) for d in dims), bool(mono.value)
+
+    # ---- array-level seams --------------------------------------------------------------------
+    def calc_k(self, press, temp, grad=False):
+        press = _np(press); temp = _np(temp)
+        W, G, NP, NT, S = self.dims
+        L = press.shape[0]
+        k = np.empty((W, G, L, S)); dk = np.empty((W, G, L, S)) if grad else None
+        self._check(self._lib.ansfm_calc_k(self._ctx, L, _ptr(press), _ptr(temp), _ptr(k), _ptr(dk)), "calc_k")
+        return (k, dk) if grad else k
+
+    def k_overlap(self, del_g, k_w_g_l_gas, amount_layer):
+        del_g = _np(del_g); k = _np(k_w_g_l_gas); am = _np(amount_layer)
+        W, G, L, S = k.shape
+        if am.shape != (S, L):
+            raise ValueError("amount_layer must be (NGAS, NLAYER)")
+        tau = np.empty((W, G, L))
+        self._check(self._lib.ansfm_k_overlap(self._ctx, W, G, L, S, _ptr(del_g), _ptr(k), _ptr(am), _ptr(tau)),
+                    "k_overlap")
+        return tau
+
+    def calc_thermal_emission_spectrum(self, ISPACE, WAVE, TAUTOT_PATH, EMITOT_PATH, TEMP, PRESS, TSURF,
+                                       EMISSIVITY, SOLFLUX, REFLECTANCE, SOL_ANG, EMISS_ANG):
+        WAVE = _np(WAVE); TAU = _np(TAUTOT_PATH); EMI = _np(EMITOT_PATH)
+        W, G, Li = TAU.shape
+        out = np.empty((W, G))
+        rc = self._lib.ansfm_thermal_emission(self._ctx, int(ISPACE), W, G, Li, _ptr(WAVE), _ptr(TAU), _ptr(EMI),
+                                              _ptr(_np(TEMP)), _ptr(_np(PRESS)), float(TSURF),
+                                              _ptr(_np(EMISSIVITY)), _ptr(_np(SOLFLUX)), _ptr(_np(REFLECTANCE)),
+                                              float(SOL_ANG), float(EMISS_ANG), _ptr(out))
+        self._check(rc, "thermal_emission")
+        return out
+
+    # ---- fused CIRSrad (batch) ----------------------------------------------------------------
+    def cirsrad_ck_thermal(self, ISPACE, lay_press_pa, lay_temp, amount, taucont, NLAYIN, LAYINC, SCALE, EMTEMP,
+                           TSURF, EMISSIVITY=None, SOLFLUX=None, REFLECTANCE=None, SOL_ANG=None, EMISS_ANG=None,
+                           xfac=None):
+        """Host arrays; leading model axis optional.  Returns SPECOUT (n,W,P) (or (W,P))."""
+        W, G, NP, NT, S = self.dims
+        lay_press_pa = _np(lay_press_pa)
+        single = lay_press_pa.ndim == 1
+        lp = np.atleast_2d(lay_press_pa); n, L = lp.shape
+        lt = _np(np.atleast_2d(_np(lay_temp)))
+        am = _np(amount).reshape(n, S, L)
+        tc = None if taucont is None else _np(taucont).reshape(n, W, L)
+        LAYINC = _np(LAYINC, np.int32); NLAYIN = _np(np.atleast_1d(NLAYIN), np.int32)
+        if LAYINC.ndim == 1:
+            LAYINC = LAYINC[:, None]
+        LIMAX, P = LAYINC.shape
+        SC = _np(np.broadcast_to(_np(SCALE).reshape(-1, LIMAX, P), (n, LIMAX, P)))
+        ET = _np(np.broadcast_to(_np(EMTEMP).reshape(-1, LIMAX, P), (n, LIMAX, P)))
+        TS = _np(np.broadcast_to(np.atleast_1d(_np(TSURF)), (n,)))
+        out = np.empty((n, W, P))
+        rc = self._lib.ansfm_cirsrad_ck_thermal(
+            self._ctx, int(ISPACE), n, L, _ptr(lp), _ptr(lt), _ptr(am), _ptr(tc), P, LIMAX, _ptr(NLAYIN),
+            _ptr(LAYINC), _ptr(SC), _ptr(ET), _ptr(TS), _ptr(_np(EMISSIVITY)), _ptr(_np(SOLFLUX)),
+            _ptr(_np(REFLECTANCE)), _ptr(None if SOL_ANG is None else _np(np.atleast_1d(SOL_ANG))),
+            _ptr(None if EMISS_ANG is None else _np(np.atleast_1d(EMISS_ANG))), _ptr(_np(xfac)), _ptr(out))
+        self._check(rc, "cirsrad_ck_thermal")
+        return out[0] if single else out
+
+    def cirsrad_ck_thermal_dev(self, ISPACE, n_models, L, lay_press_pa, lay_temp, amount, taucont, P, LIMAX,
+                               NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY, SOLFLUX, REFLECTANCE, SOL_ANG,
+                               EMISS_ANG, xfac, SPECOUT):
+        """All arguments torch device tensors (or None where optional); asynchronous."""
+        rc = self._lib.ansfm_cirsrad_ck_thermal_dev(
+            self._ctx, int(ISPACE), int(n_models), int(L), _ptr(lay_press_pa), _ptr(lay_temp), _ptr(amount),
+            _ptr(taucont), int(P), int(LIMAX), _ptr(NLAYIN), _ptr(LAYINC), _ptr(SCALE), _ptr(EMTEMP), _ptr(TSURF),
+            _ptr(EMISSIVITY), _ptr(SOLFLUX), _ptr(REFLECTANCE), _ptr(SOL_ANG), _ptr(EMISS_ANG), _ptr(xfac),
+            _ptr(SPECOUT))
+        self._check(rc, "cirsrad_ck_thermal_dev")
+
+    def get_taugas(self, L, model=0):
+        W, G = self.dims[0], self.dims[1]
+        out = np.empty((W, G, L))
+        self._check(self._lib.ansfm_get_taugas(self._ctx, int(model), _ptr(out)), "get_taugas")
+        return out
+
+    def last_kernel_ms(self):
+        a = C.c_double(); b = C.c_double(); na = C.c_int(); nb = C.c_int()
+        self._check(self._lib.ansfm_last_kernel_ms(self._ctx, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)),
+                    "last_kernel_ms")
+        return {"overlap_ms": a.value, "overlap_launches": na.value, "rt_ms": b.value, "rt_launches": nb.value}

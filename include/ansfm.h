@@ -1,0 +1,139 @@
+/*
+ * ansfm.h -- C-ABI of libansfm.so: the MI355X (gfx950) forward-model engine for the
+ * archNEMESIS radiative-transfer hot path.
+ *
+ * The reference (pure Python + numba) has no FFI; its seams are Python-level.
+ * Every entry point below replaces one of those seams and cites it (paths relative to the
+ * reference tree).  INTEGRATION.md shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - plain pointers + sizes, row-major (C order) float64 unless stated; int32 index arrays
+ *  - enum-like ints carry the reference's IntEnum values (ISPACE: 0 wavenumber, 1 wavelength)
+ *  - every function returns ANSFM_OK (0) or an error code; ansfm_last_error(ctx) gives the text
+ *  - caller owns every array it passes; outputs are caller-allocated; the library never frees
+ *    caller memory; device buffers (k-table, workspaces) are owned by the opaque ctx
+ *  - one ctx per GPU; a ctx is not re-entrant, different ctx may be used from different threads
+ *  - functions without suffix take HOST pointers (drop-in for the NumPy seams); `_dev` variants
+ *    take DEVICE pointers (HBM-resident batches, what bench.py times) and run asynchronously on
+ *    the ctx stream
+ *  - there is NO CPU fallback: without a usable HIP device ansfm_create() fails
+ */
+#ifndef ANSFM_H
+#define ANSFM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANSFM_ABI_VERSION 1
+
+#define ANSFM_OK 0
+#define ANSFM_ERR_INVALID 1     /* bad argument / shape                                  */
+#define ANSFM_ERR_HIP 2         /* HIP runtime error (text in ansfm_last_error)          */
+#define ANSFM_ERR_NOTABLE 3     /* k-table not uploaded                                  */
+#define ANSFM_ERR_UNSORTED 4    /* k-distribution not non-decreasing in g*/
+#define ANSFM_ERR_UNSUPPORTED 5 /* valid in the reference, not built yet                 */
+
+#define ANSFM_MAX_NG 32
+
+typedef struct ansfm_ctx ansfm_ctx;
+
+int ansfm_abi_version(void);
+
+/* Create / destroy the per-GPU context (device ordinal as in hipSetDevice). */
+int ansfm_create(int device, ansfm_ctx **ctx);
+void ansfm_destroy(ansfm_ctx *ctx);
+const char *ansfm_last_error(const ansfm_ctx *ctx);
+
+/* Use an external hipStream_t (e.g. torch's current stream) for all subsequent work; NULL
+ * restores the ctx-owned stream. */
+int ansfm_set_stream(ansfm_ctx *ctx, void *hip_stream);
+int ansfm_synchronize(ansfm_ctx *ctx);
+
+/* ---- k-table ------------------------------------------------------------------------------
+ * Replaces the state filled by Spectroscopy_0.read_tables (Spectroscopy_0.py:1448-1516):
+ * K[W][G][NP][NT][S] (:213), PRESS[NP] (atm), TEMP[NT] (K), WAVE[W], DELG[G].
+ * The table is re-laid out in HBM as ln k, [p][T][gas][g][wave] (wave fastest), float64.
+ * `_dev`: K is a device pointer (same reference layout); the small vectors stay host pointers. */
+int ansfm_upload_ktable(ansfm_ctx *ctx, int W, int G, int NP, int NT, int S, const double *K,
+                        const double *PRESS, const double *TEMP, const double *WAVE,
+                        const double *DELG);
+int ansfm_upload_ktable_dev(ansfm_ctx *ctx, int W, int G, int NP, int NT, int S,
+                            const double *K_dev, const double *PRESS, const double *TEMP,
+                            const double *WAVE, const double *DELG);
+/* dims = {W,G,NP,NT,S}; monotone = 1 when every k(g) column of the table is >=0 and
+ * non-decreasing in g (precondition of the merge kernel's fast path). */
+int ansfm_ktable_info(const ansfm_ctx *ctx, int64_t dims[5], int *monotone);
+
+/* ---- array-level seams (host pointers), one per numba/NumPy kernel of the reference ------- */
+
+/* Spectroscopy_0.calc_k (Spectroscopy_0.py:2298) / calc_kg (:2147), WAVECALC=None.
+ * press[L] in atm, temp[L] in K -> k_out[W][G][L][S]; dkdT_out may be NULL (calc_k). */
+int ansfm_calc_k(ansfm_ctx *ctx, int L, const double *press, const double *temp, double *k_out,
+                 double *dkdT_out);
+
+/* ForwardModel_0.k_overlap (ForwardModel_0.py:6029): del_g[G], k[W][G][L][S], amount[S][L]
+ * -> tau[W][G][L].  Does not need an uploaded table. */
+int ansfm_k_overlap(ansfm_ctx *ctx, int W, int G, int L, int S, const double *del_g,
+                    const double *k, const double *amount, double *tau);
+
+/* ForwardModel_0.calc_thermal_emission_spectrum (ForwardModel_0.py:6287).
+ * TAUTOT_PATH[W][G][Li], EMITOT_PATH[W][Li] or NULL, TEMP[Li], PRESS[Li], EMISSIVITY/SOLFLUX/
+ * REFLECTANCE[W] -> SPECOUT[W][G]. */
+int ansfm_thermal_emission(ansfm_ctx *ctx, int ISPACE, int W, int G, int NLAYIN,
+                           const double *WAVE, const double *TAUTOT_PATH,
+                           const double *EMITOT_PATH, const double *TEMP, const double *PRESS,
+                           double TSURF, const double *EMISSIVITY, const double *SOLFLUX,
+                           const double *REFLECTANCE, double SOL_ANG, double EMISS_ANG,
+                           double *SPECOUT);
+
+/* ---- fused seam: CIRSrad, ILBL=K_TABLES, IMOD=THERMAL_EMISSION ------------------------------
+ * ForwardModel_0.CIRSrad (ForwardModel_0.py:4376-4511) =
+ *   calculate_gaseous_line_opacity (:3850-3877: calc_k -> k_overlap)
+ *   -> calculate_layer_opacity (:3989 TAUTOT = TAUGAS+TAUCIA+TAUDUST+TAURAY; :4006 LAYINC*SCALE)
+ *   -> calculate_thermal_emission_spectrum (:4216-4244) -> g-quadrature (:4504)
+ * for a BATCH of n_models atmospheres sharing the uploaded k-table and the path structure
+ * (the fan-out of jacobian_nemesis, ForwardModel_0.py:2305-2337).
+ *
+ *   lay_press_pa[n][L]   LayerX.PRESS (Pa; divided by 101325 internally, :3855)
+ *   lay_temp[n][L]       LayerX.TEMP
+ *   amount[n][S][L]      f_gas = LayerX.AMOUNT[:,IGAS]*1e-4 (cm-2, :3861)
+ *   taucont[n][W][L]     TAUCIA+TAUDUST+TAURAY (vertical), or NULL (=0)
+ *   NLAYIN[P], LAYINC[LIMAX][P] (int32), SCALE[n][LIMAX][P], EMTEMP[n][LIMAX][P]   PathX (:4006,:4218)
+ *   TSURF[n]; EMISSIVITY/SOLFLUX/REFLECTANCE/xfac [W] or NULL (0,0,0,1); SOL_ANG/EMISS_ANG [P]
+ *   SPECOUT[n][W][P]
+ * n_models strides are contiguous.  Host-pointer version copies in/out; `_dev` takes device
+ * pointers for every array (int32 arrays too) and is asynchronous on the ctx stream. */
+int ansfm_cirsrad_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L,
+                             const double *lay_press_pa, const double *lay_temp,
+                             const double *amount, const double *taucont, int P, int LIMAX,
+                             const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE,
+                             const double *EMTEMP, const double *TSURF, const double *EMISSIVITY,
+                             const double *SOLFLUX, const double *REFLECTANCE,
+                             const double *SOL_ANG, const double *EMISS_ANG, const double *xfac,
+                             double *SPECOUT);
+int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L,
+                                 const double *lay_press_pa, const double *lay_temp,
+                                 const double *amount, const double *taucont, int P, int LIMAX,
+                                 const int32_t *NLAYIN, const int32_t *LAYINC,
+                                 const double *SCALE, const double *EMTEMP, const double *TSURF,
+                                 const double *EMISSIVITY, const double *SOLFLUX,
+                                 const double *REFLECTANCE, const double *SOL_ANG,
+                                 const double *EMISS_ANG, const double *xfac, double *SPECOUT);
+
+/* Vertical gas opacity of the last cirsrad call's first model, TAUGAS[W][G][L]
+ * (what CIRSrad leaves in LayerX.TAUGAS, ForwardModel_0.py:3925) -- host pointer out. */
+int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS);
+
+/* ---- measurement helpers (bench.py / profiling) -------------------------------------------
+ * Time of the dominant kernel (ck_overlap) measured with hipEvents on the ctx stream around
+ * the launches of the last cirsrad call: total milliseconds and number of launches. */
+int ansfm_last_kernel_ms(const ansfm_ctx *ctx, double *overlap_ms, int *overlap_launches,
+                         double *rt_ms, int *rt_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANSFM_H */
