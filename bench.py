@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""bench.py -- forward-models/s of the archNEMESIS correlated-k hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): synthetic 10 000-wavenumber x 100-layer x
+8-gas correlated-k nadir thermal-emission forward model, G=20, table 20 P x 15 T.  One "step" =
+one forward model per rank through the fused CIRSrad path (ck_overlap + thermal_rt kernels) with
+every input already resident in HBM.  N>1: one process per GPU, independent forward models per
+rank (the jacobian_nemesis fan-out), no data-path collective in the timed steps ("weak").
+
+After the timed steps rank 0 also reports (extra keys, outside the timed region):
+  jacobian: wall time of a 201-forward-model numerical Jacobian (C3) sharded over the N ranks with
+            one all_gather (RCCL) of the spectra.
+  cpu_baseline: the CPU oracle ("port") on a bounded sample of the same workload.
+  roofline: dominant kernel (ck_overlap) algorithmic bytes / hipEvent-measured duration vs HBM peak.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(W, G, S, L, NP, NT, P, n_models=1, V=None):
+    """B_fm = 4*W*G*S*min(NP*NT,4L) + 8*(S+V+6)*L + 8*3*W*L + 8*W*P ;
+    batch: table once + n * per-model terms."""
+    V = S if V is None else V
+    table = 4.0 * W * G * S * min(NP * NT, 4 * L)
+    per_model = 8.0 * (S + V + 6) * L + 8.0 * 3 * W * L + 8.0 * W * P
+    return table + n_models * per_model
+
+
+def torch_ktable(torch, dev, W, G, NP, NT, S, seed):
+    """Device-side twin of synthetic.synth_ktable (same family, torch RNG): K (W,G,NP,NT,S) f64."""
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    f8 = torch.float64
+    PRESS = torch.logspace(-7, 1.3, NP, dtype=f8, device=dev)
+    TEMP = torch.linspace(50.0, 500.0, NT, dtype=f8, device=dev)
+    K = torch.empty((W, G, NP, NT, S), dtype=f8, device=dev)
+    chunk = 1000
+    for w0 in range(0, W, chunk):
+        n = min(chunk, W - w0)
+        u = lambda lo, hi, shape: lo + (hi - lo) * torch.rand(shape, generator=gen, dtype=f8, device=dev)
+        base = 10.0 ** u(-28, -21, (n, 1, 1, 1, S))
+        gshape = torch.sort(10.0 ** u(-2, 3, (n, G, 1, 1, S)), dim=1).values
+        pexp = u(0.0, 0.3, (n, 1, 1, 1, S)); texp = u(-1.0, 2.0, (n, 1, 1, 1, S))
+        K[w0:w0 + n] = base * gshape * PRESS.view(1, 1, NP, 1, 1) ** pexp * (TEMP.view(1, 1, 1, NT, 1) / 200.0) ** texp
+    return PRESS.cpu().numpy(), TEMP.cpu().numpy(), K
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gases", type=int, default=8)
+    ap.add_argument("--waves", type=int, default=10000)
+    ap.add_argument("--layers", type=int, default=100)
+    ap.add_argument("--ng", type=int, default=20)
+    ap.add_argument("--jac-models", type=int, default=201)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-jacobian", action="store_true")
+    ap.add_argument("--cpu-sample-waves", type=int, default=2048)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import archnemesis_dist_amd as pkg
+    from archnemesis_dist_amd import synthetic as syn
+    from archnemesis_dist_amd.jacobian import chunk_range, gather_columns
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    W, G, S, L, NP, NT, P = args.waves, args.ng, args.gases, args.layers, 20, 15, 1
+    f8 = torch.float64
+    eng = pkg.AnsfmEngine(local_rank)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+
+    # ---- synthetic inputs, resident in HBM -----------------------------------------------------
+    _, delg = syn.gauss_legendre_01(G, as_float32=True)
+    WAVE = 200.0 + 0.1 * np.arange(W)
+    PRESS, TEMP, Kdev = torch_ktable(torch, dev, W, G, NP, NT, S, seed=20260704)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    eng.upload_ktable(Kdev, PRESS, TEMP, WAVE, delg)
+    torch.cuda.synchronize()
+    table_relayout_s = time.time() - t0
+    Wc = min(args.cpu_sample_waves, W)
+    K_sample = Kdev[:Wc].cpu().numpy() if (rank == 0 and not args.no_cpu_baseline) else None
+    del Kdev
+    torch.cuda.empty_cache()
+
+    nj = args.jac_models
+    atm = syn.synth_atmosphere(L, S, seed=7 + rank, n_models=nj, perturb=0.05)
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L)
+    cont = syn.synth_continuum(W, L)                                   # (1,W,L), shared by all models
+    EMTEMP = atm["lay_temp"][:, LAYINC[:, 0]][:, :, None]              # (n,L,1)
+    td = lambda a, dt=f8: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    d_lp, d_lt, d_am = td(atm["lay_press_pa"]), td(atm["lay_temp"]), td(atm["amount"])
+    d_cont1 = td(cont)
+    d_nlayin, d_layinc = td(NLAYIN, torch.int32), td(LAYINC, torch.int32)
+    d_scale = td(np.repeat(SCALE[None], nj, 0)); d_emtemp = td(EMTEMP)
+    d_tsurf = td(np.full(nj, -1.0))
+    d_out1 = torch.empty((1, W, P), dtype=f8, device=dev)
+
+    def step(m):
+        """one forward model (model index m of this rank's batch)"""
+        eng.cirsrad_ck_thermal_dev(0, 1, L, d_lp[m], d_lt[m], d_am[m], d_cont1, P, L, d_nlayin, d_layinc, d_scale[m],
+                                   d_emtemp[m], d_tsurf[m:m + 1], None, None, None, None, None, None, d_out1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i % nj)
+    barrier()
+    ov_ms = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i % nj)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # per-kernel duration measured live with hipEvents on the stream the kernels run on:
+    # a few extra (untimed) steps, one event pair per launch
+    rt_ms = []
+    for i in range(min(args.steps, 10)):
+        step(i % nj)
+        k = eng.last_kernel_ms()
+        ov_ms.append(k["overlap_ms"]); rt_ms.append(k["rt_ms"])
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=f8, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * args.steps / elapsed
+
+    # ---- numerical Jacobian (C3): nj forward models sharded over ranks + one gather ---------------
+    jac = None
+    if not args.no_jacobian:
+        s, e = chunk_range(nj, world, rank)
+        nloc = e - s
+        sub = 16
+        d_cont_b = d_cont1.expand(sub, W, L).contiguous()   # continuum is per-model in the ABI
+        out_b = torch.empty((nloc, W, P), dtype=f8, device=dev)
+        barrier()
+        t0 = time.perf_counter()
+        for b0 in range(s, e, sub):
+            b1 = min(e, b0 + sub)
+            nb = b1 - b0
+            eng.cirsrad_ck_thermal_dev(0, nb, L, d_lp[b0:b1], d_lt[b0:b1], d_am[b0:b1],
+                                       d_cont_b[:nb], P, L, d_nlayin, d_layinc,
+                                       d_scale[b0:b1], d_emtemp[b0:b1], d_tsurf[b0:b1], None, None, None, None, None,
+                                       None, out_b[b0 - s:b1 - s])
+        spectra = gather_columns(out_b.reshape(nloc, W * P), nj, rank, world)
+        barrier()
+        jt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([jt], dtype=f8, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            jt = float(t.item())
+        assert spectra.shape == (nj, W * P)
+        jac = {"forward_models": nj, "wall_s": jt, "fm_per_s": nj / jt, "collective": "all_gather" if world > 1 else None}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel -------------------------------------------------------------
+    ov = float(np.mean(ov_ms)) * 1e-3
+    abytes = algorithmic_bytes(W, G, S, L, NP, NT, P, 1)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"W{W}_G{G}_S{S}_L{L}"
+            traffic = tj.get(key, {}).get("ck_overlap_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roof = {"bound": "hbm", "kernel": "k_ck_overlap", "achieved": abytes / ov / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": abytes / ov / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": abytes, "kernel_ms": ov * 1e3, "rt_kernel_ms": float(np.mean(rt_ms)),
+            "note": "second bound (LDS/VALU of the in-LDS G-way merge) dominates; see DESIGN.md"}
+
+    # ---- CPU baseline: the oracle (port) on a bounded sample, rank 0 only ---------------------------------
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        orc.build()
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+        # the 1-GPU box exposes every host core but grants a 16-core share: oversubscribing OpenMP
+        # makes the baseline slower, not faster
+        cores = int(os.environ.get("ANSFM_CPU_THREADS", min(cores, 16)))
+        orc.set_num_threads(cores)
+        a0 = {k: v[0] for k, v in atm.items()}
+        t0 = time.perf_counter()
+        ref = orc.cirsrad_ck_thermal(0, K_sample, PRESS, TEMP, WAVE[:Wc], delg, a0["lay_press_pa"], a0["lay_temp"],
+                                     a0["amount"], cont[0][:Wc], NLAYIN, LAYINC, SCALE, EMTEMP[0], -1.0)
+        ct = time.perf_counter() - t0
+        step(0)
+        torch.cuda.synchronize()
+        got = d_out1[0, :Wc].cpu().numpy()
+        perr = float(np.max(np.abs(got - ref) / np.abs(ref)))
+        cpu = {"value": (Wc / W) / ct, "unit": "forward-models/s", "cores": int(cores), "kind": "port",
+               "sample": f"first {Wc} of {W} wavenumbers x {L} layers x {S} gases (G={G}), oracle/ansfm_oracle.c, "
+                         f"OpenMP over wavenumbers, {ct:.2f} s wall; value scaled by {Wc}/{W}",
+               "gpu_vs_oracle_max_rel_err_on_sample": perr}
+
+    line = {
+        "metric": "forward-models/sec (10k nu x 100 layers)", "value": value, "unit": "forward-models/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic correlated-k nadir thermal-emission forward model: {W} wavenumbers x "
+                               f"{L} layers x {S} gases, G={G}, k-table {NP}Px{NT}T (BASELINE configs[1], SURVEY C2)",
+                   "forward_models_per_step_per_gpu": 1, "parallelism": f"replicas x{world} (independent forward models)"},
+        "roofline": roof, "cpu_baseline": cpu, "jacobian": jac,
+        "table_relayout_s": table_relayout_s,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
