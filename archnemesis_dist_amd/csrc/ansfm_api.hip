@@ -232,7 +232,7 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     p.err_flag = ctx->d_flag.as<int>() + 1;
     p.W = W; p.Wpad = Wpad; p.G = G; p.NT = ctx->NT; p.S = S; p.L = L; p.n_models = n_models;
     loser_tree_init(G, p.init_loser, &p.depth);
-    const size_t lds = (size_t)G * kWave * (3 * sizeof(double) + sizeof(uint32_t)) +
+    const size_t lds = (size_t)G * kWave * (3 * sizeof(double)) +
                        (size_t)(2 * kMaxG + 2) * sizeof(double);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;

@@ -204,7 +204,7 @@ __global__ void k_calc_k_seam(const double *__restrict__ lnK, int W, int Wpad, i
 // G*G is ever stored.  Per-lane state (a[G], b[G], tree nodes) lives in LDS as [index][lane], so a
 // lane-dependent index never causes a bank conflict (bank depends on the lane only).
 //
-// LDS per wave: G*64*(8+8+8+4) bytes (+ shared del_g / g_ord tables)  -> 35 KiB at G=20.
+// LDS per wave: G*64*(8+8+8) bytes (+ shared del_g / g_ord tables)  -> 30.5 KiB at G=20.
 // ------------------------------------------------------------------------------------------------
 struct OverlapParams {
     const double *lnK;        // [NP][NT][S][G][Wpad]            (FROM_K: unused)
@@ -251,6 +251,34 @@ __device__ __forceinline__ void load_gas(const OverlapParams &p, const LayerInte
     }
 }
 
+// Tree keys: the element value a_i + b_j with the low 10 mantissa bits replaced by (j<<5 | i).
+// Keys compare like the values except among values closer than 2^-42 relative (treated as ties,
+// which rank() orders arbitrarily anyway); the exact value is recomputed from a_i + b_j when the
+// element is consumed, so sums are the reference's.  One tree level = v_min_f64 + v_max_f64.
+__device__ __forceinline__ double pack_key(double v, int row, int col)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    b = (b & ~0x3FFULL) | (unsigned long long)((col << 5) | row);
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ double sentinel_key(int row)
+{   // finite, above every real optical depth; never NaN (an inf with payload bits would be)
+    return __longlong_as_double((long long)(0x7FE0000000000000ULL | (unsigned long long)row));
+}
+__device__ __forceinline__ void minmax_f64(double a, double b, double &lo, double &hi)
+{
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ double fast_div(double n, double d)
+{   // n/d with v_rcp_f64 + 2 Newton steps + residual correction (<= ~1 ulp; frac of rank())
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
 template <int DEPTH, bool FROM_K>
 __global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
 {
@@ -260,8 +288,7 @@ __global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
     double *A = smem;
     double *B = A + G * kWave;
     double *NV = B + G * kWave;
-    uint32_t *NIP = reinterpret_cast<uint32_t *>(NV + G * kWave);
-    double *DG = reinterpret_cast<double *>(NIP + G * kWave);
+    double *DG = NV + G * kWave;
     double *GORD = DG + kMaxG;
     // shared tables: del_g and g_ord = [0, cumsum(del_g)], g_ord[G] = 1   (ForwardModel_0.py:6141-6143)
     if (lane < G) DG[lane] = p.del_g[lane];
@@ -281,7 +308,6 @@ __global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
     double *scrS = scrK + G * kWave;
     const int NVT = p.Wpad / kWave;
     const long ntiles = (long)p.n_models * NVT * p.L;
-    const double INF = __builtin_inf();
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int l = (int)(tile % p.L);
@@ -310,35 +336,40 @@ __global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
                 const double b0 = B[lane];
                 for (int x = 1; x < G; ++x) {
                     const int row = p.init_loser[x];
-                    NV[x * kWave + lane] = A[row * kWave + lane] + b0;
-                    NIP[x * kWave + lane] = (uint32_t)row;
+                    NV[x * kWave + lane] = pack_key(A[row * kWave + lane] + b0, row, 0);
                 }
-                NV[lane] = INF;
-                NIP[lane] = 0u;
+                NV[lane] = sentinel_key(31);  // node 0: dummy level for the shallower leaves
                 for (int g = 0; g < G; ++g) { scrK[g * kWave + lane] = 0.0; scrS[g * kWave + lane] = 1.0; }
-                double cv = A[lane] + b0;  // current winner: value, row, column
-                int ci = 0, cp = 0;
+                double ckey = pack_key(A[lane] + b0, 0, 0);  // current winner
                 // ---- rank() walk state -----------------------------------------------------------
                 double gd = 0.0, kacc = 0.0, sum1 = 0.0, gnext = GORD[1];
                 int ig = 0;
                 const int nloop = G * G;
                 for (int it = 0; it < nloop; ++it) {
-                    const double w = DG[ci] * DG[cp < G ? cp : G - 1];
-                    // advance the winner's row
+                    const unsigned kb = (unsigned)__double_as_longlong(ckey);
+                    const int ci = kb & 31, cp = (kb >> 5) & 31;
                     const int np = cp + 1;
                     const int npc = np < G ? np : G - 1;
                     const double ai = A[ci * kWave + lane];
+                    const double bc = B[cp * kWave + lane];
                     const double bn = B[npc * kWave + lane];
+                    const double w = DG[ci] * DG[cp];
                     const int x0 = (G + ci) >> 1;
                     double tv[DEPTH];
-                    uint32_t tip[DEPTH];
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) tv[d] = NV[(x0 >> d) * kWave + lane];
+                    // advance the winner's row and replay its tree path
+                    double car = (np < G) ? pack_key(ai + bn, ci, np) : sentinel_key(ci);
 #pragma unroll
                     for (int d = 0; d < DEPTH; ++d) {
-                        const int xx = x0 >> d;
-                        tv[d] = NV[xx * kWave + lane];
-                        tip[d] = NIP[xx * kWave + lane];
+                        double lo, hi;
+                        minmax_f64(tv[d], car, lo, hi);
+                        NV[(x0 >> d) * kWave + lane] = hi;
+                        car = lo;
                     }
+                    ckey = car;
                     // rank walk on element (cv, w)        ForwardModel_0.py:6155-6170
+                    const double cv = ai + bc;
                     const double gdn = gd + w;
                     const double cw = cv * w;
                     if (ig < G) {
@@ -347,7 +378,7 @@ __global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
                             sum1 += w;
                         } else {
                             const double gprev = (it == 0) ? wtot : gd;
-                            const double frac = (gnext - gprev) / (gdn - gprev);
+                            const double frac = fast_div(gnext - gprev, gdn - gprev);
                             scrK[ig * kWave + lane] = kacc + frac * cw;
                             scrS[ig * kWave + lane] = sum1 + frac * w;
                             ig += 1;
@@ -357,23 +388,6 @@ __global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
                         }
                     }
                     gd = gdn;
-                    // replay the tree path of leaf ci
-                    double carv = (np < G) ? (ai + bn) : INF;
-                    uint32_t carip = (uint32_t)ci | ((uint32_t)np << 8);
-#pragma unroll
-                    for (int d = 0; d < DEPTH; ++d) {
-                        const int xx = x0 >> d;
-                        const bool sw = (xx != 0) & (tv[d] < carv);
-                        const double nv = sw ? carv : tv[d];
-                        const uint32_t ni = sw ? carip : tip[d];
-                        carv = sw ? tv[d] : carv;
-                        carip = sw ? tip[d] : carip;
-                        NV[xx * kWave + lane] = nv;
-                        NIP[xx * kWave + lane] = ni;
-                    }
-                    cv = carv;
-                    ci = (int)(carip & 0xffu);
-                    cp = (int)(carip >> 8);
                 }
                 // trailing `if ig == ng-1` (ForwardModel_0.py:6171); an unfinished earlier bin stays
                 // un-normalised exactly like the reference leaves it
