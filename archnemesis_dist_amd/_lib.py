@@ -20,7 +20,7 @@ ERR_NAMES = {1: "ANSFM_ERR_INVALID", 2: "ANSFM_ERR_HIP", 3: "ANSFM_ERR_NOTABLE",
 # every symbol include/ansfm.h declares (tests check the library exports all of them)
 EXPORTS = [
     "ansfm_abi_version", "ansfm_create", "ansfm_destroy", "ansfm_last_error", "ansfm_set_stream",
-    "ansfm_synchronize", "ansfm_upload_ktable", "ansfm_upload_ktable_dev", "ansfm_ktable_info",
+    "ansfm_synchronize", "ansfm_set_f32_semantics", "ansfm_upload_ktable", "ansfm_upload_ktable_dev", "ansfm_ktable_info",
     "ansfm_calc_k", "ansfm_k_overlap", "ansfm_thermal_emission", "ansfm_cirsrad_ck_thermal",
     "ansfm_cirsrad_ck_thermal_dev", "ansfm_get_taugas", "ansfm_last_kernel_ms",
 ]
@@ -74,6 +74,7 @@ def load():
     lib.ansfm_last_error.restype = C.c_char_p
     lib.ansfm_set_stream.argtypes = [vp, vp]
     lib.ansfm_synchronize.argtypes = [vp]
+    lib.ansfm_set_f32_semantics.argtypes = [vp, ci, ci]
     lib.ansfm_upload_ktable.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]
     lib.ansfm_upload_ktable_dev.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]
     lib.ansfm_ktable_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(ci)]

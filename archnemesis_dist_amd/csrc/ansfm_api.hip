@@ -46,6 +46,7 @@ struct ansfm_ctx {
     int W = 0, Wpad = 0, G = 0, NP = 0, NT = 0, S = 0;
     int monotone = 0;
     bool have_table = false;
+    int grid_f32 = 0, delg_f32 = 0;
     DevBuf lnK, d_press, d_temp, d_wave, d_delg, d_flag;
     std::vector<double> h_delg;
 
@@ -145,6 +146,14 @@ int ansfm_set_stream(ansfm_ctx *ctx, void *hip_stream)
     return ANSFM_OK;
 }
 
+int ansfm_set_f32_semantics(ansfm_ctx *ctx, int grid_f32, int delg_f32)
+{
+    CHECK_CTX(ctx);
+    ctx->grid_f32 = grid_f32 ? 1 : 0;
+    ctx->delg_f32 = delg_f32 ? 1 : 0;
+    return ANSFM_OK;
+}
+
 int ansfm_synchronize(ansfm_ctx *ctx)
 {
     CHECK_CTX(ctx);
@@ -219,7 +228,7 @@ int ansfm_ktable_info(const ansfm_ctx *ctx, int64_t dims[5], int *monotone)
 /* ------------------------------------------------------------------------------------------ */
 static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W, int Wpad, int G, int S,
                           int L, int n_models, const LayerInterp *li, const double *amount,
-                          const double *del_g_dev, double *tau)
+                          const double *del_g_dev, const double *del_g_host, double *tau)
 {
     OverlapParams p;
     memset(&p, 0, sizeof p);
@@ -232,6 +241,18 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     p.err_flag = ctx->d_flag.as<int>() + 1;
     p.W = W; p.Wpad = Wpad; p.G = G; p.NT = ctx->NT; p.S = S; p.L = L; p.n_models = n_models;
     loser_tree_init(G, p.init_loser, &p.depth);
+    p.delg_f32 = ctx->delg_f32;
+    {   // g_ord = [0, cumsum(del_g)], g_ord[ng] = 1 (ForwardModel_0.py:6141-6143); float32 cumsum when DELG is
+        double acc = 0.0;
+        float accf = 0.0f;
+        p.g_ord[0] = 0.0;
+        for (int g = 0; g < G; ++g) {
+            if (ctx->delg_f32) { accf += (float)del_g_host[g]; p.g_ord[g + 1] = (double)accf; }
+            else { acc += del_g_host[g]; p.g_ord[g + 1] = acc; }
+        }
+        p.g_ord[G] = 1.0;
+        p.g_ord[G + 1] = __builtin_inf();
+    }
     const size_t lds = (size_t)G * kWave * (3 * sizeof(double)) +
                        (size_t)(2 * kMaxG + 2) * sizeof(double);
     int per_cu = (int)((160 * 1024) / lds);
@@ -310,7 +331,7 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
     HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_layer_prep, dim3(nblk((size_t)n_models * L, 128)), dim3(128), 0, ctx->stream,
                        n_models * L, lay_press_pa, lay_temp, ctx->NP, ctx->d_press.as<double>(), ctx->NT,
-                       ctx->d_temp.as<double>(), 101325.0, ctx->li.as<LayerInterp>());
+                       ctx->d_temp.as<double>(), 101325.0, ctx->grid_f32, ctx->li.as<LayerInterp>());
     HIPCHK(hipGetLastError());
     const double *cont_t = nullptr;
     if (taucont) {
@@ -325,7 +346,7 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
     }
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     int rc = launch_overlap(ctx, false, nullptr, W, Wpad, G, S, L, n_models, ctx->li.as<LayerInterp>(), amount,
-                            ctx->d_delg.as<double>(), ctx->tau.as<double>());
+                            ctx->d_delg.as<double>(), ctx->h_delg.data(), ctx->tau.as<double>());
     if (rc != ANSFM_OK) return rc;
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     RtParams r;
@@ -461,7 +482,7 @@ int ansfm_calc_k(ansfm_ctx *ctx, int L, const double *press, const double *temp,
     HIPCHK(ctx->li.reserve((size_t)L * sizeof(LayerInterp)));
     hipLaunchKernelGGL(k_layer_prep, dim3(nblk(L, 128)), dim3(128), 0, ctx->stream, L, (const double *)dp,
                        (const double *)dt, ctx->NP, ctx->d_press.as<double>(), ctx->NT, ctx->d_temp.as<double>(),
-                       1.0, ctx->li.as<LayerInterp>());
+                       1.0, ctx->grid_f32, ctx->li.as<LayerInterp>());
     const size_t n = (size_t)W * G * L * S;
     HIPCHK(ctx->tmp_out.reserve(n * sizeof(double) * (dkdT_out ? 2 : 1)));
     double *dk = dkdT_out ? ctx->tmp_out.as<double>() + n : nullptr;
@@ -498,7 +519,7 @@ int ansfm_k_overlap(ansfm_ctx *ctx, int W, int G, int L, int S, const double *de
     const size_t ntau = (size_t)L * G * Wpad;
     HIPCHK(ctx->misc.reserve(ntau * sizeof(double)));
     rc = launch_overlap(ctx, true, ctx->tmp_in.as<double>(), W, Wpad, G, S, L, 1, nullptr, (const double *)dam,
-                        (const double *)ddg, ctx->misc.as<double>());
+                        (const double *)ddg, del_g, ctx->misc.as<double>());
     if (rc) return rc;
     const size_t nout = (size_t)W * G * L;
     HIPCHK(ctx->tmp_out.reserve(nout * sizeof(double)));

@@ -53,9 +53,11 @@ struct LayerInterp {
 __global__ void k_layer_prep(int n_layers_total, const double *__restrict__ lay_press_pa,
                              const double *__restrict__ lay_temp, int NP,
                              const double *__restrict__ PRESS, int NT,
-                             const double *__restrict__ TEMP, double press_div,
+                             const double *__restrict__ TEMP, double press_div, int grid_f32,
                              LayerInterp *__restrict__ out)
 {
+    // grid_f32: Spectroscopy_0.PRESS/TEMP are float32 arrays (tables read from .kta): NumPy then takes
+    // np.log(PRESS[i]), phi-plo, thi-tlo and 1./(thi-tlo) in float32 (see include/ansfm.h, ansfm_set_f32_semantics)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_layers_total) return;
     double press1 = lay_press_pa[i] / press_div;  // LayerX.PRESS/ATM_TO_PASCAL  ForwardModel_0.py:3855
@@ -67,13 +69,14 @@ __global__ void k_layer_prep(int n_layers_total, const double *__restrict__ lay_
         if (d < best) { best = d; ip = k; }
     }
     int ipl, iph;
+    bool pclamp = false;
     if (PRESS[ip] >= press1) {
         iph = ip;
-        if (ip == 0) { press1 = PRESS[0]; ipl = 0; iph = 1; }
+        if (ip == 0) { press1 = PRESS[0]; ipl = 0; iph = 1; pclamp = true; }
         else ipl = ip - 1;
     } else {
         ipl = ip;
-        if (ip == NP - 1) { press1 = PRESS[NP - 1]; iph = NP - 1; ipl = NP - 2; }
+        if (ip == NP - 1) { press1 = PRESS[NP - 1]; iph = NP - 1; ipl = NP - 2; pclamp = true; }
         else iph = ip + 1;
     }
     int it = 0;
@@ -94,11 +97,20 @@ __global__ void k_layer_prep(int n_layers_total, const double *__restrict__ lay_
     }
     double lpress = log(press1), plo = log(PRESS[ipl]), phi = log(PRESS[iph]);
     double tlo = TEMP[itl], thi = TEMP[ith];
+    double pden = phi - plo, tden = thi - tlo, dudt = 1. / tden;
+    if (grid_f32) {
+        plo = (double)(float)plo;
+        phi = (double)(float)phi;
+        if (pclamp) lpress = (double)(float)lpress;
+        pden = (double)((float)phi - (float)plo);
+        tden = (double)((float)thi - (float)tlo);
+        dudt = (double)(1.0f / (float)tden);
+    }
     LayerInterp r;
     r.ipl = ipl; r.iph = iph; r.itl = itl; r.ith = ith;
-    r.v = (lpress - plo) / (phi - plo);
-    r.u = (temp1 - tlo) / (thi - tlo);
-    r.dudt = 1. / (thi - tlo);
+    r.v = (lpress - plo) / pden;
+    r.u = (temp1 - tlo) / tden;
+    r.dudt = dudt;
     out[i] = r;
 }
 
@@ -216,7 +228,9 @@ struct OverlapParams {
     double *scratch;          // [gridDim.x][2][G][64]
     int *err_flag;            // bit0: unsorted input k-distribution
     int W, Wpad, G, NT, S, L, n_models, depth;
+    int delg_f32;             // DELG is a float32 array: del_g[i]*del_g[j] is a float32 product
     unsigned char init_loser[kMaxG];
+    double g_ord[kMaxG + 2];  // [0, cumsum(del_g)] (float32 cumsum when delg_f32), g_ord[G]=1, +inf
 };
 
 template <bool FROM_K>
@@ -292,14 +306,9 @@ __global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
     double *GORD = DG + kMaxG;
     // shared tables: del_g and g_ord = [0, cumsum(del_g)], g_ord[G] = 1   (ForwardModel_0.py:6141-6143)
     if (lane < G) DG[lane] = p.del_g[lane];
-    if (lane == 0) {
-        double acc = 0.0;
-        GORD[0] = 0.0;
-        for (int g = 0; g < G; ++g) { acc += p.del_g[g]; GORD[g + 1] = acc; }
-        GORD[G] = 1.0;
-        GORD[G + 1] = __builtin_inf();
-    }
+    if (lane < G + 2) GORD[lane] = p.g_ord[lane];
     __syncthreads();
+    const bool w32 = p.delg_f32 != 0;
     double wsum = 0.0;
     for (int g = 0; g < G; ++g) wsum += DG[g];
     const double wtot = wsum * wsum;  // stands in for gdist[-1] (python wrap at iloop==0)
@@ -353,7 +362,8 @@ __global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
                     const double ai = A[ci * kWave + lane];
                     const double bc = B[cp * kWave + lane];
                     const double bn = B[npc * kWave + lane];
-                    const double w = DG[ci] * DG[cp];
+                    double w = DG[ci] * DG[cp];           // exact in double when both are float32 values
+                    if (w32) w = (double)(float)w;          // -> the float32 product NumPy forms
                     const int x0 = (G + ci) >> 1;
                     double tv[DEPTH];
 #pragma unroll

@@ -16,6 +16,10 @@ def _np(a, dtype=_f8):
     return None if a is None else np.ascontiguousarray(a, dtype=dtype)
 
 
+def _is_f32(a):
+    return getattr(a, "dtype", None) == np.float32
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -60,9 +64,18 @@ class AnsfmEngine:
     def synchronize(self):
         self._check(self._lib.ansfm_synchronize(self._ctx), "synchronize")
 
+    def set_f32_semantics(self, grid_f32, delg_f32):
+        """Reproduce NumPy's float32 arithmetic when Spectroscopy_0.PRESS/TEMP (grid) / DELG are
+        float32 arrays, as they are after read_tables on .kta files (see include/ansfm.h)."""
+        self.grid_f32, self.delg_f32 = bool(grid_f32), bool(delg_f32)
+        self._check(self._lib.ansfm_set_f32_semantics(self._ctx, int(self.grid_f32), int(self.delg_f32)),
+                    "set_f32_semantics")
+
     # ---- k-table ------------------------------------------------------------------------------
     def upload_ktable(self, K, PRESS, TEMP, WAVE, DELG):
-        """K (W,G,NP,NT,S) float64: NumPy array (host) or torch CUDA tensor (device)."""
+        """K (W,G,NP,NT,S) float64: NumPy array (host) or torch CUDA tensor (device).
+        float32 PRESS/TEMP/DELG arrays switch on the matching float32 semantics."""
+        self.set_f32_semantics(_is_f32(PRESS) or _is_f32(TEMP), _is_f32(DELG))
         PRESS = _np(PRESS); TEMP = _np(TEMP); WAVE = _np(WAVE); DELG = _np(DELG)
         W, G, NP, NT, S = (int(x) for x in K.shape)
         assert PRESS.shape == (NP,) and TEMP.shape == (NT,) and WAVE.shape == (W,) and DELG.shape == (G,)
@@ -94,6 +107,7 @@ class AnsfmEngine:
         return (k, dk) if grad else k
 
     def k_overlap(self, del_g, k_w_g_l_gas, amount_layer):
+        self.set_f32_semantics(getattr(self, "grid_f32", False), _is_f32(del_g))
         del_g = _np(del_g); k = _np(k_w_g_l_gas); am = _np(amount_layer)
         W, G, L, S = k.shape
         if am.shape != (S, L):

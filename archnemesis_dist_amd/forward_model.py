@@ -1,0 +1,167 @@
+"""Host-side mirror of the reference's ForwardModel_0 surface for the hot path.
+
+`make_gpu_forward_model(ForwardModel_0)` returns a subclass of the reference's own class
+(ForwardModel_0.py:87) whose `CIRSrad` (ForwardModel_0.py:4376-4511) runs on the MI355X through
+libansfm.so for the supported case (ILBL = K_TABLES, IMOD = THERMAL_EMISSION, no layer emissions,
+return_grad=False) and whose `jacobian_nemesis` fan-out can batch the independent forward models.
+Everything else (subprofretg, calc_path, conv, ...) is the reference's own host code.
+
+`CIRSradGPU` is the mixin with the seam itself; it only needs the `*X` attributes CIRSrad reads
+(SpectroscopyX, LayerX, PathX, AtmosphereX, SurfaceX, MeasurementX, ScatterX, StellarX, CIAX,
+EmissionsX), so tests drive it with plain namespaces rebuilt from the C1 golden fixture.
+"""
+import hashlib
+
+import numpy as np
+
+from .engine import AnsfmEngine
+
+# IntEnum / IntFlag values of the reference (archnemesis/enum/*.py) kept as plain ints at the seam
+ILBL_K_TABLES = 0                      # SpectralCalculationModeEnum.K_TABLES
+IMOD_THERMAL_EMISSION = 64             # PathCalcEnum.THERMAL_EMISSION
+IMOD_MULTIPLE_SCATTERING = 256
+IMOD_SINGLE_SCATTERING_PLANE_PARALLEL = 1024
+IMOD_ABSORBTION = 4096
+IFORM_FLUXRATIO = 1                    # SpectraUnitEnum.FluxRatio
+ATM_TO_PASCAL = 101325.0               # ForwardModel_0.py:61
+SQ_CM_TO_SQ_METER = 1.0e-4             # ForwardModel_0.py:66
+
+_ENGINES = {}
+
+
+def get_engine(device=0):
+    """One engine (ctx) per GPU per process."""
+    if device not in _ENGINES:
+        _ENGINES[device] = AnsfmEngine(device)
+    return _ENGINES[device]
+
+
+def _table_fingerprint(S):
+    """Cheap content fingerprint of the k-table held by a Spectroscopy object.  nemesisfm
+    deep-copies Spectroscopy and re-reads the tables for every forward model
+    (ForwardModel_0.py:480-482); the table in HBM is re-used when nothing changed."""
+    K = S.K
+    h = hashlib.blake2b(digest_size=16)
+    h.update(np.asarray(K.shape, dtype=np.int64).tobytes())
+    flat = K.reshape(-1)
+    step = max(1, flat.size // 8192)
+    h.update(np.ascontiguousarray(flat[::step]).tobytes())
+    for a in (S.WAVE, S.PRESS, S.TEMP, S.DELG):
+        h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    return h.hexdigest()
+
+
+class CIRSradGPU:
+    """Mixin: CIRSrad on the GPU.  Put it in front of the reference class in the MRO."""
+
+    ansfm_device = 0
+    ansfm_keep_side_products = True   # fill LayerX.TAUGAS / TAUTOT like the reference (:3925, :3997)
+
+    # ---- what is supported -----------------------------------------------------------------------
+    def _ansfm_supported(self, return_grad):
+        S = self.SpectroscopyX
+        if return_grad or S.NGAS <= 0 or int(S.ILBL) != ILBL_K_TABLES:
+            return False
+        if getattr(self, "EmissionsX", None) is not None:
+            return False
+        imod = np.unique(np.asarray(self.PathX.IMOD).astype(int))
+        if imod.size != 1:
+            return False
+        imod = int(imod[0])
+        # dispatch order of CIRSrad :4478-4489: transmission / absorption come before thermal emission
+        if not (imod & IMOD_THERMAL_EMISSION) or (imod & IMOD_ABSORBTION):
+            return False
+        return True
+
+    # ---- continuum opacities: the reference's own host routines when present ---------------------
+    def _ansfm_continuum(self):
+        S, L = self.SpectroscopyX, self.LayerX
+        if hasattr(self, "calculate_vertical_cia_opacity"):
+            TAUCIA, _ = self.calculate_vertical_cia_opacity(False)          # :3938 (sets LayerX.TAUCIA)
+            TAURAY, _ = self.calc_tau_rayleigh(MakePlot=False)              # :3952
+            L.TAURAY = TAURAY
+            TAUDUST1, TAUCLSCAT, _, _ = self.calc_tau_dust()                # :3963
+            TAUDUST1 = np.clip(np.nan_to_num(TAUDUST1), 0, 1e20)           # :3966
+            TAUDUST = np.sum(TAUDUST1, 2)
+            L.TAUDUST = TAUDUST
+            L.TAUSCAT = np.sum(TAUCLSCAT, 2)
+            L.TAUCLSCAT = TAUCLSCAT
+        else:  # standalone: continuum arrays were provided on LayerX
+            z = np.zeros((S.NWAVE, L.NLAY))
+            TAUCIA = getattr(L, "TAUCIA", None)
+            TAUCIA = z if TAUCIA is None else TAUCIA
+            TAURAY = getattr(L, "TAURAY", None)
+            TAURAY = z if TAURAY is None else TAURAY
+            TAUDUST = getattr(L, "TAUDUST", None)
+            TAUDUST = z if TAUDUST is None else TAUDUST
+        return TAUCIA, TAUDUST, TAURAY
+
+    def _ansfm_units_and_surface(self):
+        """xfac and EMISSIVITY exactly as calculate_thermal_emission_spectrum prepares them
+        (ForwardModel_0.py:4157-4189).  REFLECTANCE is identically zero there (:4208-4213), so the
+        solar-reflection term vanishes and SOLFLUX is not needed."""
+        import scipy.interpolate
+        S = self.SpectroscopyX
+        xfac = None
+        if int(self.MeasurementX.IFORM) == IFORM_FLUXRATIO:
+            xfac = np.ones(S.NWAVE) * np.pi * 4. * np.pi * ((self.AtmosphereX.RADIUS) * 1.0e2) ** 2.
+            self.StellarX.calc_solar_flux()
+            f = scipy.interpolate.interp1d(self.StellarX.WAVE, self.StellarX.SOLFLUX)
+            xfac = xfac / f(S.WAVE)
+        if self.SurfaceX.TSURF > 0.0:
+            f = scipy.interpolate.interp1d(self.SurfaceX.VEM, self.SurfaceX.EMISSIVITY)
+            emissivity = f(S.WAVE)
+        else:
+            emissivity = None
+        return xfac, emissivity
+
+    def _ansfm_upload_table(self, eng):
+        S = self.SpectroscopyX
+        fp = _table_fingerprint(S)
+        if getattr(eng, "_table_fp", None) != fp:
+            eng.upload_ktable(np.ascontiguousarray(S.K, dtype=np.float64), S.PRESS, S.TEMP, S.WAVE, S.DELG)
+            eng._table_fp = fp
+
+    def _ansfm_layer_inputs(self):
+        S, L, A = self.SpectroscopyX, self.LayerX, self.AtmosphereX
+        f_gas = np.zeros((S.NGAS, L.NLAY))
+        for i in range(S.NGAS):
+            IGAS = A.locate_gas(S.ID[i], S.ISO[i])
+            f_gas[i, :] = L.AMOUNT[:, IGAS] * SQ_CM_TO_SQ_METER             # :3861
+        return f_gas
+
+    # ---- the seam ---------------------------------------------------------------------------------
+    def CIRSrad(self, return_grad=False):
+        if not self._ansfm_supported(return_grad):
+            base = super()
+            if hasattr(base, "CIRSrad"):
+                return base.CIRSrad(return_grad)      # the reference's own implementation, in its process
+            raise NotImplementedError("CIRSrad: only ILBL=K_TABLES, IMOD=THERMAL_EMISSION, return_grad=False "
+                                      "run on the GPU so far")
+        eng = get_engine(self.ansfm_device)
+        S, L, P = self.SpectroscopyX, self.LayerX, self.PathX
+        self._ansfm_upload_table(eng)
+        TAUCIA, TAUDUST, TAURAY = self._ansfm_continuum()
+        taucont = TAUCIA + TAUDUST + TAURAY                                  # :3989 (g-independent part)
+        f_gas = self._ansfm_layer_inputs()
+        xfac, emissivity = self._ansfm_units_and_surface()
+        NPATH = int(P.NPATH) if hasattr(P, "NPATH") else np.asarray(P.LAYINC).shape[1]
+        LAYINC = np.asarray(P.LAYINC, dtype=np.int32).reshape(-1, NPATH)
+        NLAYIN = np.asarray(P.NLAYIN, dtype=np.int32).reshape(NPATH)
+        SCALE = np.asarray(P.SCALE, dtype=np.float64).reshape(-1, NPATH)
+        EMTEMP = np.asarray(P.EMTEMP, dtype=np.float64).reshape(-1, NPATH)
+        SPECOUT = eng.cirsrad_ck_thermal(
+            int(self.MeasurementX.ISPACE), np.asarray(L.PRESS, dtype=np.float64), np.asarray(L.TEMP, dtype=np.float64),
+            f_gas, taucont, NLAYIN, LAYINC, SCALE, EMTEMP, float(self.SurfaceX.TSURF), EMISSIVITY=emissivity,
+            SOL_ANG=np.asarray(P.SOL_ANG, dtype=np.float64).reshape(NPATH),
+            EMISS_ANG=np.asarray(P.EMISS_ANG, dtype=np.float64).reshape(NPATH), xfac=xfac)
+        if self.ansfm_keep_side_products:
+            L.TAUGAS = eng.get_taugas(L.NLAY, 0)                             # :3925
+            L.TAUTOT = L.TAUGAS + TAUCIA[:, None, :] + TAUDUST[:, None, :] + TAURAY[:, None, :]   # :3989,:3997
+        return SPECOUT                                                        # (NWAVE, NPATH)
+
+
+def make_gpu_forward_model(reference_forward_model_cls, device=0):
+    """Subclass of the reference's ForwardModel_0 with the GPU CIRSrad seam."""
+    return type("ForwardModel_0", (CIRSradGPU, reference_forward_model_cls),
+                {"ansfm_device": device, "__doc__": reference_forward_model_cls.__doc__})

@@ -52,6 +52,14 @@ const char *ansfm_last_error(const ansfm_ctx *ctx);
 int ansfm_set_stream(ansfm_ctx *ctx, void *hip_stream);
 int ansfm_synchronize(ansfm_ctx *ctx);
 
+/* dtype semantics of the reference's NumPy arithmetic.  Spectroscopy_0.PRESS/TEMP ("grid") and DELG
+ * are float32 arrays when the tables come from .kta files (read_ktahead, Spectroscopy_0.py:2544-2559);
+ * NumPy (and numba) then evaluate np.log(PRESS[i]), phi-plo, thi-tlo, 1./(thi-tlo) (calc_k(g),
+ * :2373-2389, :2236) and del_g[i]*del_g[j], np.cumsum(del_g) (k_overlap/rank, ForwardModel_0.py:6087,
+ * :6142) in float32 -- a 4e-5 effect on tau.  Values are still passed as float64 (exactly the float32
+ * values); these flags select the rounding.  Applies to every later call on this ctx. */
+int ansfm_set_f32_semantics(ansfm_ctx *ctx, int grid_f32, int delg_f32);
+
 /* ---- k-table ------------------------------------------------------------------------------
  * Replaces the state filled by Spectroscopy_0.read_tables (Spectroscopy_0.py:1448-1516):
  * K[W][G][NP][NT][S] (:213), PRESS[NP] (atm), TEMP[NT] (K), WAVE[W], DELG[G].

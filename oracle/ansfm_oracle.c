@@ -49,6 +49,21 @@ ORC_API void orc_set_num_threads(int n)
 #endif
 }
 
+/* dtype semantics.  When Spectroscopy_0.PRESS/TEMP (grid) or DELG are float32 arrays -- they are
+ * when the tables come from .kta files (read_ktahead, Spectroscopy_0.py:2544-2559) -- NumPy (and
+ * numba) evaluate np.log(PRESS[i]), phi-plo, thi-tlo, 1./(thi-tlo), del_g[i]*del_g[j] and
+ * np.cumsum(del_g) in float32.  The product/cumsum effect on tau is 4e-5, so it is restated.
+ * float32 log is taken as the correctly rounded value; NumPy's SIMD float32 log differs from it by
+ * 1 ulp for ~6 % of arguments (a 2e-7 effect on k the reference itself does not pin). */
+static int g_grid_f32 = 0, g_delg_f32 = 0;
+ORC_API void orc_set_f32_semantics(int grid_f32, int delg_f32)
+{
+    g_grid_f32 = grid_f32;
+    g_delg_f32 = delg_f32;
+}
+static inline double logx(double x) { return g_grid_f32 ? (double)(float)log(x) : log(x); }
+static inline double wprod(double a, double b) { return g_delg_f32 ? (double)(float)(a * b) : a * b; }
+
 /* argsort ascending by value; ties broken by original index (deterministic).  numpy's default
  * argsort (introsort) is not stable, so tie order may differ from the reference; tied keys have
  * equal `cont`, so only rounding-level differences can result (ForwardModel_0.py:6147). */
@@ -103,14 +118,14 @@ ORC_API void orc_bracket(int NP, const double *PRESS, int NT, const double *TEMP
         double d = fabs(PRESS[i] - press1);
         if (d < best) { best = d; ip = i; }
     }
-    int ip_low = 0, ip_high = 0;
+    int ip_low = 0, ip_high = 0, pclamp = 0;
     if (PRESS[ip] >= press1) {
         ip_high = ip;
-        if (ip == 0) { press1 = PRESS[0]; ip_low = 0; ip_high = 1; }
+        if (ip == 0) { press1 = PRESS[0]; ip_low = 0; ip_high = 1; pclamp = 1; }
         else ip_low = ip - 1;
     } else {
         ip_low = ip;
-        if (ip == NP - 1) { press1 = PRESS[NP - 1]; ip_high = NP - 1; ip_low = NP - 2; }
+        if (ip == NP - 1) { press1 = PRESS[NP - 1]; ip_high = NP - 1; ip_low = NP - 2; pclamp = 1; }
         else ip_high = ip + 1;
     }
     int it = 0;
@@ -129,14 +144,17 @@ ORC_API void orc_bracket(int NP, const double *PRESS, int NT, const double *TEMP
         if (it == NT - 1) { temp1 = TEMP[NT - 1]; it_high = NT - 1; it_low = NT - 2; }
         else it_high = it + 1;
     }
-    double lpress = log(press1);
-    double plo = log(PRESS[ip_low]);
-    double phi = log(PRESS[ip_high]);
+    /* a clamped press1 is PRESS[0|NP-1] itself, i.e. a float32 scalar whose log is float32 too */
+    double lpress = pclamp ? logx(press1) : log(press1);
+    double plo = logx(PRESS[ip_low]);
+    double phi = logx(PRESS[ip_high]);
     double tlo = TEMP[it_low];
     double thi = TEMP[it_high];
-    *v = (lpress - plo) / (phi - plo);
-    *u = (temp1 - tlo) / (thi - tlo);
-    *dudt = 1. / (thi - tlo);
+    double pden = g_grid_f32 ? (double)((float)phi - (float)plo) : phi - plo;
+    double tden = g_grid_f32 ? (double)((float)thi - (float)tlo) : thi - tlo;
+    *v = (lpress - plo) / pden;
+    *u = (temp1 - tlo) / tden;
+    *dudt = g_grid_f32 ? (double)(1.0f / (float)tden) : 1. / tden; /* python float / float32 -> float32 */
     *ipl = ip_low; *iph = ip_high; *itl = it_low; *ith = it_high;
 }
 
@@ -222,7 +240,12 @@ static void rank_core(rank_ws *ws, const double *weight, const double *cont, con
     /* :6141-6143  g_ord = [0, cumsum(del_g)], g_ord[ng] = 1 */
     g_ord[0] = 0.0;
     double acc = 0.0;
-    for (int i = 0; i < ng; ++i) { acc += del_g[i]; g_ord[i + 1] = acc; }
+    if (g_delg_f32) {
+        float accf = 0.0f;
+        for (int i = 0; i < ng; ++i) { accf += (float)del_g[i]; g_ord[i + 1] = (double)accf; }
+    } else {
+        for (int i = 0; i < ng; ++i) { acc += del_g[i]; g_ord[i + 1] = acc; }
+    }
     g_ord[ng] = 1.0;
     g_ord[ng + 1] = INFINITY; /* guard: the reference reads past the end here (numba: no check) */
 
@@ -321,7 +344,7 @@ static void overlap_cell(rank_ws *ws, int G, int S, const double *del_g, const d
                 int iloop = 0;
                 for (int ig = 0; ig < G; ++ig)
                     for (int jg = 0; jg < G; ++jg) {
-                        rw[iloop] = del_g[ig] * del_g[jg];
+                        rw[iloop] = wprod(del_g[ig], del_g[jg]);
                         rt[iloop] = KG(ig, igas) * amount[igas] + KG(jg, igas + 1) * amount[igas + 1];
                         if (with_grad) {
                             rg[iloop * NP1 + igas] = KG(ig, igas);
@@ -351,7 +374,7 @@ static void overlap_cell(rank_ws *ws, int G, int S, const double *del_g, const d
                 int iloop = 0;
                 for (int ig = 0; ig < G; ++ig)
                     for (int jg = 0; jg < G; ++jg) {
-                        rw[iloop] = del_g[ig] * del_g[jg];
+                        rw[iloop] = wprod(del_g[ig], del_g[jg]);
                         rt[iloop] = tau_g[ig] + KG(jg, igas + 1) * amount[igas + 1];
                         if (with_grad) {
                             for (int p = 0; p < igas + 1; ++p) rg[iloop * NP1 + p] = dk_g[ig * NP1 + p];

@@ -42,6 +42,15 @@ def _c(a, dtype=_d):
     return None if a is None else np.ascontiguousarray(a, dtype=dtype)
 
 
+def _is_f32(a):
+    return a is not None and getattr(a, "dtype", None) == np.float32
+
+
+def set_f32_semantics(grid_f32, delg_f32):
+    """float32 dtype semantics of Spectroscopy_0.PRESS/TEMP and DELG (see ansfm_oracle.c)."""
+    lib().orc_set_f32_semantics(int(bool(grid_f32)), int(bool(delg_f32)))
+
+
 def num_threads():
     return lib().orc_num_threads()
 
@@ -52,6 +61,7 @@ def set_num_threads(n):
 
 def calc_k(K, PRESS, TEMP, press, temp, grad=False):
     """Spectroscopy_0.calc_k / calc_kg.  K (W,G,NP,NT,S) -> k (W,G,L,S) [, dkdT]."""
+    set_f32_semantics(_is_f32(PRESS) or _is_f32(TEMP), False)
     K = _c(K); PRESS = _c(PRESS); TEMP = _c(TEMP); press = _c(press); temp = _c(temp)
     W, G, NP, NT, S = K.shape
     L = press.shape[0]
@@ -61,6 +71,7 @@ def calc_k(K, PRESS, TEMP, press, temp, grad=False):
 
 
 def rank(weight, cont, del_g):
+    set_f32_semantics(False, _is_f32(del_g))
     weight = _c(weight); cont = _c(cont); del_g = _c(del_g)
     ng = del_g.shape[0]
     assert weight.size == ng * ng == cont.size
@@ -70,6 +81,7 @@ def rank(weight, cont, del_g):
 
 
 def k_overlap(del_g, k_w_g_l_gas, amount_layer):
+    set_f32_semantics(False, _is_f32(del_g))
     del_g = _c(del_g); k = _c(k_w_g_l_gas); am = _c(amount_layer)
     W, G, L, S = k.shape
     assert am.shape == (S, L)
@@ -79,6 +91,7 @@ def k_overlap(del_g, k_w_g_l_gas, amount_layer):
 
 
 def k_overlapg(del_g, k_w_g_l_gas, dkdT_w_g_l_gas, amount_layer):
+    set_f32_semantics(False, _is_f32(del_g))
     del_g = _c(del_g); k = _c(k_w_g_l_gas); dkdT = _c(dkdT_w_g_l_gas); am = _c(amount_layer)
     W, G, L, S = k.shape
     tau = np.zeros((W, G, L)); dk = np.zeros((W, G, L, S + 1))
@@ -128,6 +141,7 @@ def cirsrad_ck_thermal(ISPACE, K, TPRESS, TTEMP, WAVE, DELG, lay_press_pa, lay_t
                        TAUCONT, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None, SOLFLUX=None,
                        REFLECTANCE=None, SOL_ANG=None, EMISS_ANG=None, xfac=None, return_taugas=False):
     """CIRSrad (ILBL=K_TABLES, IMOD=THERMAL_EMISSION).  ForwardModel_0.py:4376-4511."""
+    set_f32_semantics(_is_f32(TPRESS) or _is_f32(TTEMP), _is_f32(DELG))
     K = _c(K); W, G, NP, NT, S = K.shape
     lay_press_pa = _c(lay_press_pa); L = lay_press_pa.shape[0]
     patm = _c(lay_press_pa / 101325.0)

@@ -1,0 +1,102 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/ansfm.h declares (no compute
+calls without a GPU), the host-side Jacobian logic, and the N>1 gather over gloo (world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import archnemesis_dist_amd as pkg
+    pkg.build()
+    lib = pkg.load()
+    hdr = open(os.path.join(ROOT, "include", "ansfm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(ansfm_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in ansfm.h but not exported"
+    from archnemesis_dist_amd import _lib
+    assert sorted(_lib.EXPORTS) == declared
+    assert lib.ansfm_abi_version() == 1
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import archnemesis_dist_amd as pkg
+    with pytest.raises(pkg.AnsfmError):
+        pkg.AnsfmEngine(0)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "archnemesis_dist_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "ansfm_oracle" not in txt, f
+
+
+def test_chunk_range_matches_reference_arithmetic():
+    from archnemesis_dist_amd.jacobian import chunk_range
+    for nfm in (1, 7, 8, 201, 202):
+        for n in (1, 2, 3, 8):
+            n_jobs = min(n, nfm)
+            base, rem = nfm // n_jobs, nfm % n_jobs
+            got = [chunk_range(nfm, n_jobs, i) for i in range(n_jobs)]
+            ref = [(i * base + min(i, rem), (i + 1) * base + min(i + 1, rem)) for i in range(n_jobs)]   # :2322-2330
+            assert got == ref
+            assert got[0][0] == 0 and got[-1][1] == nfm
+            assert all(got[i][1] == got[i + 1][0] for i in range(n_jobs - 1))
+
+
+def test_perturbed_states_and_finite_difference():
+    from archnemesis_dist_amd.jacobian import perturbed_states, finite_difference_jacobian
+    XN = np.array([2.0, 0.0, -3.0])
+    DSTEP = 0.05 * XN                                   # Variables_0.calc_DSTEP :535
+    xnx = perturbed_states(XN, DSTEP)
+    assert xnx.shape == (3, 4)
+    np.testing.assert_allclose(xnx[:, 0], XN)
+    np.testing.assert_allclose(np.diag(xnx[:, 1:]), [2.1, 0.05, -3.15])
+    # off-diagonal zeros are replaced too (the reference's mask acts on the whole block, :2241-2242)
+    assert xnx[1, 1] == 0.05 and xnx[1, 3] == 0.05
+    A = np.array([[1.0, 2.0, 3.0], [0.5, -1.0, 4.0]])
+    f = lambda x: A @ x
+    Y = np.stack([f(xnx[:, i]) for i in range(4)], axis=1)
+    YN, KK = finite_difference_jacobian(Y, XN, inum=[0, 1, 2])
+    np.testing.assert_allclose(YN, f(XN))
+    # columns 0 and 2 see a clean one-element perturbation; column 1's run also carries xnx[1,:]=0.05
+    np.testing.assert_allclose(KK[:, 2], (Y[:, 3] - YN) / (-3.0 * 0.05))
+
+
+def test_gather_columns_gloo_world2(tmp_path):
+    script = textwrap.dedent(f'''
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import torch, torch.distributed as dist
+        from archnemesis_dist_amd.jacobian import chunk_range, gather_columns
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        nfm, NY = 7, 5
+        full = torch.arange(nfm * NY, dtype=torch.float64).reshape(nfm, NY)
+        s, e = chunk_range(nfm, world, rank)
+        out = gather_columns(full[s:e].clone(), nfm, rank, world)
+        assert out.shape == (nfm, NY) and torch.equal(out, full), (rank, out)
+        dist.destroy_process_group()
+        print("rank", rank, "ok")
+    ''')
+    f = tmp_path / "w.py"
+    f.write_text(script)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(f)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
