@@ -52,6 +52,7 @@ struct ansfm_ctx {
 
     // workspaces
     DevBuf li, tau, scratch, cont_t, tmp_in, tmp_out, misc;
+    DevBuf gscratch, dkbuf, trold_ws, dspec_i, dcont_t, tmp_in2, tmp_out2;
     DevBuf hb[24];  // staging buffers of the host-pointer entry points
     int last_n = 0, last_L = 0;
 
@@ -129,7 +130,8 @@ void ansfm_destroy(ansfm_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->lnK, &ctx->d_press, &ctx->d_temp, &ctx->d_wave, &ctx->d_delg, &ctx->d_flag,
                       &ctx->li, &ctx->tau, &ctx->scratch, &ctx->cont_t, &ctx->tmp_in, &ctx->tmp_out,
-                      &ctx->misc};
+                      &ctx->misc, &ctx->gscratch, &ctx->dkbuf, &ctx->trold_ws, &ctx->dspec_i, &ctx->dcont_t,
+                      &ctx->tmp_in2, &ctx->tmp_out2};
     for (auto *b : bufs) b->release();
     for (auto &b : ctx->hb) b.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -601,6 +603,250 @@ int ansfm_thermal_emission(ansfm_ctx *ctx, int ISPACE, int W, int G, int NLAYIN,
     HIPCHK(hipMemcpyAsync(SPECOUT, ctx->tmp_out.p, (size_t)W * G * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ANSFM_OK;
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* gradient path                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const double *dkin, int W, int Wpad,
+                           int G, int S, int L, int n_models, const LayerInterp *li, const double *amount,
+                           const double *del_g_dev, const double *del_g_host, double *tau, double *dk)
+{
+    OverlapGParams pg;
+    memset(&pg, 0, sizeof pg);
+    OverlapParams &p = pg.o;
+    p.lnK = ctx->lnK.as<double>();
+    p.kin = kin;
+    p.li = li;
+    p.amount = amount;
+    p.del_g = del_g_dev;
+    p.tau = tau;
+    p.err_flag = ctx->d_flag.as<int>() + 1;
+    p.W = W; p.Wpad = Wpad; p.G = G; p.NT = ctx->NT; p.S = S; p.L = L; p.n_models = n_models;
+    loser_tree_init(G, p.init_loser, &p.depth);
+    p.delg_f32 = ctx->delg_f32;
+    {
+        double acc = 0.0;
+        float accf = 0.0f;
+        p.g_ord[0] = 0.0;
+        for (int g = 0; g < G; ++g) {
+            if (ctx->delg_f32) { accf += (float)del_g_host[g]; p.g_ord[g + 1] = (double)accf; }
+            else { acc += del_g_host[g]; p.g_ord[g + 1] = acc; }
+        }
+        p.g_ord[G] = 1.0;
+        p.g_ord[G + 1] = __builtin_inf();
+    }
+    pg.dkin = dkin;
+    pg.dk = dk;
+    const int NP1 = S + 1;
+    if (NP1 > 21) FAIL(ANSFM_ERR_UNSUPPORTED, "gradient path supports at most 20 spectroscopic gases");
+    const size_t lds = (size_t)G * kWave * (3 * sizeof(double)) + (size_t)(2 * kMaxG + 2) * sizeof(double);
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    const long ntiles = (long)n_models * (Wpad / kWave) * L;
+    long grid = (long)ctx->num_cus * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    if (grid < 1) grid = 1;
+    HIPCHK(ctx->scratch.reserve((size_t)grid * 2 * G * kWave * sizeof(double)));
+    HIPCHK(ctx->gscratch.reserve((size_t)grid * (2 + 2 * (size_t)NP1) * G * kWave * sizeof(double)));
+    p.scratch = ctx->scratch.as<double>();
+    pg.gscratch = ctx->gscratch.as<double>();
+#define LAUNCH_OVG(MP, FK)                                                                                  \
+    hipLaunchKernelGGL((k_ck_overlapg<5, MP, FK>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg)
+    if (from_k) {
+        if (NP1 <= 5) LAUNCH_OVG(5, true); else if (NP1 <= 9) LAUNCH_OVG(9, true); else LAUNCH_OVG(21, true);
+    } else {
+        if (NP1 <= 5) LAUNCH_OVG(5, false); else if (NP1 <= 9) LAUNCH_OVG(9, false); else LAUNCH_OVG(21, false);
+    }
+#undef LAUNCH_OVG
+    HIPCHK(hipGetLastError());
+    return ANSFM_OK;
+}
+
+int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L, const double *lay_press_pa,
+                                  const double *lay_temp, const double *amount, const double *taucont,
+                                  const double *dtaucon, int NVMR, int NPAR, const int32_t *igas_map_host, int P,
+                                  int LIMAX, const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE,
+                                  const double *EMTEMP, const double *TSURF, const double *EMISSIVITY,
+                                  const double *xfac, double *SPECOUT, double *dSPECOUT, double *dTSURF)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "cirsradg: upload a k-table first");
+    if (n_models <= 0 || L <= 0 || P <= 0 || LIMAX <= 0 || !lay_press_pa || !lay_temp || !amount || !NLAYIN || !LAYINC ||
+        !SCALE || !EMTEMP || !TSURF || !SPECOUT || !dSPECOUT || !dTSURF || !igas_map_host || NPAR <= 0 ||
+        NPAR > kMaxPar || NVMR < 0 || NVMR >= NPAR || (ISPACE != 0 && ISPACE != 1))
+        FAIL(ANSFM_ERR_INVALID, "cirsradg: bad argument (NPAR <= 64)");
+    if (!ctx->monotone)
+        FAIL(ANSFM_ERR_UNSORTED, "k-table is not non-negative and non-decreasing in g: generic merge path not built");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, S = ctx->S, NP1 = S + 1;
+    HIPCHK(ctx->li.reserve((size_t)n_models * L * sizeof(LayerInterp)));
+    HIPCHK(ctx->tau.reserve((size_t)n_models * L * G * Wpad * sizeof(double)));
+    HIPCHK(ctx->dkbuf.reserve((size_t)n_models * L * NP1 * G * Wpad * sizeof(double)));
+    HIPCHK(ctx->trold_ws.reserve((size_t)n_models * P * (LIMAX + 1) * G * Wpad * sizeof(double)));
+    HIPCHK(ctx->dspec_i.reserve((size_t)n_models * P * NPAR * LIMAX * Wpad * sizeof(double)));
+    HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_layer_prep, dim3(nblk((size_t)n_models * L, 128)), dim3(128), 0, ctx->stream, n_models * L,
+                       lay_press_pa, lay_temp, ctx->NP, ctx->d_press.as<double>(), ctx->NT, ctx->d_temp.as<double>(),
+                       101325.0, ctx->grid_f32, ctx->li.as<LayerInterp>());
+    HIPCHK(hipGetLastError());
+    const double *cont_t = nullptr, *dcont_t = nullptr;
+    if (taucont) {
+        HIPCHK(ctx->cont_t.reserve((size_t)n_models * L * Wpad * sizeof(double)));
+        for (int m = 0; m < n_models; ++m)
+            hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256)), dim3(256), 0, ctx->stream,
+                               taucont + (size_t)m * W * L, ctx->cont_t.as<double>() + (size_t)m * L * Wpad, W, Wpad, 1, L,
+                               0, 0.0);
+        cont_t = ctx->cont_t.as<double>();
+    }
+    if (dtaucon) {
+        HIPCHK(ctx->dcont_t.reserve((size_t)n_models * NPAR * L * Wpad * sizeof(double)));
+        for (int m = 0; m < n_models; ++m)
+            hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)NPAR * L * Wpad, 256)), dim3(256), 0, ctx->stream,
+                               dtaucon + (size_t)m * W * NPAR * L, ctx->dcont_t.as<double>() + (size_t)m * NPAR * L * Wpad,
+                               W, Wpad, NPAR, L, 0, 0.0);
+        dcont_t = ctx->dcont_t.as<double>();
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    int rc = launch_overlapg(ctx, false, nullptr, nullptr, W, Wpad, G, S, L, n_models, ctx->li.as<LayerInterp>(), amount,
+                             ctx->d_delg.as<double>(), ctx->h_delg.data(), ctx->tau.as<double>(), ctx->dkbuf.as<double>());
+    if (rc != ANSFM_OK) return rc;
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    RtGParams q;
+    memset(&q, 0, sizeof q);
+    RtParams &r = q.r;
+    r.tau = ctx->tau.as<double>();
+    r.cont = cont_t;
+    r.wave = ctx->d_wave.as<double>();
+    r.delg = ctx->d_delg.as<double>();
+    r.nlayin = NLAYIN; r.layinc = LAYINC; r.scale = SCALE; r.emtemp = EMTEMP;
+    r.lay_press = lay_press_pa; r.tsurf = TSURF;
+    r.emissivity = EMISSIVITY; r.xfac = xfac;
+    r.out = SPECOUT;
+    r.W = W; r.Wpad = Wpad; r.G = G; r.L = L; r.P = P; r.LIMAX = LIMAX; r.ispace = ISPACE; r.per_g = 0;
+    q.dk = ctx->dkbuf.as<double>();
+    q.dcont = dcont_t;
+    q.trold_ws = ctx->trold_ws.as<double>();
+    q.dspec = ctx->dspec_i.as<double>();
+    q.dtsurf = dTSURF;
+    q.NPAR = NPAR; q.NVMR = NVMR; q.NP1 = NP1;
+    for (int k = 0; k < kMaxPar; ++k) q.slot_of_param[k] = -1;
+    for (int i = 0; i < S; ++i) {   // assignment order of :3868-3870: a later gas overwrites an earlier one
+        if (igas_map_host[i] < 0 || igas_map_host[i] >= NPAR) FAIL(ANSFM_ERR_INVALID, "cirsradg: igas_map out of range");
+        q.slot_of_param[igas_map_host[i]] = (signed char)i;
+    }
+    q.slot_of_param[NVMR] = (signed char)S;   // :3872 (written last)
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    {
+        dim3 grid((unsigned)(Wpad / kWave), (unsigned)P, (unsigned)n_models);
+        const size_t lds = (size_t)(NP1 + 2) * kGY * kWave * sizeof(double);
+        hipLaunchKernelGGL(k_thermal_rtg, grid, dim3(kWave, kGY), lds, ctx->stream, q);
+        HIPCHK(hipGetLastError());
+    }
+    for (int m = 0; m < n_models; ++m) {
+        const size_t nout = (size_t)W * NPAR * LIMAX * P;
+        hipLaunchKernelGGL(k_dspec_to_ref, dim3(nblk(nout, 256)), dim3(256), 0, ctx->stream,
+                           ctx->dspec_i.as<double>() + (size_t)m * P * NPAR * LIMAX * Wpad, dSPECOUT + (size_t)m * nout, W,
+                           Wpad, NPAR, LIMAX, P, NLAYIN);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->overlap_launches = 1; ctx->rt_launches = 1;
+    ctx->last_n = n_models; ctx->last_L = L;
+    return ANSFM_OK;
+}
+
+int ansfm_cirsradg_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L, const double *lay_press_pa,
+                              const double *lay_temp, const double *amount, const double *taucont,
+                              const double *dtaucon, int NVMR, int NPAR, const int32_t *igas_map, int P, int LIMAX,
+                              const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE, const double *EMTEMP,
+                              const double *TSURF, const double *EMISSIVITY, const double *xfac, double *SPECOUT,
+                              double *dSPECOUT, double *dTSURF)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "cirsradg: upload a k-table first");
+    if (n_models <= 0 || L <= 0 || P <= 0 || LIMAX <= 0 || NPAR <= 0 || !SPECOUT || !dSPECOUT || !dTSURF)
+        FAIL(ANSFM_ERR_INVALID, "cirsradg: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int W = ctx->W, S = ctx->S;
+    const size_t D = sizeof(double);
+    const void *d[16];
+    int i = 0, rc;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(lay_press_pa, (size_t)n_models * L * D);            // 0
+    UP(lay_temp, (size_t)n_models * L * D);                // 1
+    UP(amount, (size_t)n_models * S * L * D);              // 2
+    UP(taucont, (size_t)n_models * W * L * D);             // 3
+    UP(dtaucon, (size_t)n_models * W * NPAR * L * D);      // 4
+    UP(NLAYIN, (size_t)P * sizeof(int32_t));               // 5
+    UP(LAYINC, (size_t)LIMAX * P * sizeof(int32_t));       // 6
+    UP(SCALE, (size_t)n_models * LIMAX * P * D);           // 7
+    UP(EMTEMP, (size_t)n_models * LIMAX * P * D);          // 8
+    UP(TSURF, (size_t)n_models * D);                       // 9
+    UP(EMISSIVITY, (size_t)W * D);                         // 10
+    UP(xfac, (size_t)W * D);                               // 11
+#undef UP
+    const size_t nsp = (size_t)n_models * W * P, ndsp = (size_t)n_models * W * NPAR * LIMAX * P;
+    HIPCHK(ctx->tmp_out.reserve((2 * nsp) * D));
+    HIPCHK(ctx->tmp_out2.reserve(ndsp * D));
+    double *o_spec = ctx->tmp_out.as<double>(), *o_dts = o_spec + nsp;
+    rc = ansfm_cirsradg_ck_thermal_dev(ctx, ISPACE, n_models, L, (const double *)d[0], (const double *)d[1],
+                                       (const double *)d[2], (const double *)d[3], (const double *)d[4], NVMR, NPAR,
+                                       igas_map, P, LIMAX, (const int32_t *)d[5], (const int32_t *)d[6],
+                                       (const double *)d[7], (const double *)d[8], (const double *)d[9],
+                                       (const double *)d[10], (const double *)d[11], o_spec, ctx->tmp_out2.as<double>(),
+                                       o_dts);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(SPECOUT, o_spec, nsp * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dTSURF, o_dts, nsp * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dSPECOUT, ctx->tmp_out2.p, ndsp * D, hipMemcpyDeviceToHost, ctx->stream));
+    return check_unsorted(ctx);
+}
+
+int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *del_g, const double *k,
+                     const double *dkdT, const double *amount, double *tau, double *dk)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || G <= 0 || G > ANSFM_MAX_NG || L <= 0 || S <= 0 || !del_g || !k || !dkdT || !amount || !tau || !dk)
+        FAIL(ANSFM_ERR_INVALID, "k_overlapg: bad argument (need 1<=G<=32)");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int Wpad = round_up(W, kWave), NP1 = S + 1;
+    const size_t nk = (size_t)W * G * L * S;
+    const void *dkk, *ddk, *dam, *ddg;
+    int rc;
+    if ((rc = h2d(ctx, ctx->hb[0], k, nk * sizeof(double), &dkk))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[3], dkdT, nk * sizeof(double), &ddk))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[1], amount, (size_t)S * L * sizeof(double), &dam))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[2], del_g, (size_t)G * sizeof(double), &ddg))) return rc;
+    HIPCHK(ctx->d_flag.reserve(4 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+    const size_t nkin = (size_t)S * L * G * Wpad;
+    HIPCHK(ctx->tmp_in.reserve(nkin * sizeof(double)));
+    HIPCHK(ctx->tmp_in2.reserve(nkin * sizeof(double)));
+    hipLaunchKernelGGL(k_kin_permute, dim3(nblk(nkin, 256)), dim3(256), 0, ctx->stream, (const double *)dkk,
+                       ctx->tmp_in.as<double>(), W, Wpad, G, L, S);
+    hipLaunchKernelGGL(k_kin_permute, dim3(nblk(nkin, 256)), dim3(256), 0, ctx->stream, (const double *)ddk,
+                       ctx->tmp_in2.as<double>(), W, Wpad, G, L, S);
+    HIPCHK(hipGetLastError());
+    HIPCHK(ctx->misc.reserve((size_t)L * G * Wpad * sizeof(double)));
+    HIPCHK(ctx->dkbuf.reserve((size_t)L * NP1 * G * Wpad * sizeof(double)));
+    rc = launch_overlapg(ctx, true, ctx->tmp_in.as<double>(), ctx->tmp_in2.as<double>(), W, Wpad, G, S, L, 1, nullptr,
+                         (const double *)dam, (const double *)ddg, del_g, ctx->misc.as<double>(), ctx->dkbuf.as<double>());
+    if (rc) return rc;
+    const size_t nout = (size_t)W * G * L, ndk = nout * NP1;
+    HIPCHK(ctx->tmp_out.reserve(nout * sizeof(double)));
+    HIPCHK(ctx->tmp_out2.reserve(ndk * sizeof(double)));
+    hipLaunchKernelGGL(k_w_to_first, dim3(nblk(nout, 256)), dim3(256), 0, ctx->stream, ctx->misc.as<double>(),
+                       ctx->tmp_out.as<double>(), W, Wpad, L, G, 1);
+    hipLaunchKernelGGL(k_dk_to_ref, dim3(nblk(ndk, 256)), dim3(256), 0, ctx->stream, ctx->dkbuf.as<double>(),
+                       ctx->tmp_out2.as<double>(), W, Wpad, G, L, NP1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(tau, ctx->tmp_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dk, ctx->tmp_out2.p, ndk * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return check_unsorted(ctx);
 }
 
 }  // extern "C"

@@ -416,6 +416,267 @@ __global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1g+K2g fused: calc_kg + k_overlapg/rankg (ForwardModel_0.py:5842-6026).   "ck_overlapg"
+// Same streaming merge; the gradient rows random_grad[iloop,:n] (:5918-5921, :5946-5949) of the
+// element being consumed are formed on the fly from the previous stage's dk_g_param rows
+// (D[p][g], global ping-pong workspace, gathered by row index) and the new gas's k / dkdT*amount,
+// and accumulated per bin exactly like rankg (:6002-6025).  Slot bookkeeping of the skip
+// branches (:5897-5937) is reproduced, including the stale slots they leave behind.
+// ------------------------------------------------------------------------------------------------
+struct OverlapGParams {
+    OverlapParams o;
+    const double *dkin;   // FROM_K: dkdT[S][L][G][Wpad]
+    double *dk;           // out [n][L][S+1][G][Wpad]
+    double *gscratch;     // [gridDim.x][ (2 + 2*(S+1)) ][G][64]   KRB, DTB, Dbuf0, Dbuf1
+};
+
+template <bool FROM_K>
+__device__ __forceinline__ void load_gas_g(const OverlapGParams &pg, const LayerInterp &q, int m, int l, int s,
+                                           int nu, double *DST, double *KR, double *DT, int lane, bool &unsorted)
+{
+    const OverlapParams &p = pg.o;
+    const int G = p.G;
+    const double amt = p.amount[((size_t)m * p.S + s) * p.L + l];
+    double prev = -__builtin_inf();
+    if constexpr (FROM_K) {
+        const size_t base = (((size_t)s * p.L + l) * G) * p.Wpad + nu;
+        for (int g = 0; g < G; ++g) {
+            const double kraw = p.kin[base + (size_t)g * p.Wpad];
+            const double dkr = pg.dkin[base + (size_t)g * p.Wpad];
+            const double kk = kraw * amt;
+            DST[g * kWave + lane] = kk;
+            KR[g * kWave + lane] = kraw;
+            DT[g * kWave + lane] = dkr * amt;
+            unsorted |= (kk < prev);
+            prev = kk;
+        }
+    } else {
+        const size_t strideT = (size_t)p.S * G * p.Wpad;
+        const size_t off = (size_t)s * G * p.Wpad + nu;
+        const double *c1 = p.lnK + ((size_t)q.ipl * p.NT + q.itl) * strideT + off;
+        const double *c2 = p.lnK + ((size_t)q.ipl * p.NT + q.ith) * strideT + off;
+        const double *c3 = p.lnK + ((size_t)q.iph * p.NT + q.itl) * strideT + off;
+        const double *c4 = p.lnK + ((size_t)q.iph * p.NT + q.ith) * strideT + off;
+        for (int g = 0; g < G; ++g) {
+            size_t go = (size_t)g * p.Wpad;
+            double kraw, dkr;
+            interp_kg(c1[go], c2[go], c3[go], c4[go], q.v, q.u, q.dudt, kraw, dkr);
+            const double kk = kraw * amt;
+            DST[g * kWave + lane] = kk;
+            KR[g * kWave + lane] = kraw;
+            DT[g * kWave + lane] = dkr * amt;
+            unsorted |= (kk < prev);
+            prev = kk;
+        }
+    }
+}
+
+template <int DEPTH, int MAXP, bool FROM_K>
+__global__ __launch_bounds__(kWave) void k_ck_overlapg(OverlapGParams pg)
+{
+    const OverlapParams &p = pg.o;
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int G = p.G;
+    const int NP1 = p.S + 1;
+    double *A = smem;
+    double *B = A + G * kWave;
+    double *NV = B + G * kWave;
+    double *DG = NV + G * kWave;
+    double *GORD = DG + kMaxG;
+    if (lane < G) DG[lane] = p.del_g[lane];
+    if (lane < G + 2) GORD[lane] = p.g_ord[lane];
+    __syncthreads();
+    const bool w32 = p.delg_f32 != 0;
+    double wsum = 0.0;
+    for (int g = 0; g < G; ++g) wsum += DG[g];
+    const double wtot = wsum * wsum;
+
+    double *scrK = p.scratch + (size_t)blockIdx.x * 2 * G * kWave;
+    double *scrS = scrK + G * kWave;
+    const size_t GW = (size_t)G * kWave;
+    double *gs = pg.gscratch + (size_t)blockIdx.x * (2 + 2 * (size_t)NP1) * GW;
+    double *KRB = gs, *DTB = gs + GW;
+    double *Dbuf[2] = {gs + 2 * GW, gs + (2 + (size_t)NP1) * GW};
+    const int NVT = p.Wpad / kWave;
+    const long ntiles = (long)p.n_models * NVT * p.L;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int l = (int)(tile % p.L);
+        const long r = tile / p.L;
+        const int vt = (int)(r % NVT);
+        const int m = (int)(r / NVT);
+        const int nu = vt * kWave + lane;
+        LayerInterp q;
+        if constexpr (!FROM_K) q = p.li[(size_t)m * p.L + l];
+        bool unsorted = false;
+        int cur = 0;
+        // gas 0: a = k0*amount0 ; D[0] = k0 (d/d amount0), D[1] = dkdT0*amount0 (d/dT), rest 0
+        load_gas_g<FROM_K>(pg, q, m, l, 0, nu, A, Dbuf[0], Dbuf[0] + GW, lane, unsorted);
+        for (int pp = 2; pp < NP1; ++pp)
+            for (int g = 0; g < G; ++g) Dbuf[0][(size_t)pp * GW + g * kWave + lane] = 0.0;
+
+        for (int s = 1; s < p.S; ++s) {
+            const int igas = s - 1;
+            const int n = igas + 3;  // rankg's `n`
+            load_gas_g<FROM_K>(pg, q, m, l, s, nu, B, KRB, DTB, lane, unsorted);
+            double *Dold = Dbuf[cur], *Dnew = Dbuf[cur ^ 1];
+            const double alast = A[(G - 1) * kWave + lane];
+            const double blast = B[(G - 1) * kWave + lane];
+            bool takeB, keepA;
+            if (s == 1) { takeB = (alast <= 0.0); keepA = !takeB && (blast <= 0.0); }
+            else { keepA = (blast <= 0.0); takeB = !keepA && (alast <= 0.0); }
+            const bool do_merge = !(takeB | keepA);
+            if (!do_merge) {
+                // skip branches :5897-5907, :5930-5937 (slots beyond the ones written keep their old content)
+                for (int pp = 0; pp < NP1; ++pp)
+                    for (int g = 0; g < G; ++g) {
+                        const size_t o = (size_t)pp * GW + g * kWave + lane;
+                        double v = Dold[o];
+                        if (keepA) {
+                            if (pp == igas + 2) v = Dold[(size_t)(igas + 1) * GW + g * kWave + lane];
+                            else if (pp == igas + 1) v = 0.0;
+                        } else {  // takeB
+                            if (pp == igas + 1) v = KRB[g * kWave + lane];
+                            else if (pp == igas + 2) v = DTB[g * kWave + lane];
+                            else if (s == 1 && pp == 0) v = 0.0;
+                        }
+                        Dnew[o] = v;
+                    }
+                if (takeB)
+                    for (int g = 0; g < G; ++g) A[g * kWave + lane] = B[g * kWave + lane];
+            } else {
+                const double b0 = B[lane];
+                for (int x = 1; x < G; ++x) {
+                    const int row = p.init_loser[x];
+                    NV[x * kWave + lane] = pack_key(A[row * kWave + lane] + b0, row, 0);
+                }
+                NV[lane] = sentinel_key(31);
+                for (int g = 0; g < G; ++g) { scrK[g * kWave + lane] = 0.0; scrS[g * kWave + lane] = 1.0; }
+                for (int pp = 0; pp < NP1; ++pp)
+                    for (int g = 0; g < G; ++g) Dnew[(size_t)pp * GW + g * kWave + lane] = 0.0;
+                double ckey = pack_key(A[lane] + b0, 0, 0);
+                double gd = 0.0, kacc = 0.0, sum1 = 0.0, gnext = GORD[1];
+                double acc[MAXP];
+#pragma unroll
+                for (int pp = 0; pp < MAXP; ++pp) acc[pp] = 0.0;
+                int ig = 0;
+                const int nloop = G * G;
+                for (int it = 0; it < nloop; ++it) {
+                    const unsigned kb = (unsigned)__double_as_longlong(ckey);
+                    const int ci = kb & 31, cp = (kb >> 5) & 31;
+                    const int np = cp + 1;
+                    const int npc = np < G ? np : G - 1;
+                    const double ai = A[ci * kWave + lane];
+                    const double bc = B[cp * kWave + lane];
+                    const double bn = B[npc * kWave + lane];
+                    double w = DG[ci] * DG[cp];
+                    if (w32) w = (double)(float)w;
+                    const int x0 = (G + ci) >> 1;
+                    double tv[DEPTH];
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) tv[d] = NV[(x0 >> d) * kWave + lane];
+                    // gradient row of this element (:5946-5949)
+                    const double kbv = KRB[cp * kWave + lane];
+                    const double dtb = DTB[cp * kWave + lane];
+                    const double doldT = Dold[(size_t)(igas + 1) * GW + ci * kWave + lane];
+                    double gw[MAXP];
+#pragma unroll
+                    for (int pp = 0; pp < MAXP; ++pp) {
+                        if (pp < n) {
+                            double gp;
+                            if (pp <= igas) gp = Dold[(size_t)pp * GW + ci * kWave + lane];
+                            else if (pp == igas + 1) gp = kbv;
+                            else gp = doldT + dtb;
+                            gw[pp] = gp * w;
+                        }
+                    }
+                    double car = (np < G) ? pack_key(ai + bn, ci, np) : sentinel_key(ci);
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) {
+                        double lo, hi;
+                        minmax_f64(tv[d], car, lo, hi);
+                        NV[(x0 >> d) * kWave + lane] = hi;
+                        car = lo;
+                    }
+                    ckey = car;
+                    const double cv = ai + bc;
+                    const double gdn = gd + w;
+                    const double cw = cv * w;
+                    if (ig < G) {
+                        if (gdn < gnext) {
+                            kacc += cw;
+                            sum1 += w;
+#pragma unroll
+                            for (int pp = 0; pp < MAXP; ++pp)
+                                if (pp < n) acc[pp] += gw[pp];
+                        } else {
+                            const double gprev = (it == 0) ? wtot : gd;
+                            const double frac = fast_div(gnext - gprev, gdn - gprev);
+                            scrK[ig * kWave + lane] = kacc + frac * cw;
+                            scrS[ig * kWave + lane] = sum1 + frac * w;
+#pragma unroll
+                            for (int pp = 0; pp < MAXP; ++pp)
+                                if (pp < n) {
+                                    Dnew[(size_t)pp * GW + ig * kWave + lane] = acc[pp] + frac * gw[pp];
+                                    acc[pp] = (1.0 - frac) * gw[pp];
+                                }
+                            ig += 1;
+                            sum1 = (1.0 - frac) * w;
+                            kacc = (1.0 - frac) * cw;
+                            gnext = GORD[ig + 1];
+                        }
+                    }
+                    gd = gdn;
+                }
+                if (ig < G) {
+                    scrK[ig * kWave + lane] = kacc;
+                    scrS[ig * kWave + lane] = (ig == G - 1) ? sum1 : 1.0;
+#pragma unroll
+                    for (int pp = 0; pp < MAXP; ++pp)
+                        if (pp < n) Dnew[(size_t)pp * GW + ig * kWave + lane] = acc[pp];
+                }
+                for (int g = 0; g < G; ++g) {
+                    const double ss = scrS[g * kWave + lane];
+                    A[g * kWave + lane] = scrK[g * kWave + lane] / ss;
+                    for (int pp = 0; pp < n; ++pp) {
+                        const size_t o = (size_t)pp * GW + g * kWave + lane;
+                        Dnew[o] = Dnew[o] / ss;
+                    }
+                }
+            }
+            cur ^= 1;
+        }
+        if (unsorted) atomicOr(p.err_flag, 1);
+        double *out = p.tau + (((size_t)m * p.L + l) * G) * p.Wpad + nu;
+        for (int g = 0; g < G; ++g) out[(size_t)g * p.Wpad] = A[g * kWave + lane];
+        double *dout = pg.dk + (((size_t)m * p.L + l) * NP1) * G * p.Wpad + nu;
+        const double *Dc = Dbuf[cur];
+        if (p.S == 1) {
+            // NGAS == 1 shortcut (:5871-5876): tau = k*amount, dk[...,0] = k, dk[...,1] = dkdT*amount
+        }
+        for (int pp = 0; pp < NP1; ++pp)
+            for (int g = 0; g < G; ++g)
+                dout[((size_t)pp * G + g) * p.Wpad] = Dc[(size_t)pp * GW + g * kWave + lane];
+    }
+}
+
+// internal dk[L][NP1][G][Wpad] -> reference dk[W][G][L][NP1]   (array-level k_overlapg seam)
+__global__ void k_dk_to_ref(const double *__restrict__ src, double *__restrict__ dst, int W, int Wpad, int G,
+                            int L, int NP1)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)W * G * L * NP1;
+    if (idx >= total) return;
+    int pp = (int)(idx % NP1);
+    size_t r = idx / NP1;
+    int l = (int)(r % L); r /= L;
+    int g = (int)(r % G);
+    int w = (int)(r / G);
+    dst[idx] = src[(((size_t)l * NP1 + pp) * G + g) * Wpad + w];
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3+K4+K5+K6 fused: total opacity, LAYINC gather * SCALE, layer loop with Planck emission,
 // ground / solar terms, unit factor and g-quadrature.   "thermal_rt"
 // Block = 64 wavenumbers x GY g-groups; thread (lane, gy) integrates g = gy, gy+GY, ...
@@ -538,6 +799,207 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
             p.out[((size_t)m * p.W + nu) * p.P + ip] = t;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3g+K4g+K6: thermal emission with analytic gradients.   "thermal_rtg"
+// calc_thermal_emission_spectrumg (ForwardModel_0.py:6380-6504) carries dtr/dq for every
+// (parameter, layer) through the layer loop: O(NPAR*Li^2) per (nu,g).  The recursion is linear in
+// dTAU, so   dspec/dq[k,m] = c_m * dTAU[k,m]  (+ (trold_m - tr_m) dB/dT_m for k == NVMR)   with
+//     c_m = tr_m B_m - R_m ,   R_m = sum_{j>m} (trold_j - tr_j) B_j + trold_N * radground ,
+// one backward sweep (O(Li)); the g-quadrature (:4507) is folded in:
+//     out[k,m] = xfac * ( SCALE_m * ( fac_k * sum_g dg c_g dk[slot_k][g] + dcont_k * sum_g dg c_g )
+//                         + [k==NVMR] dBdT_m * sum_g dg (trold_m - tr_m)_g )
+// so neither dTAUTOT_LAYINC (W,G,NPAR,Li,P) nor dSPECOUT (W,G,NPAR,Li) is materialised.
+// Block = 64 wavenumbers x 4 g-groups; pass 1 stores trold_j per (g) to a workspace.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxPar = 64;
+struct RtGParams {
+    RtParams r;              // r.out = SPECOUT [n][W][P]
+    const double *dk;        // [n][L][NP1][G][Wpad]
+    const double *dcont;     // [n][NPAR][L][Wpad] or nullptr   (dTAUCON)
+    double *trold_ws;        // [n][P][LIMAX+1][G][Wpad]
+    double *dspec;           // [n][P][NPAR][LIMAX][Wpad]   (internal layout)
+    double *dtsurf;          // [n][W][P]
+    int NPAR, NVMR, NP1;
+    signed char slot_of_param[kMaxPar];   // -1 none, 0..S-1 gas slot (x1e-4), S = temperature slot
+};
+
+__device__ __forceinline__ void planckg_dev(int ispace, double y, double T, double &bb, double &dBdT)
+{
+    const double c1 = 1.1911e-12, c2 = 1.439;
+    double a, ap;
+    if (ispace == 0) { a = c1 * (y * y * y); ap = c1 * c2 * (y * y * y * y) / (T * T); }
+    else { a = c1 * (y * y * y * y * y) / 1.0e4; ap = c1 * c2 * (y * y * y * y * y * y) / 1.0e4 / (T * T); }
+    const double e = exp(c2 * y / T);
+    const double b = e - 1.0;
+    bb = a / b;
+    dBdT = e * ap / (b * b);   // ForwardModel_0.py:6274-6281
+}
+
+__global__ __launch_bounds__(kWave *kGY) void k_thermal_rtg(RtGParams q)
+{
+    const RtParams &p = q.r;
+    extern __shared__ double red[];  // [NP1+2][kGY][kWave]
+    const int lane = threadIdx.x, gy = threadIdx.y;
+    const int nu = blockIdx.x * kWave + lane;
+    const int nuc = nu < p.W ? nu : p.W - 1;
+    const int ip = blockIdx.y, m = blockIdx.z;
+    const int nl = p.nlayin[ip];
+    const int G = p.G, NP1 = q.NP1, NR = NP1 + 2;
+    const double wv = p.wave[nuc];
+    const double y = (p.ispace == 0) ? wv : 1.0e4 / wv;
+    const size_t pathbase = (size_t)m * p.LIMAX * p.P + ip;
+    const size_t GWp = (size_t)G * p.Wpad;
+    double *tws = q.trold_ws + (((size_t)m * p.P + ip) * (p.LIMAX + 1)) * GWp + nu;
+
+    double trold[kGPer], spec[kGPer];
+#pragma unroll
+    for (int k = 0; k < kGPer; ++k) { trold[k] = 1.0; spec[k] = 0.0; }
+    // ---- pass 1: forward, product form tr = trold*exp(-tau_j) (:6446-6452) -----------------------------
+    for (int j = 0; j < nl; ++j) {
+        const int lay = p.layinc[(size_t)j * p.P + ip];
+        const double sc = p.scale[pathbase + (size_t)j * p.P];
+        const double T = p.emtemp[pathbase + (size_t)j * p.P];
+        const double tc = p.cont ? p.cont[((size_t)m * p.L + lay) * p.Wpad + nu] : 0.0;
+        double bb, dB;
+        planckg_dev(p.ispace, y, T, bb, dB);
+        const double *trow = p.tau + (((size_t)m * p.L + lay) * G) * p.Wpad + nu;
+#pragma unroll
+        for (int k = 0; k < kGPer; ++k) {
+            const int g = gy + k * kGY;
+            if (g < G) {
+                tws[(size_t)j * GWp + (size_t)g * p.Wpad] = trold[k];
+                const double t = (trow[(size_t)g * p.Wpad] + tc) * sc;
+                const double tr = trold[k] * exp(-t);
+                spec[k] += (trold[k] - tr) * bb;
+                trold[k] = tr;
+            }
+        }
+    }
+    int i1 = (int)(nl / 2.0) - 1;
+    if (i1 < 0) i1 += nl;
+    const double *lp = p.lay_press + (size_t)m * p.L;
+    const bool ground = lp[p.layinc[(size_t)(nl - 1) * p.P + ip]] > lp[p.layinc[(size_t)i1 * p.P + ip]];
+    double radground = 0.0, dradgrounddT = 0.0;
+    if (ground) {
+        const double ts = p.tsurf[m];
+        if (ts <= 0.0) planckg_dev(p.ispace, y, p.emtemp[pathbase + (size_t)(nl - 1) * p.P], radground, dradgrounddT);
+        else {
+            planckg_dev(p.ispace, y, ts, radground, dradgrounddT);
+            const double em = p.emissivity ? p.emissivity[nuc] : 0.0;
+            radground *= em;
+            dradgrounddT *= em;
+        }
+    }
+    const double xf = p.xfac ? p.xfac[nuc] : 1.0;
+    double R[kGPer];
+    {
+        double accs = 0.0, acct = 0.0;
+#pragma unroll
+        for (int k = 0; k < kGPer; ++k) {
+            const int g = gy + k * kGY;
+            R[k] = 0.0;
+            if (g < G) {
+                double sgl = spec[k];
+                if (ground) sgl += trold[k] * radground;
+                accs += (sgl * xf) * p.delg[g];
+                acct += ((ground ? trold[k] * dradgrounddT : 0.0) * xf) * p.delg[g];
+                R[k] = ground ? trold[k] * radground : 0.0;
+            }
+        }
+        red[(0 * kGY + gy) * kWave + lane] = accs;
+        red[(1 * kGY + gy) * kWave + lane] = acct;
+        __syncthreads();
+        if (gy == 0 && nu < p.W) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int k = 0; k < kGY; ++k) { a += red[(0 * kGY + k) * kWave + lane]; b += red[(1 * kGY + k) * kWave + lane]; }
+            p.out[((size_t)m * p.W + nu) * p.P + ip] = a;
+            q.dtsurf[((size_t)m * p.W + nu) * p.P + ip] = b;
+        }
+        __syncthreads();
+    }
+    // ---- pass 2: backward sweep ------------------------------------------------------------------------
+    double trnext[kGPer];  // tr_m = trold_{m+1}
+#pragma unroll
+    for (int k = 0; k < kGPer; ++k) trnext[k] = trold[k];
+    double *dsp = q.dspec + (((size_t)m * p.P + ip) * q.NPAR) * (size_t)p.LIMAX * p.Wpad + nu;
+    for (int mm = nl - 1; mm >= 0; --mm) {
+        const int lay = p.layinc[(size_t)mm * p.P + ip];
+        const double sc = p.scale[pathbase + (size_t)mm * p.P];
+        const double T = p.emtemp[pathbase + (size_t)mm * p.P];
+        double bb, dB;
+        planckg_dev(p.ispace, y, T, bb, dB);
+        const double *dkl = q.dk + (((size_t)m * p.L + lay) * NP1) * GWp + nu;
+        double X = 0.0, Z = 0.0;
+        double *rb = red;
+        (void)NR;
+        double cg[kGPer];
+#pragma unroll
+        for (int k = 0; k < kGPer; ++k) {
+            const int g = gy + k * kGY;
+            cg[k] = 0.0;
+            if (g < G) {
+                const double to = tws[(size_t)mm * GWp + (size_t)g * p.Wpad];
+                const double tr = trnext[k];
+                const double c = tr * bb - R[k];
+                const double dgk = p.delg[g];
+                cg[k] = c * dgk;
+                X += cg[k];
+                Z += (to - tr) * dgk;
+                R[k] += (to - tr) * bb;
+                trnext[k] = to;
+            }
+        }
+        __syncthreads();   // the previous layer's partial sums have been consumed by every thread
+        for (int sidx = 0; sidx < NP1; ++sidx) {
+            double ysum = 0.0;
+#pragma unroll
+            for (int k = 0; k < kGPer; ++k) {
+                const int g = gy + k * kGY;
+                if (g < G) ysum += cg[k] * dkl[((size_t)sidx * G + g) * p.Wpad];
+            }
+            rb[((2 + sidx) * kGY + gy) * kWave + lane] = ysum;
+        }
+        rb[(0 * kGY + gy) * kWave + lane] = X;
+        rb[(1 * kGY + gy) * kWave + lane] = Z;
+        __syncthreads();
+        double Xs = 0.0, Zs = 0.0;
+#pragma unroll
+        for (int k = 0; k < kGY; ++k) { Xs += rb[(0 * kGY + k) * kWave + lane]; Zs += rb[(1 * kGY + k) * kWave + lane]; }
+        for (int kpar = gy; kpar < q.NPAR; kpar += kGY) {
+            const int slot = q.slot_of_param[kpar];
+            double v = 0.0;
+            if (slot >= 0) {
+                double ys = 0.0;
+#pragma unroll
+                for (int k = 0; k < kGY; ++k) ys += rb[((2 + slot) * kGY + k) * kWave + lane];
+                v = ys * ((slot == NP1 - 1) ? 1.0 : 1.0e-4);      // :3870 / :3872
+            }
+            if (q.dcont) v += q.dcont[(((size_t)m * q.NPAR + kpar) * p.L + lay) * p.Wpad + nu] * Xs;
+            v *= sc;                                               // :4012
+            if (kpar == q.NVMR) v += Zs * dB;                      // :6467-6468
+            v *= xf;                                               // :4247
+            if (v != v) v = 0.0;                                   // nan_to_num :4507
+            dsp[((size_t)kpar * p.LIMAX + mm) * p.Wpad] = v;
+        }
+    }
+}
+
+// internal dspec[P][NPAR][LIMAX][Wpad] -> reference dSPECOUT[W][NPAR][LIMAX][P]
+__global__ void k_dspec_to_ref(const double *__restrict__ src, double *__restrict__ dst, int W, int Wpad,
+                               int NPAR, int LIMAX, int P, const int32_t *__restrict__ nlayin)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)W * NPAR * LIMAX * P;
+    if (idx >= total) return;
+    int ip = (int)(idx % P);
+    size_t r = idx / P;
+    int j = (int)(r % LIMAX); r /= LIMAX;
+    int k = (int)(r % NPAR);
+    int w = (int)(r / NPAR);
+    dst[idx] = (j < nlayin[ip]) ? src[(((size_t)ip * NPAR + k) * LIMAX + j) * Wpad + w] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -117,6 +117,17 @@ class AnsfmEngine:
                     "k_overlap")
         return tau
 
+    def k_overlapg(self, del_g, k_w_g_l_gas, dkdT_w_g_l_gas, amount_layer):
+        self.set_f32_semantics(getattr(self, "grid_f32", False), _is_f32(del_g))
+        del_g = _np(del_g); k = _np(k_w_g_l_gas); dkdT = _np(dkdT_w_g_l_gas); am = _np(amount_layer)
+        W, G, L, S = k.shape
+        if am.shape != (S, L) or dkdT.shape != k.shape:
+            raise ValueError("shapes: k, dkdT (NWAVE,NG,NLAYER,NGAS); amount (NGAS,NLAYER)")
+        tau = np.empty((W, G, L)); dk = np.empty((W, G, L, S + 1))
+        self._check(self._lib.ansfm_k_overlapg(self._ctx, W, G, L, S, _ptr(del_g), _ptr(k), _ptr(dkdT), _ptr(am),
+                                               _ptr(tau), _ptr(dk)), "k_overlapg")
+        return tau, dk
+
     def calc_thermal_emission_spectrum(self, ISPACE, WAVE, TAUTOT_PATH, EMITOT_PATH, TEMP, PRESS, TSURF,
                                        EMISSIVITY, SOLFLUX, REFLECTANCE, SOL_ANG, EMISS_ANG):
         WAVE = _np(WAVE); TAU = _np(TAUTOT_PATH); EMI = _np(EMITOT_PATH)
@@ -156,6 +167,34 @@ class AnsfmEngine:
             _ptr(None if EMISS_ANG is None else _np(np.atleast_1d(EMISS_ANG))), _ptr(_np(xfac)), _ptr(out))
         self._check(rc, "cirsrad_ck_thermal")
         return out[0] if single else out
+
+    def cirsradg_ck_thermal(self, ISPACE, lay_press_pa, lay_temp, amount, taucont, dtaucon, NVMR, NPAR, igas_map,
+                            NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None, xfac=None):
+        """CIRSrad(return_grad=True): returns SPECOUT (n,W,P), dSPECOUT (n,W,NPAR,LIMAX,P), dTSURF (n,W,P)
+        (leading axis dropped for a single model)."""
+        W, G, NP, NT, S = self.dims
+        lay_press_pa = _np(lay_press_pa)
+        single = lay_press_pa.ndim == 1
+        lp = np.atleast_2d(lay_press_pa); n, L = lp.shape
+        lt = _np(np.atleast_2d(_np(lay_temp)))
+        am = _np(amount).reshape(n, S, L)
+        tc = None if taucont is None else _np(taucont).reshape(n, W, L)
+        dtc = None if dtaucon is None else _np(dtaucon).reshape(n, W, NPAR, L)
+        LAYINC = _np(LAYINC, np.int32); NLAYIN = _np(np.atleast_1d(NLAYIN), np.int32)
+        if LAYINC.ndim == 1:
+            LAYINC = LAYINC[:, None]
+        LIMAX, P = LAYINC.shape
+        SC = _np(np.broadcast_to(_np(SCALE).reshape(-1, LIMAX, P), (n, LIMAX, P)))
+        ET = _np(np.broadcast_to(_np(EMTEMP).reshape(-1, LIMAX, P), (n, LIMAX, P)))
+        TS = _np(np.broadcast_to(np.atleast_1d(_np(TSURF)), (n,)))
+        ig = _np(igas_map, np.int32)
+        spec = np.empty((n, W, P)); dspec = np.empty((n, W, NPAR, LIMAX, P)); dts = np.empty((n, W, P))
+        rc = self._lib.ansfm_cirsradg_ck_thermal(
+            self._ctx, int(ISPACE), n, L, _ptr(lp), _ptr(lt), _ptr(am), _ptr(tc), _ptr(dtc), int(NVMR), int(NPAR),
+            _ptr(ig), P, LIMAX, _ptr(NLAYIN), _ptr(LAYINC), _ptr(SC), _ptr(ET), _ptr(TS), _ptr(_np(EMISSIVITY)),
+            _ptr(_np(xfac)), _ptr(spec), _ptr(dspec), _ptr(dts))
+        self._check(rc, "cirsradg_ck_thermal")
+        return (spec[0], dspec[0], dts[0]) if single else (spec, dspec, dts)
 
     def cirsrad_ck_thermal_dev(self, ISPACE, n_models, L, lay_press_pa, lay_temp, amount, taucont, P, LIMAX,
                                NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY, SOLFLUX, REFLECTANCE, SOL_ANG,

@@ -3,7 +3,7 @@
 `make_gpu_forward_model(ForwardModel_0)` returns a subclass of the reference's own class
 (ForwardModel_0.py:87) whose `CIRSrad` (ForwardModel_0.py:4376-4511) runs on the MI355X through
 libansfm.so for the supported case (ILBL = K_TABLES, IMOD = THERMAL_EMISSION, no layer emissions,
-return_grad=False) and whose `jacobian_nemesis` fan-out can batch the independent forward models.
+with or without analytic gradients) and whose `jacobian_nemesis` fan-out can batch the independent forward models.
 Everything else (subprofretg, calc_path, conv, ...) is the reference's own host code.
 
 `CIRSradGPU` is the mixin with the seam itself; it only needs the `*X` attributes CIRSrad reads
@@ -47,6 +47,7 @@ def _table_fingerprint(S):
     step = max(1, flat.size // 8192)
     h.update(np.ascontiguousarray(flat[::step]).tobytes())
     for a in (S.WAVE, S.PRESS, S.TEMP, S.DELG):
+        h.update(str(getattr(a, "dtype", "")).encode())          # float32 grids select float32 semantics
         h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
     return h.hexdigest()
 
@@ -60,7 +61,9 @@ class CIRSradGPU:
     # ---- what is supported -----------------------------------------------------------------------
     def _ansfm_supported(self, return_grad):
         S = self.SpectroscopyX
-        if return_grad or S.NGAS <= 0 or int(S.ILBL) != ILBL_K_TABLES:
+        if S.NGAS <= 0 or int(S.ILBL) != ILBL_K_TABLES:
+            return False
+        if return_grad and (self.AtmosphereX.NVMR + 2 + self.ScatterX.NDUST > 64 or S.NGAS > 20):
             return False
         if getattr(self, "EmissionsX", None) is not None:
             return False
@@ -74,19 +77,35 @@ class CIRSradGPU:
         return True
 
     # ---- continuum opacities: the reference's own host routines when present ---------------------
-    def _ansfm_continuum(self):
+    def _ansfm_continuum(self, return_grad=False):
+        """Returns TAUCIA, TAUDUST, TAURAY (NWAVE,NLAY) and, for return_grad, dTAUCON (NWAVE,NPAR,NLAY)
+        assembled exactly as calculate_layer_opacity does (:3916-3981)."""
         S, L = self.SpectroscopyX, self.LayerX
+        dTAUCON = None
         if hasattr(self, "calculate_vertical_cia_opacity"):
-            TAUCIA, _ = self.calculate_vertical_cia_opacity(False)          # :3938 (sets LayerX.TAUCIA)
-            TAURAY, _ = self.calc_tau_rayleigh(MakePlot=False)              # :3952
+            A, Sc = self.AtmosphereX, self.ScatterX
+            TAUCIA, dTAUCIA = self.calculate_vertical_cia_opacity(return_grad)   # :3938 (sets LayerX.TAUCIA)
+            TAURAY, dTAURAY = self.calc_tau_rayleigh(MakePlot=False)              # :3952
             L.TAURAY = TAURAY
-            TAUDUST1, TAUCLSCAT, _, _ = self.calc_tau_dust()                # :3963
-            TAUDUST1 = np.clip(np.nan_to_num(TAUDUST1), 0, 1e20)           # :3966
+            TAUDUST1, TAUCLSCAT, dTAUDUST1, dTAUCLSCAT = self.calc_tau_dust()     # :3963
+            TAUDUST1 = np.clip(np.nan_to_num(TAUDUST1), 0, 1e20)                 # :3966
             TAUDUST = np.sum(TAUDUST1, 2)
             L.TAUDUST = TAUDUST
             L.TAUSCAT = np.sum(TAUCLSCAT, 2)
             L.TAUCLSCAT = TAUCLSCAT
+            if return_grad:
+                dTAUCON = np.zeros((S.NWAVE, A.NVMR + 2 + Sc.NDUST, L.NLAY))
+                if dTAUCIA is not None:                                           # :3940-3942
+                    dTAUCON[:, 0:A.NVMR, :] += np.transpose(
+                        np.transpose(dTAUCIA[:, :, 0:A.NVMR], axes=(2, 0, 1)) / (L.TOTAM.T), axes=(1, 0, 2))
+                    dTAUCON[:, A.NVMR, :] += dTAUCIA[:, :, A.NVMR]
+                if dTAURAY is not None:                                           # :3955-3957
+                    for i in range(A.NVMR):
+                        dTAUCON[:, i, :] += dTAURAY[:, :]
+                for i in range(Sc.NDUST):                                         # :3978-3980
+                    dTAUCON[:, A.NVMR + 1 + i, :] += dTAUDUST1[:, :, i]
         else:  # standalone: continuum arrays were provided on LayerX
+            dTAUCON = getattr(L, "dTAUCON", None) if return_grad else None
             z = np.zeros((S.NWAVE, L.NLAY))
             TAUCIA = getattr(L, "TAUCIA", None)
             TAUCIA = z if TAUCIA is None else TAUCIA
@@ -94,7 +113,7 @@ class CIRSradGPU:
             TAURAY = z if TAURAY is None else TAURAY
             TAUDUST = getattr(L, "TAUDUST", None)
             TAUDUST = z if TAUDUST is None else TAUDUST
-        return TAUCIA, TAUDUST, TAURAY
+        return TAUCIA, TAUDUST, TAURAY, dTAUCON
 
     def _ansfm_units_and_surface(self):
         """xfac and EMISSIVITY exactly as calculate_thermal_emission_spectrum prepares them
@@ -136,12 +155,11 @@ class CIRSradGPU:
             base = super()
             if hasattr(base, "CIRSrad"):
                 return base.CIRSrad(return_grad)      # the reference's own implementation, in its process
-            raise NotImplementedError("CIRSrad: only ILBL=K_TABLES, IMOD=THERMAL_EMISSION, return_grad=False "
-                                      "run on the GPU so far")
+            raise NotImplementedError("CIRSrad: only ILBL=K_TABLES, IMOD=THERMAL_EMISSION run on the GPU so far")
         eng = get_engine(self.ansfm_device)
         S, L, P = self.SpectroscopyX, self.LayerX, self.PathX
         self._ansfm_upload_table(eng)
-        TAUCIA, TAUDUST, TAURAY = self._ansfm_continuum()
+        TAUCIA, TAUDUST, TAURAY, dTAUCON = self._ansfm_continuum(return_grad)
         taucont = TAUCIA + TAUDUST + TAURAY                                  # :3989 (g-independent part)
         f_gas = self._ansfm_layer_inputs()
         xfac, emissivity = self._ansfm_units_and_surface()
@@ -150,14 +168,27 @@ class CIRSradGPU:
         NLAYIN = np.asarray(P.NLAYIN, dtype=np.int32).reshape(NPATH)
         SCALE = np.asarray(P.SCALE, dtype=np.float64).reshape(-1, NPATH)
         EMTEMP = np.asarray(P.EMTEMP, dtype=np.float64).reshape(-1, NPATH)
-        SPECOUT = eng.cirsrad_ck_thermal(
-            int(self.MeasurementX.ISPACE), np.asarray(L.PRESS, dtype=np.float64), np.asarray(L.TEMP, dtype=np.float64),
-            f_gas, taucont, NLAYIN, LAYINC, SCALE, EMTEMP, float(self.SurfaceX.TSURF), EMISSIVITY=emissivity,
-            SOL_ANG=np.asarray(P.SOL_ANG, dtype=np.float64).reshape(NPATH),
-            EMISS_ANG=np.asarray(P.EMISS_ANG, dtype=np.float64).reshape(NPATH), xfac=xfac)
+        if return_grad:
+            A = self.AtmosphereX
+            NVMR = int(A.NVMR)
+            NPAR = NVMR + 2 + int(self.ScatterX.NDUST)
+            igas_map = np.array([A.locate_gas(S.ID[i], S.ISO[i]) for i in range(S.NGAS)], dtype=np.int32)
+            SPECOUT, dSPECOUT, dTSURF = eng.cirsradg_ck_thermal(
+                int(self.MeasurementX.ISPACE), np.asarray(L.PRESS, dtype=np.float64),
+                np.asarray(L.TEMP, dtype=np.float64), f_gas, taucont, dTAUCON, NVMR, NPAR, igas_map, NLAYIN, LAYINC,
+                SCALE, EMTEMP, float(self.SurfaceX.TSURF), EMISSIVITY=emissivity, xfac=xfac)
+        else:
+            SPECOUT = eng.cirsrad_ck_thermal(
+                int(self.MeasurementX.ISPACE), np.asarray(L.PRESS, dtype=np.float64),
+                np.asarray(L.TEMP, dtype=np.float64), f_gas, taucont, NLAYIN, LAYINC, SCALE, EMTEMP,
+                float(self.SurfaceX.TSURF), EMISSIVITY=emissivity,
+                SOL_ANG=np.asarray(P.SOL_ANG, dtype=np.float64).reshape(NPATH),
+                EMISS_ANG=np.asarray(P.EMISS_ANG, dtype=np.float64).reshape(NPATH), xfac=xfac)
         if self.ansfm_keep_side_products:
             L.TAUGAS = eng.get_taugas(L.NLAY, 0)                             # :3925
             L.TAUTOT = L.TAUGAS + TAUCIA[:, None, :] + TAUDUST[:, None, :] + TAURAY[:, None, :]   # :3989,:3997
+        if return_grad:
+            return SPECOUT, dSPECOUT, dTSURF          # (NWAVE,NPATH), (NWAVE,NPAR,NLAYINmax,NPATH), (NWAVE,NPATH)
         return SPECOUT                                                        # (NWAVE, NPATH)
 
 

@@ -131,6 +131,37 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
                                  const double *REFLECTANCE, const double *SOL_ANG,
                                  const double *EMISS_ANG, const double *xfac, double *SPECOUT);
 
+/* ---- analytic-gradient seams ---------------------------------------------------------------
+ * ForwardModel_0.k_overlapg (ForwardModel_0.py:5842): + dkdT[W][G][L][S] -> tau[W][G][L],
+ * dk[W][G][L][S+1] (slots 0..S-1 = d tau/d amount_gas, slot S = d tau/dT). */
+int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *del_g,
+                     const double *k, const double *dkdT, const double *amount, double *tau,
+                     double *dk);
+
+/* CIRSrad(return_grad=True), ILBL=K_TABLES, IMOD=THERMAL_EMISSION (ForwardModel_0.py:4376-4511
+ * with :3853-3872 calc_kg/k_overlapg/dTAUGAS, :3993 dTAUTOT, :4012 LAYINC*SCALE, :4233
+ * calc_thermal_emission_spectrumg, :4244-4247 xfac, :4504-4508 g-quadrature + nan_to_num).
+ *   dtaucon[n][W][NPAR][L]  dTAUCON of calculate_layer_opacity (:3916-3981) or NULL
+ *   NVMR, NPAR = NVMR+2+NDUST; igas_map[S] (HOST int32) = AtmosphereX.locate_gas(ID[i],ISO[i])
+ *   SPECOUT[n][W][P], dSPECOUT[n][W][NPAR][LIMAX][P], dTSURF[n][W][P]
+ * The reference's O(NPAR*Li^2) recursion is evaluated as one backward sweep. */
+int ansfm_cirsradg_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L,
+                              const double *lay_press_pa, const double *lay_temp,
+                              const double *amount, const double *taucont, const double *dtaucon,
+                              int NVMR, int NPAR, const int32_t *igas_map, int P, int LIMAX,
+                              const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE,
+                              const double *EMTEMP, const double *TSURF, const double *EMISSIVITY,
+                              const double *xfac, double *SPECOUT, double *dSPECOUT, double *dTSURF);
+int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L,
+                                  const double *lay_press_pa, const double *lay_temp,
+                                  const double *amount, const double *taucont,
+                                  const double *dtaucon, int NVMR, int NPAR,
+                                  const int32_t *igas_map_host, int P, int LIMAX,
+                                  const int32_t *NLAYIN, const int32_t *LAYINC,
+                                  const double *SCALE, const double *EMTEMP, const double *TSURF,
+                                  const double *EMISSIVITY, const double *xfac, double *SPECOUT,
+                                  double *dSPECOUT, double *dTSURF);
+
 /* Vertical gas opacity of the last cirsrad call's first model, TAUGAS[W][G][L]
  * (what CIRSrad leaves in LayerX.TAUGAS, ForwardModel_0.py:3925) -- host pointer out. */
 int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS);

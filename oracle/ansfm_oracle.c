@@ -680,3 +680,100 @@ ORC_API void orc_cirsrad_ck_thermal(
     free(zeros);
     free(tau);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Fused gradient seam: CIRSrad(return_grad=True), ILBL=K_TABLES, IMOD=THERMAL_EMISSION.       */
+/*   calc_kg :3853 -> k_overlapg :3865 -> dTAUGAS[:,:,IGAS,:] = dk*1e-4, dTAUGAS[:,:,NVMR,:]   */
+/*   = dk[...,NGAS] :3868-3872 -> dTAUTOT = dTAUGAS + dTAUCON :3993 -> LAYINC*SCALE :4012      */
+/*   -> calc_thermal_emission_spectrumg :4233 -> *xfac :4244-4247 -> tensordot(DELG),          */
+/*   nan_to_num :4504-4508.                                                                    */
+/* igas_map[S]: AtmosphereX.locate_gas(ID[i],ISO[i]); dTAUCON[W][NPAR][L] or NULL.             */
+/* Outputs: SPECOUT[W][P], dSPECOUT[W][NPAR][LIMAX][P], dTSURF[W][P].                          */
+/* ------------------------------------------------------------------------------------------ */
+ORC_API void orc_cirsradg_ck_thermal(
+    int ISPACE, int W, int G, int NP, int NT, int S, const double *K, const double *TPRESS,
+    const double *TTEMP, const double *WAVE, const double *DELG, int L,
+    const double *lay_press_atm, const double *lay_temp, const double *lay_press_pa,
+    const double *amount /*[S][L] cm-2*/, const double *TAUCONT /*[W][L] or NULL*/,
+    const double *dTAUCON /*[W][NPAR][L] or NULL*/, int NVMR, int NPAR, const int *igas_map,
+    int NPATH, int LIMAX, const int *NLAYIN, const int *LAYINC, const double *SCALE,
+    const double *EMTEMP, double TSURF, const double *EMISSIVITY, const double *xfac,
+    double *SPECOUT, double *dSPECOUT, double *dTSURF)
+{
+    const int NP1 = S + 1;
+    size_t nk = (size_t)W * G * L * S;
+    double *k_gas = (double *)malloc(sizeof(double) * nk);
+    double *dkdT = (double *)malloc(sizeof(double) * nk);
+    double *tau = (double *)malloc(sizeof(double) * (size_t)W * G * L);
+    double *dk = (double *)malloc(sizeof(double) * (size_t)W * G * L * NP1);
+    orc_calc_k(W, G, NP, NT, S, K, TPRESS, TTEMP, L, lay_press_atm, lay_temp, k_gas, dkdT);
+    orc_k_overlap(W, G, L, S, DELG, k_gas, dkdT, amount, tau, dk);
+    free(k_gas); free(dkdT);
+    /* dTAUTOT[W][G][NPAR][L] */
+    double *dtautot = (double *)calloc((size_t)W * G * NPAR * L, sizeof(double));
+    for (size_t w = 0; w < (size_t)W; ++w)
+        for (int g = 0; g < G; ++g) {
+            double *dst = dtautot + (w * G + g) * NPAR * L;
+            for (int i = 0; i < S; ++i)      /* assignment, later gases overwrite (:3870) */
+                for (int l = 0; l < L; ++l)
+                    dst[(size_t)igas_map[i] * L + l] = dk[((w * G + g) * L + l) * NP1 + i] * 1.0e-4;
+            for (int l = 0; l < L; ++l) dst[(size_t)NVMR * L + l] = dk[((w * G + g) * L + l) * NP1 + S];
+            if (dTAUCON)
+                for (int kpar = 0; kpar < NPAR; ++kpar)
+                    for (int l = 0; l < L; ++l) dst[(size_t)kpar * L + l] += dTAUCON[(w * NPAR + kpar) * L + l];
+        }
+    free(dk);
+    if (TAUCONT)
+        for (size_t w = 0; w < (size_t)W; ++w)
+            for (int g = 0; g < G; ++g)
+                for (int l = 0; l < L; ++l) tau[(w * G + g) * L + l] += TAUCONT[w * L + l];
+    double *zeros = (double *)calloc((size_t)W, sizeof(double));
+    memset(dSPECOUT, 0, sizeof(double) * (size_t)W * NPAR * LIMAX * NPATH);
+    for (int ip = 0; ip < NPATH; ++ip) {
+        int nl = NLAYIN[ip];
+        double *tpath = (double *)malloc(sizeof(double) * (size_t)W * G * nl);
+        double *dtpath = (double *)malloc(sizeof(double) * (size_t)W * G * NPAR * nl);
+        double *emtemp = (double *)malloc(sizeof(double) * nl);
+        double *empress = (double *)malloc(sizeof(double) * nl);
+        double *spec = (double *)malloc(sizeof(double) * (size_t)W * G);
+        double *dspec = (double *)malloc(sizeof(double) * (size_t)W * G * NPAR * nl);
+        double *dts = (double *)malloc(sizeof(double) * (size_t)W * G);
+        for (int j = 0; j < nl; ++j) {
+            int lay = LAYINC[(size_t)j * NPATH + ip];
+            emtemp[j] = EMTEMP[(size_t)j * NPATH + ip];
+            empress[j] = lay_press_pa[lay];
+        }
+        for (size_t w = 0; w < (size_t)W; ++w)
+            for (int g = 0; g < G; ++g)
+                for (int j = 0; j < nl; ++j) {
+                    int lay = LAYINC[(size_t)j * NPATH + ip];
+                    double sc = SCALE[(size_t)j * NPATH + ip];
+                    tpath[(w * G + g) * nl + j] = tau[(w * G + g) * L + lay] * sc;
+                    for (int kpar = 0; kpar < NPAR; ++kpar)
+                        dtpath[((w * G + g) * NPAR + kpar) * nl + j] =
+                            dtautot[((w * G + g) * NPAR + kpar) * L + lay] * sc;
+                }
+        orc_thermal_emissiong(ISPACE, W, G, NPAR, nl, WAVE, tpath, dtpath, NVMR, emtemp, empress, TSURF,
+                              EMISSIVITY ? EMISSIVITY : zeros, spec, dspec, dts);
+        for (size_t w = 0; w < (size_t)W; ++w) {
+            double xf = xfac ? xfac[w] : 1.0;
+            double acc = 0.0, accs = 0.0;
+            for (int g = 0; g < G; ++g) {
+                acc += (spec[w * G + g] * xf) * DELG[g];
+                accs += (dts[w * G + g] * xf) * DELG[g];
+            }
+            SPECOUT[w * NPATH + ip] = acc;
+            dTSURF[w * NPATH + ip] = accs;
+            for (int kpar = 0; kpar < NPAR; ++kpar)
+                for (int j = 0; j < nl; ++j) {
+                    double a = 0.0;
+                    for (int g = 0; g < G; ++g)
+                        a += (dspec[((w * G + g) * NPAR + kpar) * nl + j] * xf) * DELG[g];
+                    if (a != a) a = 0.0; /* nan_to_num :4507 */
+                    dSPECOUT[((w * NPAR + kpar) * LIMAX + j) * NPATH + ip] = a;
+                }
+        }
+        free(tpath); free(dtpath); free(emtemp); free(empress); free(spec); free(dspec); free(dts);
+    }
+    free(zeros); free(dtautot); free(tau);
+}

@@ -67,6 +67,32 @@ def main():
         return res
 
     fm_mod.ForwardModel_0.CIRSrad = wrapper
+    # continuum gradient terms are locals of calculate_layer_opacity (:3938-3981): capture what the
+    # three host routines return on the return_grad=True pass and assemble dTAUCON exactly as :3941-3981
+    cont = {}
+    o_cia = fm_mod.ForwardModel_0.calculate_vertical_cia_opacity
+    o_ray = fm_mod.ForwardModel_0.calc_tau_rayleigh
+    o_dust = fm_mod.ForwardModel_0.calc_tau_dust
+
+    def w_cia(self, return_grad=False):
+        r = o_cia(self, return_grad)
+        if return_grad:
+            cont["cia"] = r
+        return r
+
+    def w_ray(self, *a, **k):
+        r = o_ray(self, *a, **k)
+        cont["ray"] = r
+        return r
+
+    def w_dust(self, *a, **k):
+        r = o_dust(self, *a, **k)
+        cont["dust"] = r
+        return r
+
+    fm_mod.ForwardModel_0.calculate_vertical_cia_opacity = w_cia
+    fm_mod.ForwardModel_0.calc_tau_rayleigh = w_ray
+    fm_mod.ForwardModel_0.calc_tau_dust = w_dust
     cwd = os.getcwd()
     os.chdir(work)
     try:
@@ -99,11 +125,28 @@ def main():
             SPECONVg, dSPECONV = FM.nemesisfmg()
             print("nemesisfmg", time.time() - t, "s")
             selfg, (SPg, dSP, dTS) = captured["g"]
+            Sg, Lg, Ag, Scg = selfg.SpectroscopyX, selfg.LayerX, selfg.AtmosphereX, selfg.ScatterX
+            NPAR = Ag.NVMR + 2 + Scg.NDUST
+            dTAUCON = np.zeros((Sg.NWAVE, NPAR, Lg.NLAY))
+            TAUCIA_g, dTAUCIA = cont["cia"]
+            if dTAUCIA is not None:                                                  # :3940-3942
+                dTAUCON[:, 0:Ag.NVMR, :] += np.transpose(np.transpose(dTAUCIA[:, :, 0:Ag.NVMR], axes=(2, 0, 1)) / (Lg.TOTAM.T), axes=(1, 0, 2))
+                dTAUCON[:, Ag.NVMR, :] += dTAUCIA[:, :, Ag.NVMR]
+            TAURAY_g, dTAURAY = cont["ray"]
+            if dTAURAY is not None:                                                  # :3955-3957
+                for i in range(Ag.NVMR):
+                    dTAUCON[:, i, :] += dTAURAY[:, :]
+            TAUDUST1, TAUCLSCAT, dTAUDUST1, dTAUCLSCAT = cont["dust"]
+            for i in range(Scg.NDUST):                                               # :3978-3980
+                dTAUCON[:, Ag.NVMR + 1 + i, :] += dTAUDUST1[:, :, i]
             out.update(dict(SPECOUTg=SPg[sel], dSPECOUT=dSP[sel], dTSURF=dTS[sel], SPECONVg=SPECONVg,
-                            dSPECONV=dSPECONV))
+                            dSPECONV=dSPECONV, dTAUCON=dTAUCON[sel]))
     finally:
         os.chdir(cwd)
         fm_mod.ForwardModel_0.CIRSrad = orig
+        fm_mod.ForwardModel_0.calculate_vertical_cia_opacity = o_cia
+        fm_mod.ForwardModel_0.calc_tau_rayleigh = o_ray
+        fm_mod.ForwardModel_0.calc_tau_dust = o_dust
         shutil.rmtree(work, ignore_errors=True)
     fn = os.path.join(OUT, "c1_cirsrad_grad.npz" if want_grad else "c1_cirsrad.npz")
     np.savez_compressed(fn, **out)

@@ -158,3 +158,26 @@ def cirsrad_ck_thermal(ISPACE, K, TPRESS, TTEMP, WAVE, DELG, lay_press_pa, lay_t
         _p(_c(SOLFLUX)), _p(_c(REFLECTANCE)), _p(_c(SOL_ANG)), _p(_c(EMISS_ANG)), _p(_c(xfac)),
         _p(out), _p(tg))
     return (out, tg) if return_taugas else out
+
+
+def cirsradg_ck_thermal(ISPACE, K, TPRESS, TTEMP, WAVE, DELG, lay_press_pa, lay_temp, amount, TAUCONT, dTAUCON,
+                        NVMR, NPAR, igas_map, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None, xfac=None):
+    """CIRSrad(return_grad=True) (ILBL=K_TABLES, THERMAL_EMISSION): SPECOUT (W,P), dSPECOUT (W,NPAR,LIMAX,P),
+    dTSURF (W,P).  ForwardModel_0.py:4376-4511 with :3853-3872, :3993, :4012, :4233-4247, :4504-4508."""
+    set_f32_semantics(_is_f32(TPRESS) or _is_f32(TTEMP), _is_f32(DELG))
+    K = _c(K); W, G, NP, NT, S = K.shape
+    lay_press_pa = _c(lay_press_pa); L = lay_press_pa.shape[0]
+    patm = _c(lay_press_pa / 101325.0)
+    amount = _c(amount); assert amount.shape == (S, L)
+    LAYINC = _c(LAYINC, np.int32); SCALE = _c(SCALE); EMTEMP = _c(EMTEMP); NLAYIN = _c(NLAYIN, np.int32)
+    LIMAX, P = LAYINC.shape
+    dTAUCON = _c(dTAUCON)
+    if dTAUCON is not None:
+        assert dTAUCON.shape == (W, NPAR, L)
+    spec = np.zeros((W, P)); dspec = np.zeros((W, NPAR, LIMAX, P)); dts = np.zeros((W, P))
+    lib().orc_cirsradg_ck_thermal(
+        int(ISPACE), W, G, NP, NT, S, _p(K), _p(_c(TPRESS)), _p(_c(TTEMP)), _p(_c(WAVE)), _p(_c(DELG)), L, _p(patm),
+        _p(_c(lay_temp)), _p(lay_press_pa), _p(amount), _p(_c(TAUCONT)), _p(dTAUCON), int(NVMR), int(NPAR),
+        _p(_c(igas_map, np.int32)), P, LIMAX, _p(NLAYIN), _p(LAYINC), _p(SCALE), _p(EMTEMP), C.c_double(TSURF),
+        _p(_c(EMISSIVITY)), _p(_c(xfac)), _p(spec), _p(dspec), _p(dts))
+    return spec, dspec, dts

@@ -21,6 +21,8 @@ def load_c1(golden_dir, name="c1_cirsrad.npz"):
                            ILBL=int(z["ILBL"]))
     layer = SimpleNamespace(NLAY=L, PRESS=z["LAY_PRESS"], TEMP=z["LAY_TEMP"], AMOUNT=z["LAY_AMOUNT"],
                             TOTAM=z["LAY_TOTAM"], TAUCIA=z["TAUCIA"], TAURAY=z["TAURAY"], TAUDUST=z["TAUDUST"])
+    if "dTAUCON" in z.files:
+        layer.dTAUCON = z["dTAUCON"]
     path = SimpleNamespace(NPATH=z["LAYINC"].shape[1], NLAYIN=z["NLAYIN"], LAYINC=z["LAYINC"], SCALE=z["SCALE"],
                            EMTEMP=z["EMTEMP"], IMOD=z["IMOD"], SOL_ANG=z["SOL_ANG"], EMISS_ANG=z["EMISS_ANG"])
     igas = {(int(i), int(s)): int(g) for i, s, g in zip(z["ID"], z["ISO"], z["IGAS"])}

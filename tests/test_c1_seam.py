@@ -43,3 +43,46 @@ def test_gpu_cirsrad_mixin_matches_reference(golden_dir):
     np.testing.assert_allclose(fm.LayerX.TAUTOT, z["TAUTOT"], rtol=1e-10)
     with pytest.raises(NotImplementedError):
         fm.CIRSrad(return_grad=True)
+
+
+def _grad_close(got, ref, tol):
+    """|got-ref| <= tol * max|ref| per (parameter) slab: gradients span many decades across layers."""
+    scale = np.abs(ref).max(axis=(0, 2, 3), keepdims=True) + 1e-300
+    return float(np.max(np.abs(got - ref) / scale)) <= tol
+
+
+def test_oracle_reproduces_reference_cirsradg(oracle, golden_dir):
+    z, X = load_c1(golden_dir, "c1_cirsrad_grad.npz")
+    S, L, P, A = X["SpectroscopyX"], X["LayerX"], X["PathX"], X["AtmosphereX"]
+    amount, cont = _oracle_inputs(z, X)
+    NPAR = A.NVMR + 2 + X["ScatterX"].NDUST
+    spec, dspec, dts = oracle.cirsradg_ck_thermal(X["MeasurementX"].ISPACE, S.K, S.PRESS, S.TEMP, S.WAVE, S.DELG,
+                                                  L.PRESS, L.TEMP, amount, cont, z["dTAUCON"], A.NVMR, NPAR, z["IGAS"],
+                                                  P.NLAYIN, P.LAYINC, P.SCALE, P.EMTEMP, X["SurfaceX"].TSURF)
+    np.testing.assert_allclose(spec, z["SPECOUTg"], rtol=1e-12)
+    np.testing.assert_allclose(dts, z["dTSURF"], rtol=1e-12, atol=0)
+    assert dspec.shape == z["dSPECOUT"].shape
+    assert _grad_close(dspec, z["dSPECOUT"], 1e-11)
+
+
+@pytest.mark.gpu
+def test_gpu_cirsradg_mixin_matches_reference(golden_dir):
+    from archnemesis_dist_amd.forward_model import CIRSradGPU
+
+    class FM(CIRSradGPU):
+        pass
+
+    z, X = load_c1(golden_dir, "c1_cirsrad_grad.npz")
+    fm = FM()
+    for k, v in X.items():
+        setattr(fm, k, v)
+    spec, dspec, dts = fm.CIRSrad(return_grad=True)
+    np.testing.assert_allclose(spec, z["SPECOUTg"], rtol=1e-10)
+    np.testing.assert_allclose(dts, z["dTSURF"], rtol=1e-10, atol=0)
+    assert dspec.shape == z["dSPECOUT"].shape
+    assert _grad_close(dspec, z["dSPECOUT"], 1e-4)          # north_star Jacobian contract
+    assert _grad_close(dspec, z["dSPECOUT"], 1e-9)          # what the kernels hold
+    # element-wise relative check on the entries that matter (>= 1e-8 of the slab maximum)
+    ref = z["dSPECOUT"]
+    big = np.abs(ref) >= 1e-8 * np.abs(ref).max(axis=(0, 2, 3), keepdims=True)
+    assert np.max(np.abs(dspec[big] - ref[big]) / np.abs(ref[big])) < 1e-6

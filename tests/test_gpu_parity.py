@@ -147,3 +147,52 @@ def test_c2_full_size_properties(eng):
     s = eng.calc_thermal_emission_spectrum(0, WAVE, np.zeros((W, G, Li)), None, np.full(Li, 100.0), PR, T0, em, z,
                                            z, 180.0, 0.0)
     np.testing.assert_allclose(s, np.repeat((em * bb)[:, None], G, 1), rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", CK_CASES)
+def test_k_overlapg_golden(eng, golden_dir, name):
+    z = _load(golden_dir, name)
+    taug, dk = eng.k_overlapg(z["DELG"], z["kg"], z["dkdT"], z["amount"])
+    np.testing.assert_allclose(taug, z["taug"], rtol=1e-11, atol=0)
+    # tie-order caveat of rankg gradients (see tests/test_oracle_golden.py): 1e-5 of the per-cell
+    # column scale where exact ties exist, 1e-10 otherwise; the Jacobian contract is 1e-4
+    scale = np.abs(z["dk"]).max(axis=1, keepdims=True) + 1e-300
+    tol = 1e-10 if name.endswith("nozero") else 1e-5
+    assert np.max(np.abs(dk - z["dk"]) / scale) < tol
+
+
+@pytest.mark.parametrize("W,G,S,L,f32", [(96, 20, 8, 20, True), (70, 10, 3, 9, False), (40, 16, 12, 6, False)])
+def test_cirsradg_vs_oracle(eng, oracle, W, G, S, L, f32):
+    """Fused CIRSrad(return_grad=True) for a 2-model batch vs the CPU oracle (literal O(Li^2) recursion)."""
+    from archnemesis_dist_amd import synthetic as syn
+    NP, NT = 8, 6
+    _, delg = syn.gauss_legendre_01(G, as_float32=f32)
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S, seed=9 + W)
+    WAVE = 150.0 + 0.7 * np.arange(W)
+    n = 2
+    atm = syn.synth_atmosphere(L, S, seed=4, n_models=n, perturb=0.05)
+    atm["amount"][0, 1, 3] = 0.0
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L, emiss_ang=25.0)
+    cont = syn.synth_continuum(W, L, n_models=n)
+    NVMR, NDUST = S + 2, 1                      # more atmospheric gases than spectroscopic ones
+    NPAR = NVMR + 2 + NDUST
+    rng = np.random.default_rng(3)
+    igas_map = rng.permutation(NVMR)[:S].astype(np.int32)
+    dcont = cont[:, :, None, :] * rng.uniform(0.0, 1e-22, size=(n, W, NPAR, L))
+    EMTEMP = atm["lay_temp"][:, LAYINC[:, 0]][:, :, None]
+    TSURF = np.array([-1.0, 280.0])
+    EMIS = np.linspace(0.8, 1.0, W)
+    xfac = np.linspace(1.0, 1.5, W)
+    eng.upload_ktable(K, PRESS, TEMP, WAVE, delg)
+    spec, dspec, dts = eng.cirsradg_ck_thermal(0, atm["lay_press_pa"], atm["lay_temp"], atm["amount"], cont, dcont,
+                                               NVMR, NPAR, igas_map, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF,
+                                               EMISSIVITY=EMIS, xfac=xfac)
+    for m in range(n):
+        rs, rd, rt = oracle.cirsradg_ck_thermal(0, K, PRESS, TEMP, WAVE, delg, atm["lay_press_pa"][m],
+                                                atm["lay_temp"][m], atm["amount"][m], cont[m], dcont[m], NVMR, NPAR,
+                                                igas_map, NLAYIN, LAYINC, SCALE, EMTEMP[m], TSURF[m], EMISSIVITY=EMIS,
+                                                xfac=xfac)
+        np.testing.assert_allclose(spec[m], rs, rtol=1e-10)
+        np.testing.assert_allclose(dts[m], rt, rtol=1e-10, atol=0)
+        scale = np.abs(rd).max(axis=(0, 2, 3), keepdims=True) + 1e-300
+        assert np.max(np.abs(dspec[m] - rd) / scale) < 1e-9, m
