@@ -41,8 +41,6 @@ def test_gpu_cirsrad_mixin_matches_reference(golden_dir):
     np.testing.assert_allclose(out, z["SPECOUT"], rtol=1e-10)         # what the kernels actually hold
     np.testing.assert_allclose(fm.LayerX.TAUGAS, z["TAUGAS"], rtol=1e-10)
     np.testing.assert_allclose(fm.LayerX.TAUTOT, z["TAUTOT"], rtol=1e-10)
-    with pytest.raises(NotImplementedError):
-        fm.CIRSrad(return_grad=True)
 
 
 def _grad_close(got, ref, tol):
@@ -84,5 +82,5 @@ def test_gpu_cirsradg_mixin_matches_reference(golden_dir):
     assert _grad_close(dspec, z["dSPECOUT"], 1e-9)          # what the kernels hold
     # element-wise relative check on the entries that matter (>= 1e-8 of the slab maximum)
     ref = z["dSPECOUT"]
-    big = np.abs(ref) >= 1e-8 * np.abs(ref).max(axis=(0, 2, 3), keepdims=True)
+    big = (np.abs(ref) >= 1e-8 * np.abs(ref).max(axis=(0, 2, 3), keepdims=True)) & (np.abs(ref) > 0)
     assert np.max(np.abs(dspec[big] - ref[big]) / np.abs(ref[big])) < 1e-6
