@@ -1,6 +1,7 @@
 // ansfm_api.hip -- C-ABI of libansfm.so (include/ansfm.h): context, HBM buffers, launches.
 // gfx950 only.  No CPU fallback: every entry point needs a live HIP device.
 #include "ansfm_kernels.hip.h"
+#include "ansfm_ms_kernels.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -847,6 +848,80 @@ int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *d
     HIPCHK(hipMemcpyAsync(tau, ctx->tmp_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(dk, ctx->tmp_out2.p, ndk * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return check_unsorted(ctx);
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* multiple scattering                                                                         */
+/* ------------------------------------------------------------------------------------------ */
+int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const double *phasarr, const double *radg,
+                            int ngeom, const double *sol_angs, const double *emiss_angs, const double *solar,
+                            const double *aphis, int lowbc, const double *brdf_matrix, int nmu, const double *mu1,
+                            const double *wt1, int nf, const double *bnu, int ng, int nlay, const double *taus,
+                            const double *tauray, const double *omegas_s, int nphi, int iray, int imie,
+                            const double *lfrac, double *rad)
+{
+    CHECK_CTX(ctx);
+    if (ncont < 0 || nwave <= 0 || ngeom <= 0 || nmu < 2 || nf < 0 || ng <= 0 || nlay <= 0 || nphi <= 0 || !radg ||
+        !sol_angs || !emiss_angs || !solar || !aphis || !brdf_matrix || !mu1 || !wt1 || !bnu || !taus || !tauray ||
+        !omegas_s || !rad || (ncont > 0 && (!phasarr || !lfrac || nth < 3)))
+        FAIL(ANSFM_ERR_INVALID, "scloud11wave_core: bad argument");
+    if (nmu > 20 || ngeom > kMsMaxPath || ncont > 60)
+        FAIL(ANSFM_ERR_UNSUPPORTED, "scloud11wave_core: nmu <= 20, npath <= 16 per call supported");
+    int nless = 0, nmore = 0;
+    for (int i = 0; i < ngeom; ++i) { if (emiss_angs[i] < 90) ++nless; if (emiss_angs[i] > 90) ++nmore; }
+    if (nless != ngeom && nmore != ngeom)
+        FAIL(ANSFM_ERR_INVALID, "Emission angles are a mix of values above and below 90 degrees.");   // :776
+    if (nmore == ngeom) FAIL(ANSFM_ERR_UNSUPPORTED, "scloud11wave_core: look-up geometry (emission angle > 90) not built");
+    HIPCHK(hipSetDevice(ctx->device));
+    MsParams p;
+    memset(&p, 0, sizeof p);
+    const size_t D = sizeof(double);
+    const void *d[10];
+    int i = 0, rc;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(phasarr, (size_t)ncont * nwave * 2 * nth * D);           // 0
+    UP(radg, (size_t)nwave * nmu * D);                          // 1
+    UP(solar, (size_t)nwave * D);                               // 2
+    UP(brdf_matrix, (size_t)nwave * nmu * nmu * (nf + 1) * D);  // 3
+    UP(bnu, (size_t)nwave * nlay * D);                          // 4
+    UP(taus, (size_t)nwave * ng * nlay * D);                    // 5
+    UP(tauray, (size_t)nwave * nlay * D);                       // 6
+    UP(omegas_s, (size_t)nwave * ng * nlay * D);                // 7
+    UP(lfrac, (size_t)nwave * ncont * nlay * D);                // 8
+#undef UP
+    p.phasarr = (const double *)d[0]; p.radg = (const double *)d[1]; p.solar = (const double *)d[2];
+    p.brdf = (const double *)d[3]; p.bnu = (const double *)d[4]; p.taus = (const double *)d[5];
+    p.tauray = (const double *)d[6]; p.omegas = (const double *)d[7]; p.lfrac = (const double *)d[8];
+    p.ncont = ncont; p.ncomp = ncont + 1; p.nwave = nwave; p.nth = nth; p.ngeom = ngeom; p.lowbc = lowbc; p.nmu = nmu;
+    p.nf = nf; p.ng = ng; p.nlay = nlay; p.nphi = nphi; p.iray = iray; p.imie = imie;
+    double xs = 0.0;
+    for (int k = 0; k < nmu; ++k) { xs += mu1[k] * wt1[k]; p.mu[k] = mu1[nmu - 1 - k]; p.wtmu[k] = wt1[nmu - 1 - k]; }
+    p.xfac = 0.5 / xs;                                          // :720-722
+    for (int k = 0; k < ngeom; ++k) { p.sol_ang[k] = sol_angs[k]; p.emiss_ang[k] = emiss_angs[k]; p.aphi[k] = aphis[k]; }
+    const size_t nn = (size_t)nmu * nmu;
+    const size_t nph = (size_t)nwave * (nf + 1) * p.ncomp * nn;
+    HIPCHK(ctx->misc.reserve(2 * nph * D));
+    HIPCHK(ctx->tmp_in2.reserve((size_t)nwave * ng * (nf + 1) * ngeom * D));
+    HIPCHK(ctx->tmp_out.reserve((size_t)ngeom * ng * nwave * D));
+    HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 2 * nph * D, ctx->stream));
+    p.ppl = ctx->misc.as<double>(); p.pmi = p.ppl + nph;
+    p.drad = ctx->tmp_in2.as<double>();
+    p.rad = ctx->tmp_out.as<double>();
+    const int ncomp_run = ncont + (iray > 0 ? 1 : 0);
+    if (ncomp_run > 0) {
+        hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, (unsigned)ncomp_run), dim3(256), 0, ctx->stream, p);
+        HIPCHK(hipGetLastError());
+    }
+    const size_t lds = (12 * nn + 6 * kMsMaxMu + 2) * D;
+    hipLaunchKernelGGL(k_ms_chain, dim3((unsigned)((size_t)nwave * ng * (nf + 1))), dim3(64), lds, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    const size_t tot = (size_t)nwave * ng * ngeom;
+    hipLaunchKernelGGL(k_ms_fourier, dim3(nblk(tot, 128)), dim3(128), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(rad, ctx->tmp_out.p, (size_t)ngeom * ng * nwave * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
 }
 
 }  // extern "C"

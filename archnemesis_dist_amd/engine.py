@@ -207,6 +207,22 @@ class AnsfmEngine:
             _ptr(SPECOUT))
         self._check(rc, "cirsrad_ck_thermal_dev")
 
+    def scloud11wave_core(self, phasarr, radg, sol_angs, emiss_angs, solar, aphis, lowbc, brdf_matrix, mu1, wt1, nf,
+                          vwaves, bnu, taus, tauray, omegas_s, nphi, iray, imie, lfrac):
+        """Multiple_Scattering_Core.scloud11wave_core (same arguments) -> rad (NPATH, NG, NWAVE)."""
+        phasarr = _np(phasarr); taus = _np(taus)
+        ncont, nwave, _, nth = phasarr.shape
+        nmu = len(mu1); ngeom = len(emiss_angs)
+        _, ng, nlay = taus.shape
+        rad = np.empty((ngeom, ng, nwave))
+        rc = self._lib.ansfm_scloud11wave_core(
+            self._ctx, ncont, nwave, nth, _ptr(phasarr), _ptr(_np(radg)), ngeom, _ptr(_np(sol_angs)),
+            _ptr(_np(emiss_angs)), _ptr(_np(solar)), _ptr(_np(aphis)), int(lowbc), _ptr(_np(brdf_matrix)), nmu,
+            _ptr(_np(mu1)), _ptr(_np(wt1)), int(nf), _ptr(_np(bnu)), ng, nlay, _ptr(taus), _ptr(_np(tauray)),
+            _ptr(_np(omegas_s)), int(nphi), int(iray), int(imie), _ptr(_np(lfrac)), _ptr(rad))
+        self._check(rc, "scloud11wave_core")
+        return rad
+
     def get_taugas(self, L, model=0):
         W, G = self.dims[0], self.dims[1]
         out = np.empty((W, G, L))

@@ -162,6 +162,24 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
                                   const double *EMISSIVITY, const double *xfac, double *SPECOUT,
                                   double *dSPECOUT, double *dTSURF);
 
+/* ---- multiple scattering ---------------------------------------------------------------------
+ * Multiple_Scattering_Core.scloud11wave_core (Multiple_Scattering_Core.py:651-960): plane-parallel
+ * matrix-operator doubling/adding with azimuth Fourier expansion.  Arguments, layouts and meaning
+ * are the reference's (host pointers):
+ *   phasarr[ncont][nwave][2][nth] (HG: f,g1,g2 in the first 3 slots of [..][0][:] when imie == 0),
+ *   radg[nwave][nmu], sol_angs/emiss_angs/aphis[ngeom] (deg), solar[nwave], lowbc (0 thermal, >0 surface),
+ *   brdf_matrix[nwave][nmu][nmu][nf+1], mu1/wt1[nmu], bnu[nwave][nlay], taus[nwave][ng][nlay],
+ *   tauray[nwave][nlay], omegas_s[nwave][ng][nlay], lfrac[nwave][ncont][nlay]  ->  rad[ngeom][ng][nwave].
+ * Mixed emission angles above/below 90 deg -> ANSFM_ERR_INVALID (the reference raises ValueError :776);
+ * look-up geometry (all > 90) -> ANSFM_ERR_UNSUPPORTED for now. */
+int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const double *phasarr,
+                            const double *radg, int ngeom, const double *sol_angs,
+                            const double *emiss_angs, const double *solar, const double *aphis,
+                            int lowbc, const double *brdf_matrix, int nmu, const double *mu1,
+                            const double *wt1, int nf, const double *bnu, int ng, int nlay,
+                            const double *taus, const double *tauray, const double *omegas_s,
+                            int nphi, int iray, int imie, const double *lfrac, double *rad);
+
 /* Vertical gas opacity of the last cirsrad call's first model, TAUGAS[W][G][L]
  * (what CIRSrad leaves in LayerX.TAUGAS, ForwardModel_0.py:3925) -- host pointer out. */
 int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS);

@@ -17,8 +17,8 @@ _d = np.float64
 
 def build(force=False):
     so = os.path.join(_HERE, "libansfm_oracle.so")
-    src = os.path.join(_HERE, "ansfm_oracle.c")
-    if force or (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("ansfm_oracle.c", "ansfm_oracle_ms.c", "Makefile")]
+    if force or (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -181,3 +181,22 @@ def cirsradg_ck_thermal(ISPACE, K, TPRESS, TTEMP, WAVE, DELG, lay_press_pa, lay_
         _p(_c(igas_map, np.int32)), P, LIMAX, _p(NLAYIN), _p(LAYINC), _p(SCALE), _p(EMTEMP), C.c_double(TSURF),
         _p(_c(EMISSIVITY)), _p(_c(xfac)), _p(spec), _p(dspec), _p(dts))
     return spec, dspec, dts
+
+
+def scloud11wave_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, lowbc, brdf_matrix, mu1, wt1, nf, vwaves, bnu,
+                      taus, tauray, omegas_s, nphi, iray, imie, lfrac):
+    """Multiple_Scattering_Core.scloud11wave_core (:651) -> rad (NPATH, NG, NWAVE)."""
+    phasarr = _c(phasarr); radg = _c(radg); taus = _c(taus)
+    ncont, nwave, _, nth = phasarr.shape
+    nmu = len(mu1); ngeom = len(emiss_angs)
+    _, ng, nlay = taus.shape
+    rad = np.zeros((ngeom, ng, nwave))
+    rc = lib().orc_scloud11wave_core(
+        ncont, nwave, nth, _p(phasarr), _p(radg), ngeom, _p(_c(sol_angs)), _p(_c(emiss_angs)), _p(_c(solar)),
+        _p(_c(aphis)), int(lowbc), _p(_c(brdf_matrix)), nmu, _p(_c(mu1)), _p(_c(wt1)), int(nf), _p(_c(bnu)), ng, nlay,
+        _p(taus), _p(_c(tauray)), _p(_c(omegas_s)), int(nphi), int(iray), int(imie), _p(_c(lfrac)), _p(rad))
+    if rc == 1:
+        raise ValueError("Emission angles are a mix of values above and below 90 degrees (or NMU too large).")
+    if rc == 5:
+        raise NotImplementedError("look-up geometry (emission angle > 90) not restated")
+    return rad

@@ -196,3 +196,38 @@ def test_cirsradg_vs_oracle(eng, oracle, W, G, S, L, f32):
         np.testing.assert_allclose(dts[m], rt, rtol=1e-10, atol=0)
         scale = np.abs(rd).max(axis=(0, 2, 3), keepdims=True) + 1e-300
         assert np.max(np.abs(dspec[m] - rd) / scale) < 1e-9, m
+
+
+@pytest.mark.parametrize("name", ["ms_nmu5_hg_ray", "ms_nmu5_tab_lambert", "ms_nmu16_tab_ray"])
+def test_scloud11wave_core_golden(eng, golden_dir, name):
+    """Doubling/adding core vs the reference's scloud11wave_core (golden) -- contract 1e-6."""
+    from test_ms_oracle import ms_args
+    z = _load(golden_dir, name)
+    rad = eng.scloud11wave_core(*ms_args(z))
+    assert rad.shape == z["rad"].shape
+    np.testing.assert_allclose(rad, z["rad"], rtol=1e-8)
+
+
+def test_scloud11wave_core_vs_oracle_random(eng, oracle, golden_dir):
+    """A wider random stack (more waves/g/layers than the golden) against the CPU oracle."""
+    from test_ms_oracle import ms_args
+    z = dict(_load(golden_dir, "ms_nmu5_hg_ray"))
+    rng = np.random.default_rng(5)
+    W, G, L = 40, 3, 12
+    nmu = z["mu1"].size; ncont = z["phasarr"].shape[0]; nth = z["phasarr"].shape[3]
+    z["vwaves"] = 400.0 + 10.0 * np.arange(W)
+    ph = np.zeros((ncont, W, 2, nth)); ph[:, :, 1, :] = z["phasarr"][0, 0, 1, :]
+    ph[:, :, 0, 0] = rng.uniform(0.5, 0.95, (ncont, W)); ph[:, :, 0, 1] = rng.uniform(0.2, 0.85, (ncont, W))
+    ph[:, :, 0, 2] = rng.uniform(-0.6, -0.05, (ncont, W))
+    z["phasarr"] = ph
+    taus = 10.0 ** rng.uniform(-5, 1.3, size=(W, G, L))
+    tauray = 10.0 ** rng.uniform(-6, -2, size=(W, L)); tauscat = 10.0 ** rng.uniform(-5, 0, size=(W, L))
+    taus = np.maximum(taus, (tauscat + tauray)[:, None, :] * 1.01)
+    z["taus"] = taus; z["tauray"] = tauray
+    z["omegas_s"] = np.broadcast_to((tauray + tauscat)[:, None, :], taus.shape) / taus
+    fr = rng.uniform(0.1, 1.0, size=(W, ncont, L)); z["lfrac"] = fr / fr.sum(axis=1, keepdims=True)
+    z["bnu"] = 10.0 ** rng.uniform(-8, -6, size=(W, L)); z["radg"] = 10.0 ** rng.uniform(-8, -6, size=(W, nmu))
+    z["solar"] = 10.0 ** rng.uniform(-9, -8, W); z["brdf_matrix"] = np.zeros((W, nmu, nmu, int(z["nf"]) + 1))
+    rad = eng.scloud11wave_core(*ms_args(z))
+    ref = oracle.scloud11wave_core(*ms_args(z))
+    np.testing.assert_allclose(rad, ref, rtol=1e-8)
