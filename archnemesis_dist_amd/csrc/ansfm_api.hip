@@ -901,16 +901,32 @@ int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const
     for (int k = 0; k < ngeom; ++k) { p.sol_ang[k] = sol_angs[k]; p.emiss_ang[k] = emiss_angs[k]; p.aphi[k] = aphis[k]; }
     const size_t nn = (size_t)nmu * nmu;
     const size_t nph = (size_t)nwave * (nf + 1) * p.ncomp * nn;
-    HIPCHK(ctx->misc.reserve(2 * nph * D));
+    const size_t nfc = (size_t)ng * nwave * p.ncomp * nn;
+    HIPCHK(ctx->misc.reserve((2 * nph + nfc) * D));
     HIPCHK(ctx->tmp_in2.reserve((size_t)nwave * ng * (nf + 1) * ngeom * D));
     HIPCHK(ctx->tmp_out.reserve((size_t)ngeom * ng * nwave * D));
-    HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 2 * nph * D, ctx->stream));
-    p.ppl = ctx->misc.as<double>(); p.pmi = p.ppl + nph;
+    HIPCHK(hipMemsetAsync(ctx->misc.p, 0, (2 * nph + nfc) * D, ctx->stream));
+    p.ppl = ctx->misc.as<double>(); p.pmi = p.ppl + nph; p.fc = p.pmi + nph;
     p.drad = ctx->tmp_in2.as<double>();
     p.rad = ctx->tmp_out.as<double>();
     const int ncomp_run = ncont + (iray > 0 ? 1 : 0);
     if (ncomp_run > 0) {
-        hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, (unsigned)ncomp_run), dim3(256), 0, ctx->stream, p);
+        // Rayleigh lives in slot ncont even when there are no aerosols
+        if (ncont > 0)
+            hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, (unsigned)ncont), dim3(256), 0, ctx->stream, p);
+        if (iray > 0) {
+            MsParams pr = p;
+            pr.phase_comp0 = ncont;
+            hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, 1), dim3(256), 0, ctx->stream, pr);
+        }
+        HIPCHK(hipGetLastError());
+        p.hansen_comp0 = 0;
+        if (ncont > 0) hipLaunchKernelGGL(k_ms_hansen_seq, dim3((unsigned)ncont), dim3(64), 0, ctx->stream, p);
+        if (iray > 0) {
+            MsParams pr = p;
+            pr.hansen_comp0 = ncont;
+            hipLaunchKernelGGL(k_ms_hansen_seq, dim3(1), dim3(64), 0, ctx->stream, pr);
+        }
         HIPCHK(hipGetLastError());
     }
     const size_t lds = (12 * nn + 6 * kMsMaxMu + 2) * D;

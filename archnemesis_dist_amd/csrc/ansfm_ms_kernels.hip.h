@@ -6,8 +6,10 @@
 //
 // Decomposition (every (wavenumber, g, Fourier order) chain is independent):
 //   k_ms_phase   one block per (wave, scatterer): azimuth-integrated phase matrices P++ / P+- for
-//                ic = 0..nf with Hansen renormalisation.  They do not depend on g; the reference
-//                recomputes them inside its g loop (:780-815) -- hoisted here.
+//                ic = 0..nf.  They do not depend on g; the reference recomputes them inside its g
+//                loop (:780-815) -- hoisted here.
+//   k_ms_hansen_seq  Hansen renormalisation factors, sequential in the reference's (g, wave) order
+//                (its fc array is carried from one iteration to the next, see the kernel).
 //   k_ms_chain   one wavefront per (wave, g, ic): per layer doubling (double1/add) and adding
 //                (addp) of the (R,T,J) operators, nmu x nmu float64 matrices in LDS; then the
 //                2x2 (mu0,mu) samples of R u0+ + T u- + J for every path -> drad[wave][g][ic][path].
@@ -36,13 +38,15 @@ struct MsParams {
     const double *omegas;    // [nwave][ng][nlay]
     const double *lfrac;     // [nwave][ncont][nlay]
     // workspaces / outputs
-    double *ppl, *pmi;       // [nwave][nf+1][ncomp][nmu*nmu]
+    double *ppl, *pmi;       // [nwave][nf+1][ncomp][nmu*nmu]   raw azimuth integrals
+    double *fc;              // [ng][nwave][ncomp][nmu*nmu]     Hansen factors in the reference's loop order
     double *drad;            // [nwave][ng][nf+1][ngeom]
     double *rad;             // [ngeom][ng][nwave]
     int ncont, ncomp, nwave, nth, ngeom, lowbc, nmu, nf, ng, nlay, nphi, iray, imie;
     double mu[kMsMaxMu], wtmu[kMsMaxMu];          // already reversed (:725-726)
     double sol_ang[kMsMaxPath], emiss_ang[kMsMaxPath], aphi[kMsMaxPath];
     double xfac;
+    int hansen_comp0, phase_comp0;
 };
 
 __device__ __forceinline__ double ms_interp(double x, const double *xp, const double *fp, int n)
@@ -56,61 +60,76 @@ __device__ __forceinline__ double ms_interp(double x, const double *xp, const do
 }
 
 // ---- phase matrices -----------------------------------------------------------------------------
+// raw azimuth integrals (phasint2 :141-197), one block per (wave, scatterer), all ic
 __global__ __launch_bounds__(256) void k_ms_phase(MsParams p)
 {
-    __shared__ double ppl[kMsMaxMu * kMsMaxMu], pmi[kMsMaxMu * kMsMaxMu], fc[kMsMaxMu * kMsMaxMu];
-    __shared__ double rsum[kMsMaxMu], tsum[kMsMaxMu];
-    __shared__ double test_s;
-    const int widx = blockIdx.x, comp = blockIdx.y;  // comp == ncont -> Rayleigh
+    const int widx = blockIdx.x, comp = blockIdx.y + p.phase_comp0;  // comp == ncont -> Rayleigh
     const int n = p.nmu, nn = n * n, tid = threadIdx.x;
     const double pi = 3.141592653589793;
     const double dphi = 2.0 * pi / p.nphi;
-    // the reference passes the LAST aerosol's (pfunc, xmu) to the Rayleigh call too (unused for iscat 0)
     const int jc = comp < p.ncont ? comp : (p.ncont > 0 ? p.ncont - 1 : 0);
     const double *pfunc = p.phasarr + (((size_t)jc * p.nwave + widx) * 2 + 0) * p.nth;
     const double *xmu = p.phasarr + (((size_t)jc * p.nwave + widx) * 2 + 1) * p.nth;
     const int iscat = (comp == p.ncont) ? 0 : (p.imie == 0 ? 2 : 4);
-    for (int e = tid; e < nn; e += blockDim.x) fc[e] = 1.0;
-    __syncthreads();
-    for (int ic = 0; ic <= p.nf; ++ic) {
-        for (int e = tid; e < nn; e += blockDim.x) {
-            const int i = e / n, j = e % n;
-            const double sthi = sqrt(1.0 - p.mu[i] * p.mu[i]), sthj = sqrt(1.0 - p.mu[j] * p.mu[j]);
-            const double ss = sthi * sthj, mmu = p.mu[i] * p.mu[j];
-            double spl = 0.0, smi = 0.0;
-            for (int k = 0; k <= p.nphi; ++k) {
-                const double phi = k * dphi;
-                const double cphi = cos(phi);
-                const double cpl = ss * cphi + mmu, cmi = ss * cphi - mmu;
-                double pl, pm;
-                if (iscat == 0) {
-                    pl = 0.75 * (1.0 + cpl * cpl) / (4 * pi);
-                    pm = 0.75 * (1.0 + cmi * cmi) / (4 * pi);
-                } else if (iscat == 2) {
-                    const double f1 = pfunc[0], f2 = 1.0 - f1;
-                    const double hg11 = 1.0 - pfunc[1] * pfunc[1], hg12 = 2.0 - hg11;
-                    const double hg21 = 1.0 - pfunc[2] * pfunc[2], hg22 = 2.0 - hg21;
-                    double s1 = sqrt(hg12 - 2.0 * pfunc[1] * cpl), s2 = sqrt(hg22 - 2.0 * pfunc[2] * cpl);
-                    pl = f1 * hg11 / (s1 * s1 * s1) + f2 * hg21 / (s2 * s2 * s2);
-                    s1 = sqrt(hg12 - 2.0 * pfunc[1] * cmi); s2 = sqrt(hg22 - 2.0 * pfunc[2] * cmi);
-                    pm = f1 * hg11 / (s1 * s1 * s1) + f2 * hg21 / (s2 * s2 * s2);
-                    pl /= 4 * pi; pm /= 4 * pi;
-                } else {
-                    pl = ms_interp(cpl, xmu, pfunc, p.nth);
-                    pm = ms_interp(cmi, xmu, pfunc, p.nth);
-                }
-                double wphi = (k == 0 || k == p.nphi) ? 0.5 * dphi : dphi;
-                if (ic == 0) wphi /= (2.0 * pi); else wphi /= pi;
-                const double cic = cos(ic * phi);
-                spl += wphi * (pl * cic);
-                smi += wphi * (pm * cic);
+    for (int work = tid; work < nn * (p.nf + 1); work += blockDim.x) {
+        const int ic = work / nn, e = work % nn;
+        const int i = e / n, j = e % n;
+        const double sthi = sqrt(1.0 - p.mu[i] * p.mu[i]), sthj = sqrt(1.0 - p.mu[j] * p.mu[j]);
+        const double ss = sthi * sthj, mmu = p.mu[i] * p.mu[j];
+        double spl = 0.0, smi = 0.0;
+        for (int k = 0; k <= p.nphi; ++k) {
+            const double phi = k * dphi;
+            const double cphi = cos(phi);
+            const double cpl = ss * cphi + mmu, cmi = ss * cphi - mmu;
+            double pl, pm;
+            if (iscat == 0) {
+                pl = 0.75 * (1.0 + cpl * cpl) / (4 * pi);
+                pm = 0.75 * (1.0 + cmi * cmi) / (4 * pi);
+            } else if (iscat == 2) {
+                const double f1 = pfunc[0], f2 = 1.0 - f1;
+                const double hg11 = 1.0 - pfunc[1] * pfunc[1], hg12 = 2.0 - hg11;
+                const double hg21 = 1.0 - pfunc[2] * pfunc[2], hg22 = 2.0 - hg21;
+                double s1 = sqrt(hg12 - 2.0 * pfunc[1] * cpl), s2 = sqrt(hg22 - 2.0 * pfunc[2] * cpl);
+                pl = f1 * hg11 / (s1 * s1 * s1) + f2 * hg21 / (s2 * s2 * s2);
+                s1 = sqrt(hg12 - 2.0 * pfunc[1] * cmi); s2 = sqrt(hg22 - 2.0 * pfunc[2] * cmi);
+                pm = f1 * hg11 / (s1 * s1 * s1) + f2 * hg21 / (s2 * s2 * s2);
+                pl /= 4 * pi; pm /= 4 * pi;
+            } else {
+                pl = ms_interp(cpl, xmu, pfunc, p.nth);
+                pm = ms_interp(cmi, xmu, pfunc, p.nth);
             }
-            ppl[e] = spl;
-            pmi[e] = smi;
+            double wphi = (k == 0 || k == p.nphi) ? 0.5 * dphi : dphi;
+            if (ic == 0) wphi /= (2.0 * pi); else wphi /= pi;
+            const double cic = cos(ic * phi);
+            spl += wphi * (pl * cic);
+            smi += wphi * (pm * cic);
         }
-        __syncthreads();
-        if (ic == 0) {  // hansen :200-233
-            const double x1 = 2.0 * pi;
+        p.ppl[(((size_t)widx * (p.nf + 1) + ic) * p.ncomp + comp) * nn + e] = spl;
+        p.pmi[(((size_t)widx * (p.nf + 1) + ic) * p.ncomp + comp) * nn + e] = smi;
+    }
+}
+
+// Hansen renormalisation (hansen :200-233).  The reference keeps ONE fc array per scatterer for the whole
+// call and hansen() updates it in place, so the factor found for (g, wave) is the starting point of the
+// next (g, wave) in loop order (:780-815); the normalisation has no unique solution, so the result depends
+// on that history (a 1e-4 effect on the radiance).  Reproduced: one wavefront per scatterer walks the
+// (g outer, wave inner) sequence and stores fc[g][wave][comp][nmu*nmu].
+__global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
+{
+    __shared__ double ppl[kMsMaxMu * kMsMaxMu], pmi[kMsMaxMu * kMsMaxMu], fc[kMsMaxMu * kMsMaxMu];
+    __shared__ double rsum[kMsMaxMu], tsum[kMsMaxMu];
+    __shared__ double test_s;
+    const int comp = blockIdx.x + p.hansen_comp0;
+    const int n = p.nmu, nn = n * n, tid = threadIdx.x;
+    const double x1 = 2.0 * 3.141592653589793;
+    for (int e = tid; e < nn; e += 64) fc[e] = 1.0;
+    __syncthreads();
+    for (int ig = 0; ig < p.ng; ++ig)
+        for (int widx = 0; widx < p.nwave; ++widx) {
+            const double *gppl = p.ppl + (((size_t)widx * (p.nf + 1) + 0) * p.ncomp + comp) * nn;
+            const double *gpmi = p.pmi + (((size_t)widx * (p.nf + 1) + 0) * p.ncomp + comp) * nn;
+            for (int e = tid; e < nn; e += 64) { ppl[e] = gppl[e]; pmi[e] = gpmi[e]; }
+            __syncthreads();
             if (tid < n) {
                 double s = 0.0;
                 for (int i = 0; i < n; ++i) s += pmi[i * n + tid] * p.wtmu[i];
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(256) void k_ms_phase(MsParams p)
                 }
                 __syncthreads();
                 if (test_s < 1e-14) break;
-                for (int e = tid; e < nn; e += blockDim.x) {
+                for (int e = tid; e < nn; e += 64) {
                     const int i = e / n, j = e % n;
                     if (i <= j) {
                         const double xj = (1.0 - rsum[j]) / tsum[j], xi = (1.0 - rsum[i]) / tsum[i];
@@ -142,12 +161,10 @@ __global__ __launch_bounds__(256) void k_ms_phase(MsParams p)
                 }
                 __syncthreads();
             }
+            double *ofc = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp + comp) * nn;
+            for (int e = tid; e < nn; e += 64) ofc[e] = fc[e];
+            __syncthreads();
         }
-        double *oppl = p.ppl + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp + comp) * nn;
-        double *opmi = p.pmi + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp + comp) * nn;
-        for (int e = tid; e < nn; e += blockDim.x) { oppl[e] = ppl[e] * fc[e]; opmi[e] = pmi[e]; }
-        __syncthreads();
-    }
 }
 
 // ---- small dense helpers on LDS matrices (one wavefront = one block) ----------------------------------
@@ -244,6 +261,7 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
     }
     const double *PPL = p.ppl + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
     const double *PMI = p.pmi + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
+    const double *FC = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp) * nn;   // ppl *= fc (:232)
 
     for (int l = 0; l < p.nlay; ++l) {
         const int k = l;  // look-down: bottom layer first (:842-845)
@@ -277,11 +295,11 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
             iscl = 1;
             const double fr = taur / (tauscat + taur), fs = tauscat / (tauscat + taur);
             for (int e = lane; e < nn; e += 64) {
-                double a = (p.iray > 0) ? fr * PPL[(size_t)p.ncont * nn + e] : 0.0;
+                double a = (p.iray > 0) ? fr * (PPL[(size_t)p.ncont * nn + e] * FC[(size_t)p.ncont * nn + e]) : 0.0;
                 double b = (p.iray > 0) ? fr * PMI[(size_t)p.ncont * nn + e] : 0.0;
                 for (int c = 0; c < p.ncont; ++c) {
                     const double f = p.lfrac[((size_t)widx * p.ncont + c) * p.nlay + k];
-                    a += fs * PPL[(size_t)c * nn + e] * f;
+                    a += fs * (PPL[(size_t)c * nn + e] * FC[(size_t)c * nn + e]) * f;
                     b += fs * PMI[(size_t)c * nn + e] * f;
                 }
                 pp[e] = a;
