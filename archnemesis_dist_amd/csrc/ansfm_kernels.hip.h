@@ -86,13 +86,14 @@ __global__ void k_layer_prep(int n_layers_total, const double *__restrict__ lay_
         if (d < best) { best = d; it = k; }
     }
     int itl, ith;
+    bool tclamp = false;
     if (TEMP[it] >= temp1) {
         ith = it;
-        if (it == 0) { temp1 = TEMP[0]; itl = 0; ith = 1; }
+        if (it == 0) { temp1 = TEMP[0]; itl = 0; ith = 1; tclamp = true; }
         else itl = it - 1;
     } else {
         itl = it;
-        if (it == NT - 1) { temp1 = TEMP[NT - 1]; ith = NT - 1; itl = NT - 2; }
+        if (it == NT - 1) { temp1 = TEMP[NT - 1]; ith = NT - 1; itl = NT - 2; tclamp = true; }
         else ith = it + 1;
     }
     double lpress = log(press1), plo = log(PRESS[ipl]), phi = log(PRESS[iph]);
@@ -110,6 +111,8 @@ __global__ void k_layer_prep(int n_layers_total, const double *__restrict__ lay_
     r.ipl = ipl; r.iph = iph; r.itl = itl; r.ith = ith;
     r.v = (lpress - plo) / pden;
     r.u = (temp1 - tlo) / tden;
+    if (grid_f32 && pclamp) r.v = (double)(((float)lpress - (float)plo) / (float)pden);   // all-float32 expression
+    if (grid_f32 && tclamp) r.u = (double)(((float)temp1 - (float)tlo) / (float)tden);
     r.dudt = dudt;
     out[i] = r;
 }

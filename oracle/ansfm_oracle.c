@@ -134,14 +134,14 @@ ORC_API void orc_bracket(int NP, const double *PRESS, int NT, const double *TEMP
         double d = fabs(TEMP[i] - temp1);
         if (d < best) { best = d; it = i; }
     }
-    int it_low = 0, it_high = 0;
+    int it_low = 0, it_high = 0, tclamp = 0;
     if (TEMP[it] >= temp1) {
         it_high = it;
-        if (it == 0) { temp1 = TEMP[0]; it_low = 0; it_high = 1; }
+        if (it == 0) { temp1 = TEMP[0]; it_low = 0; it_high = 1; tclamp = 1; }
         else it_low = it - 1;
     } else {
         it_low = it;
-        if (it == NT - 1) { temp1 = TEMP[NT - 1]; it_high = NT - 1; it_low = NT - 2; }
+        if (it == NT - 1) { temp1 = TEMP[NT - 1]; it_high = NT - 1; it_low = NT - 2; tclamp = 1; }
         else it_high = it + 1;
     }
     /* a clamped press1 is PRESS[0|NP-1] itself, i.e. a float32 scalar whose log is float32 too */
@@ -154,6 +154,8 @@ ORC_API void orc_bracket(int NP, const double *PRESS, int NT, const double *TEMP
     double tden = g_grid_f32 ? (double)((float)thi - (float)tlo) : thi - tlo;
     *v = (lpress - plo) / pden;
     *u = (temp1 - tlo) / tden;
+    if (g_grid_f32 && pclamp) *v = (double)(((float)lpress - (float)plo) / (float)pden);   /* all-float32 expression */
+    if (g_grid_f32 && tclamp) *u = (double)(((float)temp1 - (float)tlo) / (float)tden);
     *dudt = g_grid_f32 ? (double)(1.0f / (float)tden) : 1. / tden; /* python float / float32 -> float32 */
     *ipl = ip_low; *iph = ip_high; *itl = it_low; *ith = it_high;
 }
@@ -776,4 +778,104 @@ ORC_API void orc_cirsradg_ck_thermal(
         free(tpath); free(dtpath); free(emtemp); free(empress); free(spec); free(dspec); free(dts);
     }
     free(zeros); free(dtautot); free(tau);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* K11: LBL-table (P,T) interpolation   Spectroscopy_0.calc_klbl :1768-1919, calc_klblg :1601  */
+/* K[W][NP][NTa][S]; PRESS[NP] (atm); TEMP[NTa] or, when temp2d (NT<0 in the reference),       */
+/* TEMP[NP][NTa] (one temperature grid per pressure).  press[L] (atm), temp[L].                */
+/* with_grad selects calc_klblg, which lacks the it<0 clamp (:1672-1675): a layer exactly at    */
+/* the lowest table temperature then indexes TEMP[-1] (python wrap) -- reproduced.             */
+/* ------------------------------------------------------------------------------------------ */
+static int searchsorted_left(const double *a, int n, double x)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+ORC_API void orc_lbl_bracket(int NP, const double *PRESS, int NTa, const double *TEMP, int temp2d,
+                             double press1, double temp1, int with_grad, int *ip_o, int *it1_o, int *it2_o,
+                             double *v_o, double *u1_o, double *u2_o, double *du1_o, double *du2_o,
+                             double *omu1_o, double *omu2_o)
+{
+    double lp[256];
+    double pmin = INFINITY, pmax = -INFINITY;
+    for (int i = 0; i < NP; ++i) { lp[i] = logx(PRESS[i]); if (lp[i] < pmin) pmin = lp[i]; if (lp[i] > pmax) pmax = lp[i]; }
+    double p_l = log(press1);
+    int pcl = 0;   /* clamped p_l = np.min/np.max(log PRESS): float32 scalar when PRESS is float32 */
+    if (p_l < pmin) { p_l = pmin; pcl = 1; }
+    if (p_l > pmax) { p_l = pmax; pcl = 1; }
+    int nt_all = temp2d ? NP * NTa : NTa;
+    double tmin = INFINITY, tmax = -INFINITY;
+    for (int i = 0; i < nt_all; ++i) { if (TEMP[i] < tmin) tmin = TEMP[i]; if (TEMP[i] > tmax) tmax = TEMP[i]; }
+    double t_l = temp1;
+    int tcl = 0;   /* a clamped t_l is np.min/np.max(TEMP): a float32 scalar when TEMP is float32, and NumPy
+                      then evaluates u and (1.0-u) in float32 */
+    if (t_l < tmin) { t_l = tmin; tcl = 1; }
+    if (t_l > tmax) { t_l = tmax; tcl = 1; }
+    int ip = searchsorted_left(lp, NP, p_l) - 1;
+    if (ip < 0) ip = 0;
+    if (ip >= NP - 1) ip = NP - 2;
+    double pden = g_grid_f32 ? (double)((float)lp[ip + 1] - (float)lp[ip]) : lp[ip + 1] - lp[ip];
+    if (g_grid_f32 && pcl) *v_o = (double)(((float)p_l - (float)lp[ip]) / (float)pden);
+    else *v_o = (p_l - lp[ip]) / pden;
+    const double *Tn = temp2d ? TEMP + (size_t)ip * NTa : TEMP;
+    const double *Tn2 = temp2d ? TEMP + (size_t)(ip + 1) * NTa : TEMP;
+    for (int side = 0; side < 2; ++side) {
+        const double *T = side ? Tn2 : Tn;
+        int it = searchsorted_left(T, NTa, t_l) - 1;
+        if (!with_grad && it < 0) it = 0;
+        if (it >= NTa - 1) it = NTa - 2;
+        int itw = it < 0 ? it + NTa : it;          /* python negative index */
+        int itn = it + 1;                           /* it+1 == 0 when it == -1 */
+        double den = g_grid_f32 ? (double)((float)T[itn] - (float)T[itw]) : T[itn] - T[itw];
+        double u = (t_l - T[itw]) / den, omu;
+        if (g_grid_f32 && tcl) {
+            float uf = ((float)t_l - (float)T[itw]) / (float)den;
+            u = (double)uf;
+            omu = (double)(1.0f - uf);
+        } else
+            omu = 1.0 - u;
+        double du = g_grid_f32 ? (double)(1.0f / (float)den) : 1. / den;
+        if (side) { *it2_o = it; *u2_o = u; *du2_o = du; *omu2_o = omu; }
+        else { *it1_o = it; *u1_o = u; *du1_o = du; *omu1_o = omu; }
+    }
+    *ip_o = ip;
+}
+
+ORC_API void orc_calc_klbl(int W, int NP, int NTa, int S, const double *K, const double *PRESS, const double *TEMP,
+                           int temp2d, int L, const double *press, const double *temp, double *k_out /*[W][L][S]*/,
+                           double *dkdT_out /*or NULL*/)
+{
+    const int with_grad = dkdT_out != NULL;
+    for (int l = 0; l < L; ++l) {
+        int ip, it1, it2;
+        double v, u1, u2, du1, du2, omu1, omu2;
+        orc_lbl_bracket(NP, PRESS, NTa, TEMP, temp2d, press[l], temp[l], with_grad, &ip, &it1, &it2, &v, &u1, &u2, &du1, &du2,
+                        &omu1, &omu2);
+        int a1 = it1 < 0 ? it1 + NTa : it1, b1 = it1 + 1;
+        int a2 = it2 < 0 ? it2 + NTa : it2, b2 = it2 + 1;
+#pragma omp parallel for schedule(static)
+        for (int w = 0; w < W; ++w)
+            for (int s = 0; s < S; ++s) {
+                const double *base = K + (size_t)w * NP * NTa * S;
+                double klo1 = base[((size_t)ip * NTa + a1) * S + s];
+                double klo2 = base[((size_t)ip * NTa + b1) * S + s];
+                double khi1 = base[((size_t)(ip + 1) * NTa + a2) * S + s];
+                double khi2 = base[((size_t)(ip + 1) * NTa + b2) * S + s];
+                double kk = 0.0, dk = 0.0;
+                if (klo1 > 0.0 && klo2 > 0.0 && khi1 > 0.0 && khi2 > 0.0) {
+                    double l1 = log(klo1), l2 = log(klo2), h1 = log(khi1), h2 = log(khi2);
+                    kk = exp((1.0 - v) * omu1 * l1 + v * omu2 * h1 + v * u2 * h2 + (1.0 - v) * u1 * l2);
+                    double dxdt = -l1 * (1.0 - v) * du1 - h1 * v * du2 + h2 * v * du2 + l2 * (1.0 - v) * du1;
+                    dk = kk * dxdt;
+                } else if (klo1 <= 0.0 && klo2 <= 0.0 && khi1 <= 0.0 && khi2 <= 0.0) {
+                    kk = (1.0 - v) * omu1 * klo1 + v * omu2 * khi1 + v * u2 * khi2 + (1.0 - v) * u1 * klo2;
+                    dk = -klo1 * (1.0 - v) * du1 - khi1 * v * du2 + khi2 * v * du2 + klo2 * (1.0 - v) * du1;
+                }
+                size_t o = ((size_t)w * L + l) * S + s;
+                k_out[o] = kk;
+                if (with_grad) dkdT_out[o] = dk;
+            }
+    }
 }

@@ -63,12 +63,15 @@ def make_spec(ans, WAVE, G, PRESS, TEMP, K, g_ord, del_g):
     return sp
 
 
-def case_ck(ans, name, seed, W, G, NP, NT, S, L, fp32=True, zero_low_g=True, special=True):
+def case_ck(ans, name, seed, W, G, NP, NT, S, L, fp32=True, zero_low_g=True, special=True, f32_dtype=False):
     fm = sys.modules['archnemesis.ForwardModel_0']
     rng = np.random.default_rng(seed)
     g_ord, del_g = gauss_legendre_01(G, fp32)
     PRESS, TEMP, K = synth_ktable(rng, W, G, NP, NT, S, zero_low_g, fp32)
     WAVE = 200.0 + 2.5 * np.arange(W)
+    if f32_dtype:   # what read_tables leaves behind for .kta input: float32 PRESS/TEMP/G_ORD/DELG arrays
+        PRESS = PRESS.astype(np.float32); TEMP = (TEMP + 0.123).astype(np.float32)
+        g_ord = g_ord.astype(np.float32); del_g = del_g.astype(np.float32)
     sp = make_spec(ans, WAVE, G, PRESS, TEMP, K, g_ord, del_g)
     press = np.logspace(np.log10(5.0), -6.5, L)           # atm, bottom -> top
     temp = 110.0 + 250.0 * (np.linspace(0, 1, L) - 0.4) ** 2 + rng.uniform(-3, 3, L)
@@ -155,9 +158,47 @@ def case_thermal(ans, name, seed, W, G, Li, NPAR, NVMR):
     print(name, "ok")
 
 
+def case_lbl(ans, name, seed, W, NP, NTa, S, L, temp2d=False, fp32=False):
+    """Spectroscopy_0.calc_klbl / calc_klblg on a synthetic LBL table K (W,NP,NT,S)."""
+    rng = np.random.default_rng(seed)
+    PRESS = np.logspace(-6, 1.0, NP)
+    if temp2d:   # NT < 0: one temperature grid per pressure level (:1664-1669)
+        TEMP = np.stack([np.linspace(80.0 + 3 * i, 330.0 + 5 * i, NTa) for i in range(NP)])
+    else:
+        TEMP = np.linspace(90.0, 350.0, NTa)
+    K = 10.0 ** rng.uniform(-27, -19, size=(W, NP, NTa, S))
+    K[1, :, :, 0] = 0.0                      # an all-zero line ("bad" branch)
+    K[2, 1, 2, 1] = 0.0                      # a mixed-sign corner (-> 0)
+    if fp32:
+        PRESS = PRESS.astype(np.float32); TEMP = TEMP.astype(np.float32)
+        K = (K * 1e20).astype(np.float32).astype(np.float64) * 1e-20
+    sp = ans.Spectroscopy_0(ILBL=2)
+    sp.NGAS = S; sp.ID = np.arange(1, S + 1); sp.ISO = np.zeros(S, dtype=int)
+    sp.NWAVE = W; sp.WAVE = 2000.0 + 0.01 * np.arange(W)
+    sp.NP = NP; sp.NT = -NTa if temp2d else NTa; sp.PRESS = PRESS; sp.TEMP = TEMP
+    sp.NG = 1; sp.G_ORD = np.array([0.]); sp.DELG = np.array([1.0]); sp.K = K
+    press = np.logspace(0.8, -5.5, L)
+    temp = np.linspace(120.0, 300.0, L) + rng.uniform(-4, 4, L)
+    press[0] = float(PRESS[-1]) * 2.0; press[-1] = float(PRESS[0]) * 0.3      # outside the table
+    temp[1] = float(np.max(TEMP)) + 20.0; temp[2] = float(np.min(TEMP)) - 5.0  # clamped (klblg: python [-1] wrap)
+    press[3] = float(PRESS[2]); temp[3] = float(np.ravel(TEMP)[1])            # on grid values
+    k = sp.calc_klbl(L, press, temp)
+    kg, dkdT = sp.calc_klblg(L, press, temp)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), K=K, TPRESS=PRESS, TTEMP=TEMP, press=press, temp=temp,
+                        k=k, kg=kg, dkdT=dkdT, WAVE=sp.WAVE)
+    print(name, k.shape, "max|k-kg|/k", np.nanmax(np.abs(k - kg) / np.maximum(np.abs(k), 1e-300)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ans = import_reference()
+    if "--f32-only" in sys.argv:
+        case_ck(ans, "ck_g10_s3_f32dtype", 106, W=6, G=10, NP=6, NT=5, S=3, L=8, f32_dtype=True)
+        return
+    if "--lbl-only" in sys.argv:
+        case_lbl(ans, "lbl_tab", 301, W=9, NP=6, NTa=5, S=3, L=9)
+        case_lbl(ans, "lbl_tab_t2d_f32", 302, W=7, NP=5, NTa=4, S=2, L=8, temp2d=True, fp32=True)
+        return
     case_rank(ans, "rank_g10", 11, 10)
     case_rank(ans, "rank_g20", 12, 20)
     case_ck(ans, "ck_g10_s4", 101, W=10, G=10, NP=7, NT=6, S=4, L=9)

@@ -200,3 +200,16 @@ def scloud11wave_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, lowbc, 
     if rc == 5:
         raise NotImplementedError("look-up geometry (emission angle > 90) not restated")
     return rad
+
+
+def calc_klbl(K, PRESS, TEMP, press, temp, grad=False):
+    """Spectroscopy_0.calc_klbl / calc_klblg.  K (W,NP,|NT|,S); TEMP (|NT|,) or (NP,|NT|) (the NT<0 form)
+    -> k (W,L,S) [, dkdT]."""
+    set_f32_semantics(_is_f32(PRESS) or _is_f32(TEMP), False)
+    K = _c(K); PRESS = _c(PRESS); TEMP = _c(TEMP); press = _c(press); temp = _c(temp)
+    W, NP, NTa, S = K.shape
+    temp2d = int(TEMP.ndim == 2)
+    L = press.shape[0]
+    k = np.zeros((W, L, S)); dk = np.zeros((W, L, S)) if grad else None
+    lib().orc_calc_klbl(W, NP, NTa, S, _p(K), _p(PRESS), _p(TEMP), temp2d, L, _p(press), _p(temp), _p(k), _p(dk))
+    return (k, dk) if grad else k

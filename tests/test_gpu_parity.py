@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CK_CASES = ["ck_g10_s4", "ck_g20_s8", "ck_g16_s2", "ck_g8_s1", "ck_g10_s3_nozero"]
+CK_CASES = ["ck_g10_s4", "ck_g20_s8", "ck_g16_s2", "ck_g8_s1", "ck_g10_s3_nozero", "ck_g10_s3_f32dtype"]
 
 
 @pytest.fixture(scope="module")
@@ -34,10 +34,12 @@ def test_calc_k_golden(eng, golden_dir, name):
     eng.upload_ktable(z["K"], z["TPRESS"], z["TTEMP"], z["WAVE"], z["DELG"])
     k = eng.calc_k(z["press"], z["temp"])
     assert np.array_equal(k == 0.0, z["k"] == 0.0)           # good/bad/mixed mask exactly
-    np.testing.assert_allclose(k, z["k"], rtol=1e-12, atol=0)
+    # float32 grids: NumPy's float32 log is not correctly rounded -> reference defined to ~1e-7 only
+    rt = 2e-7 if name.endswith("f32dtype") else 1e-12
+    np.testing.assert_allclose(k, z["k"], rtol=rt, atol=0)
     kg, dk = eng.calc_k(z["press"], z["temp"], grad=True)
-    np.testing.assert_allclose(kg, z["kg"], rtol=1e-12, atol=0)
-    np.testing.assert_allclose(dk, z["dkdT"], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(kg, z["kg"], rtol=rt, atol=0)
+    np.testing.assert_allclose(dk, z["dkdT"], rtol=max(rt, 1e-10), atol=0)
 
 
 @pytest.mark.parametrize("name", CK_CASES)

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-CK_CASES = ["ck_g10_s4", "ck_g20_s8", "ck_g16_s2", "ck_g8_s1", "ck_g10_s3_nozero"]
+CK_CASES = ["ck_g10_s4", "ck_g20_s8", "ck_g16_s2", "ck_g8_s1", "ck_g10_s3_nozero", "ck_g10_s3_f32dtype"]
 
 
 def _load(golden_dir, name):
@@ -29,12 +29,16 @@ def test_rank(oracle, golden_dir, name):
 def test_calc_k(oracle, golden_dir, name):
     z = _load(golden_dir, name)
     k = oracle.calc_k(z["K"], z["TPRESS"], z["TTEMP"], z["press"], z["temp"])
-    np.testing.assert_allclose(k, z["k"], rtol=2e-14, atol=0)
+    # float32 PRESS/TEMP: NumPy takes np.log(PRESS[i]) with its SIMD float32 log, which is not correctly
+    # rounded (1 ulp_f32 off for ~6 % of arguments; numba's logf differs again) -> the reference itself
+    # is only defined to ~1e-7 there; the oracle uses the correctly rounded float32 log
+    rt = 2e-7 if name.endswith("f32dtype") else 2e-14
+    np.testing.assert_allclose(k, z["k"], rtol=rt, atol=0)
     # exact zeros (mixed-sign corners, all-zero corners) must be reproduced exactly
     assert np.array_equal(k == 0.0, z["k"] == 0.0)
     kg, dk = oracle.calc_k(z["K"], z["TPRESS"], z["TTEMP"], z["press"], z["temp"], grad=True)
-    np.testing.assert_allclose(kg, z["kg"], rtol=2e-14, atol=0)
-    np.testing.assert_allclose(dk, z["dkdT"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(kg, z["kg"], rtol=rt, atol=0)
+    np.testing.assert_allclose(dk, z["dkdT"], rtol=max(rt, 1e-12), atol=0)
 
 
 @pytest.mark.parametrize("name", CK_CASES)
@@ -82,3 +86,13 @@ def test_thermal(oracle, golden_dir):
             bb, db = oracle.planckg(ispace, W, T)
             np.testing.assert_allclose(bb, z[f"{tag}_planckg_bb"][i], rtol=1e-14)
             np.testing.assert_allclose(db, z[f"{tag}_planckg_db"][i], rtol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["lbl_tab", "lbl_tab_t2d_f32"])
+def test_calc_klbl(oracle, golden_dir, name):
+    z = _load(golden_dir, name)
+    k = oracle.calc_klbl(z["K"], z["TPRESS"], z["TTEMP"], z["press"], z["temp"])
+    np.testing.assert_allclose(k, z["k"], rtol=1e-12, atol=0)
+    kg, dk = oracle.calc_klbl(z["K"], z["TPRESS"], z["TTEMP"], z["press"], z["temp"], grad=True)
+    np.testing.assert_allclose(kg, z["kg"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(dk, z["dkdT"], rtol=1e-10, atol=0)
