@@ -680,6 +680,150 @@ __global__ void k_dk_to_ref(const double *__restrict__ src, double *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// K11: LBL-table mode (ILBL = LINE_BY_LINE_TABLES): Spectroscopy_0.calc_klbl :1768-1919 /
+// calc_klblg :1601-1765 and the gas sum of calculate_gaseous_line_opacity (:3795-3817).
+// The table is stored like the k-table with G = 1: lnK[NP][NTa][S][1][Wpad].
+// ------------------------------------------------------------------------------------------------
+struct LblInterp {
+    int ip, a1, b1, a2, b2;   // corner temperature indices (a = it with python wrap, b = it+1)
+    double v, u1, u2, omu1, omu2, du1, du2;
+};
+
+__device__ __forceinline__ int searchsorted_left_dev(const double *a, int n, double x)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// One thread per (model, layer).  TEMP is [NTa] or, when temp2d (the reference's NT < 0), [NP][NTa].
+// with_grad selects calc_klblg's bracket (no it<0 clamp: python [-1] wrap, :1672-1675).
+__global__ void k_layer_prep_lbl(int n_layers_total, const double *__restrict__ lay_press,
+                                 const double *__restrict__ lay_temp, int NP, const double *__restrict__ PRESS,
+                                 int NTa, const double *__restrict__ TEMP, int temp2d, double press_div,
+                                 int grid_f32, int with_grad, LblInterp *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_layers_total) return;
+    auto lg = [&](double x) { double r = log(x); return grid_f32 ? (double)(float)r : r; };
+    double pmin = __builtin_inf(), pmax = -__builtin_inf();
+    for (int k = 0; k < NP; ++k) { double l = lg(PRESS[k]); pmin = fmin(pmin, l); pmax = fmax(pmax, l); }
+    double p_l = log(lay_press[i] / press_div);
+    bool pcl = false, tcl = false;
+    if (p_l < pmin) { p_l = pmin; pcl = true; }
+    if (p_l > pmax) { p_l = pmax; pcl = true; }
+    const int nt_all = temp2d ? NP * NTa : NTa;
+    double tmin = __builtin_inf(), tmax = -__builtin_inf();
+    for (int k = 0; k < nt_all; ++k) { tmin = fmin(tmin, TEMP[k]); tmax = fmax(tmax, TEMP[k]); }
+    double t_l = lay_temp[i];
+    if (t_l < tmin) { t_l = tmin; tcl = true; }
+    if (t_l > tmax) { t_l = tmax; tcl = true; }
+    // searchsorted(log PRESS, p_l) - 1 on the (ascending) log grid
+    int lo = 0, hi = NP;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (lg(PRESS[mid]) < p_l) lo = mid + 1; else hi = mid; }
+    int ip = lo - 1;
+    if (ip < 0) ip = 0;
+    if (ip >= NP - 1) ip = NP - 2;
+    const double l0 = lg(PRESS[ip]), l1 = lg(PRESS[ip + 1]);
+    const double pden = grid_f32 ? (double)((float)l1 - (float)l0) : l1 - l0;
+    LblInterp r;
+    r.ip = ip;
+    r.v = (grid_f32 && pcl) ? (double)(((float)p_l - (float)l0) / (float)pden) : (p_l - l0) / pden;
+    for (int side = 0; side < 2; ++side) {
+        const double *T = temp2d ? TEMP + (size_t)(ip + side) * NTa : TEMP;
+        int it = searchsorted_left_dev(T, NTa, t_l) - 1;
+        if (!with_grad && it < 0) it = 0;
+        if (it >= NTa - 1) it = NTa - 2;
+        const int itw = it < 0 ? it + NTa : it, itn = it + 1;
+        const double den = grid_f32 ? (double)((float)T[itn] - (float)T[itw]) : T[itn] - T[itw];
+        double u = (t_l - T[itw]) / den, omu;
+        if (grid_f32 && tcl) {
+            const float uf = ((float)t_l - (float)T[itw]) / (float)den;
+            u = (double)uf;
+            omu = (double)(1.0f - uf);
+        } else
+            omu = 1.0 - u;
+        const double du = grid_f32 ? (double)(1.0f / (float)den) : 1. / den;
+        if (side) { r.a2 = itw; r.b2 = itn; r.u2 = u; r.omu2 = omu; r.du2 = du; }
+        else { r.a1 = itw; r.b1 = itn; r.u1 = u; r.omu1 = omu; r.du1 = du; }
+    }
+    out[i] = r;
+}
+
+__device__ __forceinline__ void interp_klbl(double l1, double l2, double h1, double h2, const LblInterp &q,
+                                            double &kk, double &dk)
+{   // l1 = (ip,it1) l2 = (ip,it1+1) h1 = (ip+1,it2) h2 = (ip+1,it2+1)      :1898-1917 / :1727-1762
+    const bool b1 = lnk_is_boxed(l1), b2 = lnk_is_boxed(l2), b3 = lnk_is_boxed(h1), b4 = lnk_is_boxed(h2);
+    kk = 0.0; dk = 0.0;
+    const double omv = 1.0 - q.v;
+    if (!(b1 | b2 | b3 | b4)) {
+        kk = exp(omv * q.omu1 * l1 + q.v * q.omu2 * h1 + q.v * q.u2 * h2 + omv * q.u1 * l2);
+        dk = kk * (-l1 * omv * q.du1 - h1 * q.v * q.du2 + h2 * q.v * q.du2 + l2 * omv * q.du1);
+    } else if (b1 & b2 & b3 & b4) {
+        const double klo1 = lnk_unbox(l1), klo2 = lnk_unbox(l2), khi1 = lnk_unbox(h1), khi2 = lnk_unbox(h2);
+        kk = omv * q.omu1 * klo1 + q.v * q.omu2 * khi1 + q.v * q.u2 * khi2 + omv * q.u1 * klo2;
+        dk = -klo1 * omv * q.du1 - khi1 * q.v * q.du2 + khi2 * q.v * q.du2 + klo2 * omv * q.du1;
+    }
+}
+
+// array-level seam: k[W][L][S] (+dkdT)
+__global__ void k_calc_klbl_seam(const double *__restrict__ lnK, int W, int Wpad, int NTa, int S, int L,
+                                 const LblInterp *__restrict__ li, double *__restrict__ k_out,
+                                 double *__restrict__ dk_out)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)L * S * W;
+    if (idx >= total) return;
+    const int w = (int)(idx % W);
+    const int s = (int)((idx / W) % S);
+    const int l = (int)(idx / ((size_t)W * S));
+    const LblInterp q = li[l];
+    const size_t strideT = (size_t)S * Wpad, off = (size_t)s * Wpad + w;
+    const double l1 = lnK[((size_t)q.ip * NTa + q.a1) * strideT + off];
+    const double l2 = lnK[((size_t)q.ip * NTa + q.b1) * strideT + off];
+    const double h1 = lnK[((size_t)(q.ip + 1) * NTa + q.a2) * strideT + off];
+    const double h2 = lnK[((size_t)(q.ip + 1) * NTa + q.b2) * strideT + off];
+    double kk, dk;
+    interp_klbl(l1, l2, h1, h2, q, kk, dk);
+    const size_t o = ((size_t)w * L + l) * S + s;
+    k_out[o] = kk;
+    if (dk_out) dk_out[o] = dk;
+}
+
+// fused: tau[n][L][1][Wpad] = sum_s k_s * amount_s ; dk[n][L][S+1][1][Wpad]: slot s = k_s, slot S = sum dkdT_s*amount_s
+__global__ void k_lbl_tau(const double *__restrict__ lnK, int Wpad, int NTa, int S, int L, int n_models,
+                          const LblInterp *__restrict__ li, const double *__restrict__ amount,
+                          double *__restrict__ tau, double *__restrict__ dk)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)n_models * L * Wpad;
+    if (idx >= total) return;
+    const int w = (int)(idx % Wpad);
+    const int l = (int)((idx / Wpad) % L);
+    const int m = (int)(idx / ((size_t)Wpad * L));
+    const LblInterp q = li[(size_t)m * L + l];
+    const size_t strideT = (size_t)S * Wpad;
+    double t = 0.0, dT = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const size_t off = (size_t)s * Wpad + w;
+        const double l1 = lnK[((size_t)q.ip * NTa + q.a1) * strideT + off];
+        const double l2 = lnK[((size_t)q.ip * NTa + q.b1) * strideT + off];
+        const double h1 = lnK[((size_t)(q.ip + 1) * NTa + q.a2) * strideT + off];
+        const double h2 = lnK[((size_t)(q.ip + 1) * NTa + q.b2) * strideT + off];
+        double kk, dkk;
+        interp_klbl(l1, l2, h1, h2, q, kk, dkk);
+        const double am = amount[((size_t)m * S + s) * L + l];
+        t += kk * am;                                   // TAUGAS[:,0,:,i] = k*VLOSDENS ; np.sum(TAUGAS,3)  :3810,:3817
+        if (dk) {
+            dk[(((size_t)m * L + l) * (S + 1) + s) * Wpad + w] = kk;     // :3813
+            dT += dkk * am;                                              // :3814
+        }
+    }
+    tau[((size_t)m * L + l) * Wpad + w] = t;
+    if (dk) dk[(((size_t)m * L + l) * (S + 1) + S) * Wpad + w] = dT;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3+K4+K5+K6 fused: total opacity, LAYINC gather * SCALE, layer loop with Planck emission,
 // ground / solar terms, unit factor and g-quadrature.   "thermal_rt"
 // Block = 64 wavenumbers x GY g-groups; thread (lane, gy) integrates g = gy, gy+GY, ...

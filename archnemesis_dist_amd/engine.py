@@ -91,6 +91,26 @@ class AnsfmEngine:
         self.dims = (W, G, NP, NT, S)
         self.WAVE, self.DELG = WAVE, DELG
 
+    def upload_lbltable(self, K, PRESS, TEMP, WAVE):
+        """LBL table (ILBL = 2): K (W,NP,|NT|,S) float64 host array; TEMP (|NT|,) or (NP,|NT|) (NT < 0 form)."""
+        self.set_f32_semantics(_is_f32(PRESS) or _is_f32(TEMP), False)
+        K = _np(K); PRESS = _np(PRESS); TEMP = _np(TEMP); WAVE = _np(WAVE)
+        W, NP, NT, S = (int(x) for x in K.shape)
+        temp2d = int(TEMP.ndim == 2)
+        assert PRESS.shape == (NP,) and WAVE.shape == (W,) and TEMP.shape == ((NP, NT) if temp2d else (NT,))
+        self._check(self._lib.ansfm_upload_lbltable(self._ctx, W, NP, NT, S, _ptr(K), _ptr(PRESS), _ptr(TEMP), temp2d,
+                                                    _ptr(WAVE)), "upload_lbltable")
+        self.dims = (W, 1, NP, NT, S)
+        self.WAVE, self.DELG = WAVE, np.array([1.0])
+
+    def calc_klbl(self, press, temp, grad=False):
+        press = _np(press); temp = _np(temp)
+        W, _, NP, NT, S = self.dims
+        L = press.shape[0]
+        k = np.empty((W, L, S)); dk = np.empty((W, L, S)) if grad else None
+        self._check(self._lib.ansfm_calc_klbl(self._ctx, L, _ptr(press), _ptr(temp), _ptr(k), _ptr(dk)), "calc_klbl")
+        return (k, dk) if grad else k
+
     def ktable_info(self):
         dims = (C.c_int64 * 5)()
         mono = C.c_int()

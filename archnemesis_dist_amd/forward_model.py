@@ -2,7 +2,7 @@
 
 `make_gpu_forward_model(ForwardModel_0)` returns a subclass of the reference's own class
 (ForwardModel_0.py:87) whose `CIRSrad` (ForwardModel_0.py:4376-4511) runs on the MI355X through
-libansfm.so for the supported case (ILBL = K_TABLES, IMOD = THERMAL_EMISSION, no layer emissions,
+libansfm.so for the supported cases (ILBL = K_TABLES or LINE_BY_LINE_TABLES, IMOD = THERMAL_EMISSION, no layer emissions,
 with or without analytic gradients) and whose `jacobian_nemesis` fan-out can batch the independent forward models.
 Everything else (subprofretg, calc_path, conv, ...) is the reference's own host code.
 
@@ -18,6 +18,7 @@ from .engine import AnsfmEngine
 
 # IntEnum / IntFlag values of the reference (archnemesis/enum/*.py) kept as plain ints at the seam
 ILBL_K_TABLES = 0                      # SpectralCalculationModeEnum.K_TABLES
+ILBL_LBL_TABLES = 2                    # SpectralCalculationModeEnum.LINE_BY_LINE_TABLES
 IMOD_THERMAL_EMISSION = 64             # PathCalcEnum.THERMAL_EMISSION
 IMOD_MULTIPLE_SCATTERING = 256
 IMOD_SINGLE_SCATTERING_PLANE_PARALLEL = 1024
@@ -43,6 +44,7 @@ def _table_fingerprint(S):
     K = S.K
     h = hashlib.blake2b(digest_size=16)
     h.update(np.asarray(K.shape, dtype=np.int64).tobytes())
+    h.update(str(int(S.ILBL)).encode())
     flat = K.reshape(-1)
     step = max(1, flat.size // 8192)
     h.update(np.ascontiguousarray(flat[::step]).tobytes())
@@ -61,7 +63,7 @@ class CIRSradGPU:
     # ---- what is supported -----------------------------------------------------------------------
     def _ansfm_supported(self, return_grad):
         S = self.SpectroscopyX
-        if S.NGAS <= 0 or int(S.ILBL) != ILBL_K_TABLES:
+        if S.NGAS <= 0 or int(S.ILBL) not in (ILBL_K_TABLES, ILBL_LBL_TABLES) or S.K is None:
             return False
         if return_grad and (self.AtmosphereX.NVMR + 2 + self.ScatterX.NDUST > 64 or S.NGAS > 20):
             return False
@@ -138,7 +140,10 @@ class CIRSradGPU:
         S = self.SpectroscopyX
         fp = _table_fingerprint(S)
         if getattr(eng, "_table_fp", None) != fp:
-            eng.upload_ktable(np.ascontiguousarray(S.K, dtype=np.float64), S.PRESS, S.TEMP, S.WAVE, S.DELG)
+            if int(S.ILBL) == ILBL_LBL_TABLES:      # K (NWAVE,NP,|NT|,NGAS); TEMP (NP,|NT|) when NT < 0
+                eng.upload_lbltable(np.ascontiguousarray(S.K, dtype=np.float64), S.PRESS, S.TEMP, S.WAVE)
+            else:
+                eng.upload_ktable(np.ascontiguousarray(S.K, dtype=np.float64), S.PRESS, S.TEMP, S.WAVE, S.DELG)
             eng._table_fp = fp
 
     def _ansfm_layer_inputs(self):

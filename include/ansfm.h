@@ -75,6 +75,19 @@ int ansfm_upload_ktable_dev(ansfm_ctx *ctx, int W, int G, int NP, int NT, int S,
  * non-decreasing in g (precondition of the merge kernel's fast path). */
 int ansfm_ktable_info(const ansfm_ctx *ctx, int64_t dims[5], int *monotone);
 
+/* ---- LBL tables (ILBL = LINE_BY_LINE_TABLES) ------------------------------------------------------
+ * State of Spectroscopy_0 after read_tables on .lta / HDF5 LBL tables: K[W][NP][|NT|][S] (NG = 1),
+ * PRESS[NP] (atm), TEMP[|NT|] or -- temp2d != 0, the reference's NT < 0 -- TEMP[NP][|NT|] (one
+ * temperature grid per pressure, Spectroscopy_0.py:1664-1669).  After this upload the fused
+ * cirsrad entry points run the ILBL=2 branch of calculate_gaseous_line_opacity (ForwardModel_0.py
+ * :3795-3817: calc_klbl(g), tau = sum_gas k * amount) instead of the k-distribution merge. */
+int ansfm_upload_lbltable(ansfm_ctx *ctx, int W, int NP, int NT, int S, const double *K,
+                          const double *PRESS, const double *TEMP, int temp2d, const double *WAVE);
+/* Spectroscopy_0.calc_klbl (:1768) / calc_klblg (:1601, when dkdT_out != NULL; note its missing
+ * it<0 clamp is reproduced): press[L] atm, temp[L] K -> k_out[W][L][S] (, dkdT_out[W][L][S]). */
+int ansfm_calc_klbl(ansfm_ctx *ctx, int L, const double *press, const double *temp, double *k_out,
+                    double *dkdT_out);
+
 /* ---- array-level seams (host pointers), one per numba/NumPy kernel of the reference ------- */
 
 /* Spectroscopy_0.calc_k (Spectroscopy_0.py:2298) / calc_kg (:2147), WAVECALC=None.

@@ -233,3 +233,59 @@ def test_scloud11wave_core_vs_oracle_random(eng, oracle, golden_dir):
     rad = eng.scloud11wave_core(*ms_args(z))
     ref = oracle.scloud11wave_core(*ms_args(z))
     np.testing.assert_allclose(rad, ref, rtol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["lbl_tab", "lbl_tab_t2d_f32"])
+def test_calc_klbl_golden(eng, golden_dir, name):
+    z = _load(golden_dir, name)
+    eng.upload_lbltable(z["K"], z["TPRESS"], z["TTEMP"], z["WAVE"])
+    k = eng.calc_klbl(z["press"], z["temp"])
+    np.testing.assert_allclose(k, z["k"], rtol=1e-12, atol=0)
+    kg, dk = eng.calc_klbl(z["press"], z["temp"], grad=True)
+    np.testing.assert_allclose(kg, z["kg"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(dk, z["dkdT"], rtol=1e-10, atol=0)
+
+
+def test_cirsrad_lbl_tables_vs_oracle(eng, oracle):
+    """Fused CIRSrad for ILBL = LINE_BY_LINE_TABLES (NG=1), forward and analytic gradient, against the oracle
+    composed the way calculate_gaseous_line_opacity does it (:3795-3817)."""
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(12)
+    W, NP, NT, S, L = 300, 7, 6, 3, 15
+    PRESS = np.logspace(-6, 1.1, NP); TEMP = np.linspace(80.0, 420.0, NT)
+    K = 10.0 ** rng.uniform(-27, -20, size=(W, NP, NT, S))
+    WAVE = 2000.0 + 0.01 * np.arange(W)
+    atm = syn.synth_atmosphere(L, S, seed=3)
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L, 15.0)
+    cont = syn.synth_continuum(W, L)
+    EMTEMP = atm["lay_temp"][:, LAYINC[:, 0]][:, :, None]
+    lp, lt, am = atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0]
+    eng.upload_lbltable(K, PRESS, TEMP, WAVE)
+    out = eng.cirsrad_ck_thermal(0, lp, lt, am, cont[0], NLAYIN, LAYINC, SCALE, EMTEMP[0], 250.0, EMISSIVITY=np.ones(W))
+    k, dkdT = oracle.calc_klbl(K, PRESS, TEMP, lp / 101325.0, lt, grad=True)              # (W,L,S)
+    tau = np.zeros((W, L))
+    for s in range(S):
+        tau = tau + k[:, :, s] * am[s][None, :]
+    tautot = tau + cont[0]
+    path = (tautot[:, LAYINC[:, 0]] * SCALE[:, 0])[:, None, :]
+    z = np.zeros(W)
+    ref = oracle.calc_thermal_emission_spectrum(0, WAVE, path, None, EMTEMP[0][:, 0], lp[LAYINC[:, 0]], 250.0,
+                                                np.ones(W), z, z, 180.0, 180.0)
+    np.testing.assert_allclose(out[:, 0], ref[:, 0], rtol=1e-11)
+    # gradient
+    NVMR, NPAR = S, S + 2
+    igas_map = np.arange(S, dtype=np.int32)
+    spec, dspec, dts = eng.cirsradg_ck_thermal(0, lp, lt, am, cont[0], None, NVMR, NPAR, igas_map, NLAYIN, LAYINC, SCALE,
+                                               EMTEMP[0], 250.0, EMISSIVITY=np.ones(W))
+    dtau = np.zeros((W, 1, NPAR, L))
+    for s in range(S):
+        dtau[:, 0, s, :] = k[:, :, s] * 1.0e-4
+        dtau[:, 0, NVMR, :] += dkdT[:, :, s] * am[s][None, :]
+    dpath = dtau[:, :, :, LAYINC[:, 0]] * SCALE[:, 0]
+    rs, rd, rt = oracle.calc_thermal_emission_spectrumg(0, WAVE, path, dpath, NVMR, EMTEMP[0][:, 0], lp[LAYINC[:, 0]],
+                                                        250.0, np.ones(W))
+    np.testing.assert_allclose(spec[:, 0], rs[:, 0], rtol=1e-11)
+    np.testing.assert_allclose(dts[:, 0], rt[:, 0], rtol=1e-11)
+    ref_d = rd[:, 0]                                                       # (W,NPAR,Li)
+    scale = np.abs(ref_d).max(axis=(0, 2), keepdims=True) + 1e-300
+    assert np.max(np.abs(dspec[:, :, :, 0] - ref_d) / scale) < 1e-10
