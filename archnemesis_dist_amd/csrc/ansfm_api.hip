@@ -2,12 +2,14 @@
 // gfx950 only.  No CPU fallback: every entry point needs a live HIP device.
 #include "ansfm_kernels.hip.h"
 #include "ansfm_ms_kernels.hip.h"
+#include "ansfm_lbl_kernels.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -1033,6 +1035,89 @@ int ansfm_calc_klbl(ansfm_ctx *ctx, int L, const double *press, const double *te
     HIPCHK(hipMemcpyAsync(k_out, ctx->tmp_out.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (dkdT_out) HIPCHK(hipMemcpyAsync(dkdT_out, dk, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* runtime line-by-line                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+int ansfm_add_line_set_monochromatic_absorption(
+    ansfm_ctx *ctx, int nw, const double *wn_grid, int lineshape_id, int L, const double *t_calc, double t_ref,
+    const double *p_calc, double p_ref, const double *q_ratio, double isotopic_abundance, double isotopic_mass, int M,
+    const double *mol_mix_frac, int N, const double *broadening_params, const double *nu, const double *sw,
+    const double *e_lower, const double *stim_ref, double *out, double *store, double s_floor, double wn_calc_window,
+    double wn_approx_window)
+{
+    CHECK_CTX(ctx);
+    if (nw <= 0 || L <= 0 || M <= 0 || N < 0 || !wn_grid || !t_calc || !p_calc || !q_ratio || !mol_mix_frac || !out ||
+        (N > 0 && (!broadening_params || !nu || !sw || !e_lower || !stim_ref)))
+        FAIL(ANSFM_ERR_INVALID, "add_line_set_monochromatic_absorption: bad argument");
+    if (lineshape_id != 0 && lineshape_id != 4 && lineshape_id != 12)
+        FAIL(ANSFM_ERR_UNSUPPORTED, "lineshape: VOIGT (0), LORENTZ (4), DOPPLER (12) are built");   // enum map raises NotImplementedError
+    for (int j = 1; j < nw; ++j)
+        if (wn_grid[j] < wn_grid[j - 1]) FAIL(ANSFM_ERR_INVALID, "wn_grid must be ascending (LineData_0.py:230)");
+    if (N == 0) return ANSFM_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    // lines sorted by wavenumber for the windowed gather (the reference accepts any order; summation order then
+    // differs from it only in rounding)
+    std::vector<int> ord(N);
+    for (int i = 0; i < N; ++i) ord[i] = i;
+    bool sorted = true;
+    for (int i = 1; i < N; ++i) if (nu[i] < nu[i - 1]) { sorted = false; break; }
+    if (!sorted) std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return nu[a] < nu[b]; });
+    std::vector<double> h((size_t)(4 + 3 * M) * N);
+    double *hnu = h.data(), *hsw = hnu + N, *hel = hsw + N, *hsr = hel + N, *hbp = hsr + N;
+    double dmax = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const int o = ord[i];
+        hnu[i] = nu[o]; hsw[i] = sw[o]; hel[i] = e_lower[o]; hsr[i] = stim_ref[o];
+        double d = 0.0;
+        for (int r = 0; r < 3 * M; ++r) hbp[(size_t)r * N + i] = broadening_params[(size_t)r * N + o];
+        for (int j = 0; j < M; ++j) d += fabs(broadening_params[(size_t)(3 * j + 2) * N + o] * mol_mix_frac[j]);
+        if (d > dmax) dmax = d;
+    }
+    double pmax = 0.0;
+    for (int l = 0; l < L; ++l) if (fabs(p_calc[l] / p_ref) > pmax) pmax = fabs(p_calc[l] / p_ref);
+    const size_t D = sizeof(double);
+    const void *d_lines, *d_grid, *d_mmf, *d_t, *d_p, *d_q, *d_out;
+    int rc;
+    if ((rc = h2d(ctx, ctx->hb[0], h.data(), h.size() * D, &d_lines))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[1], wn_grid, (size_t)nw * D, &d_grid))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[2], mol_mix_frac, (size_t)M * D, &d_mmf))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[3], t_calc, (size_t)L * D, &d_t))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[4], p_calc, (size_t)L * D, &d_p))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[5], q_ratio, (size_t)L * D, &d_q))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[6], out, (size_t)L * nw * D, &d_out))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // h is a local buffer
+    HIPCHK(ctx->misc.reserve((size_t)L * 5 * N * D));
+    LblParams p;
+    memset(&p, 0, sizeof p);
+    const double *dl = (const double *)d_lines;
+    p.wn_grid = (const double *)d_grid;
+    p.nu = dl; p.sw = dl + N; p.e_lower = dl + 2 * (size_t)N; p.stim_ref = dl + 3 * (size_t)N; p.bparams = dl + 4 * (size_t)N;
+    p.mmf = (const double *)d_mmf; p.t_calc = (const double *)d_t; p.p_calc = (const double *)d_p; p.q_ratio = (const double *)d_q;
+    p.store = ctx->misc.as<double>();
+    p.out = (double *)const_cast<void *>(d_out);
+    p.nw = nw; p.N = N; p.M = M; p.L = L; p.lineshape_id = lineshape_id;
+    p.t_ref = t_ref; p.p_ref = p_ref; p.iso_abundance = isotopic_abundance; p.iso_mass = isotopic_mass; p.s_floor = s_floor;
+    p.wn_calc_window = wn_calc_window; p.wn_approx_window = wn_approx_window;
+    p.max_shift = dmax * pmax * 1.0000001 + 1e-12;
+    hipLaunchKernelGGL(k_lbl_line_params, dim3(nblk((size_t)L * N, 256)), dim3(256), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_lbl_accumulate, dim3(nblk(nw, 256), (unsigned)L), dim3(256), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, p.out, (size_t)L * nw * D, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> hst;
+    if (store) {
+        hst.resize((size_t)L * 5 * N);
+        HIPCHK(hipMemcpyAsync(hst.data(), p.store, hst.size() * D, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (store)   // store[L][4][N] in the caller's line order
+        for (int l = 0; l < L; ++l)
+            for (int r = 0; r < 4; ++r)
+                for (int i = 0; i < N; ++i) store[((size_t)l * 4 + r) * N + ord[i]] = hst[((size_t)l * 5 + r) * N + i];
     return ANSFM_OK;
 }
 

@@ -1,0 +1,154 @@
+// ansfm_lbl_kernels.hip.h -- runtime line-by-line absorption on gfx950.
+//
+// Restates LineData_0.add_line_set_monochromatic_absorption (LineData_0.py:280-357) = line_strength :206,
+// doppler_width :144, lorentz_width :159, line_shift :189, add_line_set_monochromatic_spectrum :229-277, with the
+// line shapes lineshape/voigt (scipy.special.voigt_profile), lorentz and gaussian.
+//
+// The reference loops lines (outer) x grid points (inner) and accumulates into out[j]: a scatter with a
+// race on j if parallelised over lines.  Here one thread owns one (layer, grid point) and gathers the lines
+// whose +-wn_approx_window contains it, in ascending line order (the order the reference adds them in);
+// a block of 256 consecutive grid points walks one shared line range, so line parameters are broadcast loads.
+// Faddeeva function: |z| >= 8 -> 12-term Laplace continued fraction, else trapezoid/midpoint rule (h = 1/2)
+// with pole correction -- measured <= 6e-14 relative against scipy.special.wofz for y in [1e-12, 1e2].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ansfm {
+
+__device__ __forceinline__ double lbl_rew(double x, double y)
+{
+    const double PI = 3.141592653589793;
+    x = fabs(x);
+    if (x * x + y * y >= 64.0) {
+        double rr = 0.0, ri = 0.0;
+#pragma unroll
+        for (int k = 12; k > 0; --k) {
+            const double dr = x - rr, di = y - ri, den = dr * dr + di * di;
+            rr = (k * 0.5) * dr / den;
+            ri = -(k * 0.5) * di / den;
+        }
+        const double dr = x - rr, di = y - ri;
+        return di / (1.7724538509055159 * (dr * dr + di * di));
+    }
+    const double h = 0.5;
+    const double fr = x / h - floor(x / h);
+    const bool use_mid = (fr < 0.25) || (fr > 0.75);
+    const double shift = use_mid ? 0.5 : 0.0;
+    double s = 0.0;
+    for (int k = -14; k <= 13; ++k) {
+        const double t = (k + shift) * h;
+        s += exp(-t * t) * y / ((x - t) * (x - t) + y * y);
+    }
+    s *= h / PI;
+    if (y < PI / h) {
+        const double er = exp(-(x * x - y * y)), ang = -2.0 * x * y;
+        double sa, ca, s2, c2;
+        sincos(ang, &sa, &ca);
+        const double nr = 2.0 * er * ca, ni = 2.0 * er * sa;
+        const double em = exp(2.0 * PI * y / h);
+        sincos(-2.0 * PI * x / h, &s2, &c2);
+        const double sg = use_mid ? -1.0 : 1.0;
+        const double dr = 1.0 - sg * em * c2, di = -sg * em * s2;
+        s += (nr * dr + ni * di) / (dr * dr + di * di);
+    }
+    return s;
+}
+
+__device__ __forceinline__ double lbl_voigt_profile(double x, double sigma, double gamma)
+{   // scipy.special.voigt_profile
+    const double PI = 3.141592653589793;
+    if (sigma == 0.0) {
+        if (gamma == 0.0) return (x == 0.0) ? __builtin_inf() : 0.0;
+        return gamma / PI / (x * x + gamma * gamma);
+    }
+    if (gamma == 0.0) return 1.0 / sqrt(2.0 * PI) / sigma * exp(-(x / sigma) * (x / sigma) / 2.0);
+    const double isq2 = 0.70710678118654752440;
+    return lbl_rew(x / sigma * isq2, gamma / sigma * isq2) / sigma / sqrt(2.0 * PI);
+}
+
+// ids = SpectroscopicLineProfileEnum: 0 VOIGT, 4 LORENTZ, 12 DOPPLER
+__device__ __forceinline__ double lbl_lineshape(int id, double dwn, double alpha_d, double gamma_l)
+{
+    const double PI = 3.141592653589793;
+    if (id == 4) return gamma_l / (PI * (gamma_l * gamma_l + dwn * dwn));
+    if (id == 12) return sqrt(log(2.0) / PI) / alpha_d * exp(-(dwn * dwn * log(2.0)) / (alpha_d * alpha_d));
+    return lbl_voigt_profile(dwn, alpha_d / sqrt(2.0 * log(2.0)), gamma_l);
+}
+
+struct LblParams {
+    const double *wn_grid;  // [nw] ascending
+    const double *nu, *sw, *e_lower, *stim_ref;  // [N], nu ascending
+    const double *bparams;  // [3M][N]
+    const double *mmf;      // [M]
+    const double *t_calc, *p_calc, *q_ratio;  // [L]
+    double *store;          // [L][5][N]: strength, alpha_d, gamma_l, shift, line_approx_const
+    double *out;            // [L][nw]  (added to)
+    int nw, N, M, L, lineshape_id;
+    double t_ref, p_ref, iso_abundance, iso_mass, s_floor, wn_calc_window, wn_approx_window, max_shift;
+};
+
+// per (layer, line): store[0..3] exactly as the reference fills them (:306-341) + the wing constant (:261)
+__global__ void k_lbl_line_params(LblParams p)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)p.L * p.N) return;
+    const int i = (int)(idx % p.N), l = (int)(idx / p.N);
+    const double c_light_cgs = 2.99792458E10, h_planck_cgs = 6.62607015E-27, k_boltzmann_cgs = 1.380649E-16,
+                 N_avogadro = 6.02214129E+23;
+    const double c2_cgs = c_light_cgs * h_planck_cgs / k_boltzmann_cgs;
+    const double t_calc = p.t_calc[l], p_calc = p.p_calc[l];
+    const double boltz = c2_cgs * (t_calc - p.t_ref) / (t_calc * p.t_ref);
+    const double dconst = (1.0 / c_light_cgs) * sqrt(2 * log(2.0) * N_avogadro * k_boltzmann_cgs);
+    const double t_ratio = p.t_ref / t_calc, p_ratio = p_calc / p.p_ref;
+    const double nu = p.nu[i];
+    const double strength = p.sw[i] * ((1 - exp(-c2_cgs * nu / t_calc)) / p.stim_ref[i]) * exp(boltz * p.e_lower[i]) * p.q_ratio[l];
+    const double alpha_d = dconst * nu * sqrt(t_calc / p.iso_mass);
+    double g = 0, sh = 0;
+    for (int j = 0; j < p.M; ++j) {
+        g += (pow(t_ratio, p.bparams[(size_t)(3 * j + 1) * p.N + i])) * p.bparams[(size_t)(3 * j) * p.N + i] * p.mmf[j] * p_ratio;
+        sh += (p_ratio * p.bparams[(size_t)(3 * j + 2) * p.N + i]) * p.mmf[j];
+    }
+    double *st = p.store + (size_t)l * 5 * p.N;
+    st[i] = strength;
+    st[p.N + i] = alpha_d;
+    st[2 * (size_t)p.N + i] = g;
+    st[3 * (size_t)p.N + i] = sh;
+    st[4 * (size_t)p.N + i] = lbl_lineshape(p.lineshape_id, p.wn_calc_window, alpha_d, g);
+}
+
+__global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
+{
+    const int l = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int jc = j < p.nw ? j : p.nw - 1;
+    const double wn = p.wn_grid[jc];
+    // line range shared by the block: every line that can reach any of its grid points
+    const int j0 = blockIdx.x * blockDim.x;
+    const int j1 = min(j0 + (int)blockDim.x - 1, p.nw - 1);
+    const double lo_wn = p.wn_grid[j0] - p.wn_approx_window - p.max_shift;
+    const double hi_wn = p.wn_grid[j1] + p.wn_approx_window + p.max_shift;
+    int a = 0, b = p.N;
+    while (a < b) { int mid = (a + b) >> 1; if (p.nu[mid] < lo_wn) a = mid + 1; else b = mid; }
+    const int ilo = a;
+    b = p.N;
+    while (a < b) { int mid = (a + b) >> 1; if (p.nu[mid] <= hi_wn) a = mid + 1; else b = mid; }
+    const int ihi = a;
+    const double *st = p.store + (size_t)l * 5 * p.N;
+    const double cmin = -1 * p.wn_calc_window, cmax = p.wn_calc_window;
+    const double amin = -1 * p.wn_approx_window, amax = p.wn_approx_window;
+    double acc = (j < p.nw) ? p.out[(size_t)l * p.nw + j] : 0.0;
+    for (int i = ilo; i < ihi; ++i) {
+        const double strength = st[i];
+        if (strength < p.s_floor) continue;                                     // :258
+        const double wn_delta = wn - (p.nu[i] + st[3 * (size_t)p.N + i]);       // :264
+        if (wn_delta >= amax || wn_delta < amin) continue;                      // :266-269
+        if (cmin <= wn_delta && wn_delta < cmax)
+            acc += p.iso_abundance * strength * lbl_lineshape(p.lineshape_id, wn_delta, st[p.N + i], st[2 * (size_t)p.N + i]);
+        else
+            acc += p.iso_abundance * strength * st[4 * (size_t)p.N + i] * (cmax * cmax) / (wn_delta * wn_delta);
+    }
+    if (j < p.nw) p.out[(size_t)l * p.nw + j] = acc;
+}
+
+}  // namespace ansfm

@@ -243,6 +243,29 @@ class AnsfmEngine:
         self._check(rc, "scloud11wave_core")
         return rad
 
+    def add_line_set_monochromatic_absorption(self, wn_grid, lineshape_id, t_calc, t_ref, p_calc, p_ref, q_ratio,
+                                              isotopic_abundance, isotopic_mass, mol_mix_frac, broadening_params, nu, sw,
+                                              e_lower, stimulated_emission_at_t_ref, out, store=None, s_floor=0.0,
+                                              wn_calc_window=25.0, wn_approx_window=75.0):
+        """LineData_0.add_line_set_monochromatic_absorption (:280).  Scalars t_calc/p_calc/q_ratio = the reference
+        call (out (nw,), store (4,N)); 1-D arrays of length L = batched over (T,p) points (out (L,nw), store (L,4,N)).
+        `out` (float64, C-contiguous) is added to in place and returned."""
+        wn_grid = _np(wn_grid); mmf = _np(mol_mix_frac); bp = _np(broadening_params)
+        t = _np(np.atleast_1d(t_calc)); p = _np(np.atleast_1d(p_calc)); q = _np(np.atleast_1d(q_ratio))
+        L = t.shape[0]
+        nu = _np(nu); N = nu.shape[0]; M = mmf.shape[0]
+        if out.dtype != np.float64 or not out.flags.c_contiguous or out.size != L * wn_grid.shape[0]:
+            raise ValueError("out must be a C-contiguous float64 array of shape (nw,) or (L,nw)")
+        if store is not None and (store.dtype != np.float64 or not store.flags.c_contiguous or store.size != L * 4 * N):
+            raise ValueError("store must be a C-contiguous float64 array of shape (4,N) or (L,4,N)")
+        rc = self._lib.ansfm_add_line_set_monochromatic_absorption(
+            self._ctx, wn_grid.shape[0], _ptr(wn_grid), int(lineshape_id), L, _ptr(t), float(t_ref), _ptr(p), float(p_ref),
+            _ptr(q), float(isotopic_abundance), float(isotopic_mass), M, _ptr(mmf), N, _ptr(bp), _ptr(nu), _ptr(_np(sw)),
+            _ptr(_np(e_lower)), _ptr(_np(stimulated_emission_at_t_ref)), _ptr(out), _ptr(store), float(s_floor),
+            float(wn_calc_window), float(wn_approx_window))
+        self._check(rc, "add_line_set_monochromatic_absorption")
+        return out
+
     def get_taugas(self, L, model=0):
         W, G = self.dims[0], self.dims[1]
         out = np.empty((W, G, L))

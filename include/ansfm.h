@@ -193,6 +193,21 @@ int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const
                             const double *taus, const double *tauray, const double *omegas_s,
                             int nphi, int iray, int imie, const double *lfrac, double *rad);
 
+/* ---- runtime line-by-line (ILBL = LINE_BY_LINE_RUNTIME) -------------------------------------------
+ * LineData_0.add_line_set_monochromatic_absorption (LineData_0.py:280-357), batched over L (T,p) points
+ * (L = 1 is the reference's signature).  lineshape_id = SpectroscopicLineProfileEnum value: 0 VOIGT
+ * (scipy.special.voigt_profile), 4 LORENTZ, 12 DOPPLER; the rest -> ANSFM_ERR_UNSUPPORTED (the reference's
+ * enum map raises NotImplementedError for them too).
+ *   wn_grid[nw] ascending; t_calc/p_calc/q_ratio[L]; mol_mix_frac[M]; broadening_params[3M][N]
+ *   (gamma, n, delta per broadener); nu/sw/e_lower/stim_ref[N];
+ *   out[L][nw] is ADDED to (like the reference); store[L][4][N] (strength, alpha_d, gamma_l, shift) or NULL. */
+int ansfm_add_line_set_monochromatic_absorption(
+    ansfm_ctx *ctx, int nw, const double *wn_grid, int lineshape_id, int L, const double *t_calc, double t_ref,
+    const double *p_calc, double p_ref, const double *q_ratio, double isotopic_abundance,
+    double isotopic_mass, int M, const double *mol_mix_frac, int N, const double *broadening_params,
+    const double *nu, const double *sw, const double *e_lower, const double *stim_ref, double *out,
+    double *store, double s_floor, double wn_calc_window, double wn_approx_window);
+
 /* Vertical gas opacity of the last cirsrad call's first model, TAUGAS[W][G][L]
  * (what CIRSrad leaves in LayerX.TAUGAS, ForwardModel_0.py:3925) -- host pointer out. */
 int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS);

@@ -17,7 +17,7 @@ _d = np.float64
 
 def build(force=False):
     so = os.path.join(_HERE, "libansfm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("ansfm_oracle.c", "ansfm_oracle_ms.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ansfm_oracle.c", "ansfm_oracle_ms.c", "ansfm_oracle_lbl.c", "Makefile")]
     if force or (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -213,3 +213,38 @@ def calc_klbl(K, PRESS, TEMP, press, temp, grad=False):
     k = np.zeros((W, L, S)); dk = np.zeros((W, L, S)) if grad else None
     lib().orc_calc_klbl(W, NP, NTa, S, _p(K), _p(PRESS), _p(TEMP), temp2d, L, _p(press), _p(temp), _p(k), _p(dk))
     return (k, dk) if grad else k
+
+
+LINESHAPE_VOIGT, LINESHAPE_LORENTZ, LINESHAPE_DOPPLER = 0, 4, 12      # SpectroscopicLineProfileEnum values
+
+
+def rew(x, y):
+    """Re wofz(x + i y) (the oracle's own Faddeeva restatement)."""
+    f = lib().orc_rew; f.restype = C.c_double
+    x, y = np.broadcast_arrays(np.asarray(x, float), np.asarray(y, float))
+    return np.array([f(C.c_double(a), C.c_double(b)) for a, b in zip(x.ravel(), y.ravel())]).reshape(x.shape)
+
+
+def voigt_profile(x, sigma, gamma):
+    f = lib().orc_voigt_profile; f.restype = C.c_double
+    x, sigma, gamma = np.broadcast_arrays(np.asarray(x, float), np.asarray(sigma, float), np.asarray(gamma, float))
+    return np.array([f(C.c_double(a), C.c_double(b), C.c_double(c))
+                     for a, b, c in zip(x.ravel(), sigma.ravel(), gamma.ravel())]).reshape(x.shape)
+
+
+def add_line_set_monochromatic_absorption(wn_grid, lineshape_id, t_calc, t_ref, p_calc, p_ref, q_ratio,
+                                          isotopic_abundance, isotopic_mass, mol_mix_frac, broadening_params, nu, sw,
+                                          e_lower, stimulated_emission_at_t_ref, out, store=None, s_floor=0.0,
+                                          wn_calc_window=25.0, wn_approx_window=75.0):
+    """LineData_0.add_line_set_monochromatic_absorption (:280); adds into `out` (float64, contiguous)."""
+    wn_grid = _c(wn_grid); mmf = _c(mol_mix_frac); bp = _c(broadening_params); nu = _c(nu); sw = _c(sw)
+    el = _c(e_lower); sr = _c(stimulated_emission_at_t_ref)
+    assert out.dtype == np.float64 and out.flags.c_contiguous
+    N = nu.shape[0]; M = mmf.shape[0]
+    assert bp.shape == (3 * M, N)
+    lib().orc_add_line_set_monochromatic_absorption(
+        wn_grid.shape[0], _p(wn_grid), int(lineshape_id), C.c_double(t_calc), C.c_double(t_ref), C.c_double(p_calc),
+        C.c_double(p_ref), C.c_double(q_ratio), C.c_double(isotopic_abundance), C.c_double(isotopic_mass), M, _p(mmf), N,
+        _p(bp), _p(nu), _p(sw), _p(el), _p(sr), _p(out), _p(store), C.c_double(s_floor), C.c_double(wn_calc_window),
+        C.c_double(wn_approx_window))
+    return out

@@ -289,3 +289,37 @@ def test_cirsrad_lbl_tables_vs_oracle(eng, oracle):
     ref_d = rd[:, 0]                                                       # (W,NPAR,Li)
     scale = np.abs(ref_d).max(axis=(0, 2), keepdims=True) + 1e-300
     assert np.max(np.abs(dspec[:, :, :, 0] - ref_d) / scale) < 1e-10
+
+
+def test_lbl_runtime_golden(eng, golden_dir):
+    """Runtime line-by-line absorption vs the reference's add_line_set_monochromatic_absorption (golden)."""
+    from test_lbl_oracle import lbl_case
+    z = _load(golden_dir, "lbl_lines")
+    N = z["nu"].size
+    for name in z["names"]:
+        a = lbl_case(z, str(name))
+        out = np.zeros(z["wn_grid"].size); store = np.empty((4, N))
+        eng.add_line_set_monochromatic_absorption(
+            z["wn_grid"], a["lineshape_id"], a["t_calc"], float(z["t_ref"]), a["p_calc"], float(z["p_ref"]), a["q_ratio"],
+            float(z["isotopic_abundance"]), float(z["isotopic_mass"]), z["mol_mix_frac"], z["broadening_params"], z["nu"],
+            z["sw"], z["e_lower"], z["stim_ref"], out, store, a["s_floor"], a["wn_calc_window"], a["wn_approx_window"])
+        np.testing.assert_allclose(store, z[str(name) + "_store"], rtol=1e-12, err_msg=str(name))
+        ref = z[str(name) + "_k"]
+        np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-300, err_msg=str(name))
+
+
+def test_lbl_runtime_batched_unsorted_vs_oracle(eng, oracle, golden_dir):
+    """L = 3 (T,p) points in one call, lines handed over in random order, accumulation into a non-zero `out`."""
+    z = _load(golden_dir, "lbl_lines")
+    rng = np.random.default_rng(8)
+    perm = rng.permutation(z["nu"].size)
+    nu, sw, el, sr, bp = z["nu"][perm], z["sw"][perm], z["e_lower"][perm], z["stim_ref"][perm], z["broadening_params"][:, perm]
+    wn = z["wn_grid"][::2].copy()
+    t = np.array([160.0, 230.0, 300.0]); p = np.array([1e-3, 0.2, 2.0]); q = np.array([1.9, 1.2, 0.97])
+    out = rng.uniform(0, 1e-22, size=(3, wn.size)); ref = out.copy()
+    eng.add_line_set_monochromatic_absorption(wn, 0, t, 296.0, p, 1.0, q, 0.9, 28.0, z["mol_mix_frac"], bp, nu, sw, el, sr, out)
+    srt = np.argsort(nu, kind="stable")
+    for l in range(3):
+        oracle.add_line_set_monochromatic_absorption(wn, 0, t[l], 296.0, p[l], 1.0, q[l], 0.9, 28.0, z["mol_mix_frac"],
+                                                     bp[:, srt], nu[srt], sw[srt], el[srt], sr[srt], ref[l])
+    np.testing.assert_allclose(out, ref, rtol=1e-10)
