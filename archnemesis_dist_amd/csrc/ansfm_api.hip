@@ -3,6 +3,7 @@
 #include "ansfm_kernels.hip.h"
 #include "ansfm_ms_kernels.hip.h"
 #include "ansfm_lbl_kernels.hip.h"
+#include "ansfm_layer_kernels.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -1118,6 +1119,65 @@ int ansfm_add_line_set_monochromatic_absorption(
         for (int l = 0; l < L; ++l)
             for (int r = 0; r < 4; ++r)
                 for (int i = 0; i < N; ++i) store[((size_t)l * 4 + r) * N + ord[i]] = hst[((size_t)l * 5 + r) * N + i];
+    return ANSFM_OK;
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* layering                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, const double *H, const double *P,
+                        const double *T, int NVMR, const double *VMR, int NDUST, const double *DUST, const double *PARAH2,
+                        int NLAY, const double *BASEH, double LAYANG, int LAYINT, double LAYHT, int NINT,
+                        const int32_t *DUST_UNITS, const double *XMOLWT, double *HEIGHT, double *PRESS, double *TEMP,
+                        double *TOTAM, double *AMOUNT, double *PP, double *CONT, double *FRAC, double *DELH, double *BASET,
+                        double *LAYSF)
+{
+    CHECK_CTX(ctx);
+    if (n_models <= 0 || NPRO < 2 || NVMR <= 0 || NDUST < 0 || NLAY <= 0 || !H || !P || !T || !VMR || !BASEH || !HEIGHT ||
+        !PRESS || !TEMP || !TOTAM || !AMOUNT || !PP || !FRAC || !DELH || !BASET || !LAYSF || (NDUST > 0 && (!DUST || !CONT)) ||
+        (LAYINT != 0 && LAYINT != 1))
+        FAIL(ANSFM_ERR_INVALID, "layer_average: bad argument");
+    if (LAYINT == 1 && ((NINT % 2) == 0 || NINT < 3 || NINT > kLayMaxNint))
+        FAIL(ANSFM_ERR_UNSUPPORTED, "layer_average: NINT must be odd and in [3,256] (scipy's even-N Simpson correction not built)");
+    if (5 + 2 * NVMR + NDUST > 160) FAIL(ANSFM_ERR_UNSUPPORTED, "layer_average: 5 + 2*NVMR + NDUST <= 160");
+    if (DUST_UNITS && !XMOLWT)
+        for (int j = 0; j < NDUST; ++j)
+            if (DUST_UNITS[j] == -1) FAIL(ANSFM_ERR_INVALID, "if DUST_UNITS=-1 (particles per gram of atm), the XMOLWT must be defined");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t D = sizeof(double), n = n_models;
+    const void *d[10];
+    int i = 0, rc;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(H, n * NPRO * D); UP(P, n * NPRO * D); UP(T, n * NPRO * D);              // 0 1 2
+    UP(VMR, n * NPRO * NVMR * D);                                               // 3
+    UP(DUST, n * NPRO * NDUST * D);                                             // 4
+    UP(PARAH2, n * NPRO * D);                                                   // 5
+    UP(XMOLWT, n * NPRO * D);                                                   // 6
+    UP(BASEH, n * NLAY * D);                                                    // 7
+    UP(DUST_UNITS, (size_t)NDUST * sizeof(int32_t));                            // 8
+#undef UP
+    const size_t nl = n * NLAY;
+    const size_t tot = nl * (8 + 2 * (size_t)NVMR + NDUST);
+    HIPCHK(ctx->tmp_out.reserve(tot * D));
+    double *o = ctx->tmp_out.as<double>();
+    LayerAvgParams p;
+    memset(&p, 0, sizeof p);
+    p.H = (const double *)d[0]; p.P = (const double *)d[1]; p.T = (const double *)d[2]; p.VMR = (const double *)d[3];
+    p.DUST = (const double *)d[4]; p.PARAH2 = (const double *)d[5]; p.XMOLWT = (const double *)d[6];
+    p.BASEH = (const double *)d[7]; p.dust_units = (const int32_t *)d[8];
+    p.HEIGHT = o; p.PRESS = o + nl; p.TEMP = o + 2 * nl; p.TOTAM = o + 3 * nl; p.FRAC = o + 4 * nl; p.DELH = o + 5 * nl;
+    p.BASET = o + 6 * nl; p.LAYSF = o + 7 * nl; p.AMOUNT = o + 8 * nl; p.PP = p.AMOUNT + nl * NVMR; p.CONT = p.PP + nl * NVMR;
+    p.RADIUS = RADIUS; p.LAYANG = LAYANG; p.LAYHT = LAYHT;
+    p.n_models = n_models; p.NPRO = NPRO; p.NVMR = NVMR; p.NDUST = NDUST; p.NLAY = NLAY; p.LAYINT = LAYINT; p.NINT = NINT;
+    hipLaunchKernelGGL(k_layer_average, dim3((unsigned)NLAY, (unsigned)n_models), dim3(128), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    double *outs[8] = {HEIGHT, PRESS, TEMP, TOTAM, FRAC, DELH, BASET, LAYSF};
+    for (int k = 0; k < 8; ++k) HIPCHK(hipMemcpyAsync(outs[k], o + k * nl, nl * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(AMOUNT, p.AMOUNT, nl * NVMR * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(PP, p.PP, nl * NVMR * D, hipMemcpyDeviceToHost, ctx->stream));
+    if (NDUST > 0) HIPCHK(hipMemcpyAsync(CONT, p.CONT, nl * NDUST * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return ANSFM_OK;
 }
 

@@ -1,0 +1,153 @@
+// ansfm_layer_kernels.hip.h -- Layer_0.layer_average on gfx950, batched over atmospheric states.
+//
+// Restates archnemesis/Layer_0.py:755-1030 (MID_PATH and the Curtis-Godson ABSORBER_WEIGHTED_AVERAGE branch
+// :949-1010): slant-path sub-division of every layer into NINT points, linear interpolation (with
+// extrapolation) of the profile in height, n = p/(k_B T), Simpson integrals of n, h n, p n, T n, f n, vmr n,
+// vmr p n and dust, then the scaling back to vertical columns (:1013-1023).
+// One workgroup per (state, layer): phase 1 = one thread per sub-point (geometry, bracket, p, T, n), phase 2 =
+// one thread per integrated quantity (scipy's unequal-spacing Simpson sum, sequential like np.sum's order to
+// rounding).  A numerical Jacobian re-derives the layers for every perturbed state (jacobian_nemesis ->
+// nemesisfm -> calc_path, ForwardModel_0.py:516); this kernel does all of them in one launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ansfm {
+
+constexpr int kLayMaxNint = 256;
+
+struct LayerAvgParams {
+    const double *H, *P, *T;        // [n][NPRO]
+    const double *VMR;              // [n][NPRO][NVMR]
+    const double *DUST;             // [n][NPRO][NDUST] or nullptr
+    const double *PARAH2;           // [n][NPRO] or nullptr (zeros)
+    const double *XMOLWT;           // [n][NPRO] kg/mol or nullptr
+    const double *BASEH;            // [n][NLAY]
+    const int32_t *dust_units;      // [NDUST] or nullptr
+    double *HEIGHT, *PRESS, *TEMP, *TOTAM, *FRAC, *DELH, *BASET, *LAYSF;   // [n][NLAY]
+    double *AMOUNT, *PP;            // [n][NLAY][NVMR]
+    double *CONT;                   // [n][NLAY][NDUST]
+    double RADIUS, LAYANG, LAYHT;
+    int n_models, NPRO, NVMR, NDUST, NLAY, LAYINT, NINT;
+};
+
+__device__ __forceinline__ int lay_bracket(const double *x, int n, double xn)
+{   // scipy interp1d linear: idx = clip(searchsorted(x, xn, 'left'), 1, n-1)
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (x[mid] < xn) lo = mid + 1; else hi = mid; }
+    return lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+}
+__device__ __forceinline__ double lay_interp(const double *x, const double *y, int stride, int idx, double xn)
+{
+    const double ylo = y[(size_t)(idx - 1) * stride], yhi = y[(size_t)idx * stride];
+    const double slope = (yhi - ylo) / (x[idx] - x[idx - 1]);
+    return slope * (xn - x[idx - 1]) + ylo;
+}
+
+__global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
+{
+    __shared__ double S[kLayMaxNint], hh[kLayMaxNint], pp[kLayMaxNint], duds[kLayMaxNint], mw[kLayMaxNint];
+    __shared__ int idx[kLayMaxNint];
+    __shared__ double res[160];
+    const double k_B = 1.38065e-23, AVOGAD = 6.02214076e23, PI = 3.141592653589793;
+    const int I = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+    const int NPRO = p.NPRO, V = p.NVMR, D = p.NDUST, NL = p.NLAY;
+    const double *H = p.H + (size_t)m * NPRO, *P = p.P + (size_t)m * NPRO, *T = p.T + (size_t)m * NPRO;
+    const double *VMR = p.VMR + (size_t)m * NPRO * V;
+    const double *DUST = p.DUST ? p.DUST + (size_t)m * NPRO * D : nullptr;
+    const double *PH2 = p.PARAH2 ? p.PARAH2 + (size_t)m * NPRO : nullptr;
+    const double *XM = (p.dust_units && p.XMOLWT) ? p.XMOLWT + (size_t)m * NPRO : nullptr;
+    const double *BASEH = p.BASEH + (size_t)m * NL;
+    const double sn = sin(p.LAYANG * PI / 180), cs = cos(p.LAYANG * PI / 180);
+    const double z0 = p.RADIUS + p.LAYHT, zmax = p.RADIUS + H[NPRO - 1];
+    const double SMAX = sqrt(zmax * zmax - (z0 * sn) * (z0 * sn)) - z0 * cs;
+    auto bases = [&](int i) { const double r = p.RADIUS + BASEH[i]; return sqrt(r * r - (z0 * sn) * (z0 * sn)) - z0 * cs; };
+    const double S0 = bases(I), S1 = (I < NL - 1) ? bases(I + 1) : SMAX;
+    const double DELS = S1 - S0;
+    const double DELH = (I < NL - 1) ? BASEH[I + 1] - BASEH[I] : H[NPRO - 1] - BASEH[NL - 1];
+    const double LAYSF = DELS / DELH;
+    const int npts = (p.LAYINT == 0) ? 1 : p.NINT;
+    // ---- phase 1: sub-points -------------------------------------------------------------------------
+    for (int k = tid; k < npts; k += blockDim.x) {
+        double s;
+        if (p.LAYINT == 0) s = (I < NL - 1) ? (bases(I + 1) + S0) / 2 : (SMAX + S0) / 2;      // :899-901
+        else { const double step = (S1 - S0) / (p.NINT - 1); s = (k == p.NINT - 1) ? S1 : k * step + S0; }   // np.linspace
+        const double h = sqrt(s * s + z0 * z0 + 2 * s * z0 * cs) - p.RADIUS;
+        const int ix = lay_bracket(H, NPRO, h);
+        const double pk = lay_interp(H, P, 1, ix, h), tk = lay_interp(H, T, 1, ix, h);
+        S[k] = s; hh[k] = h; idx[k] = ix; pp[k] = pk;
+        duds[k] = pk / (k_B * tk);
+        mw[k] = XM ? lay_interp(H, XM, 1, ix, h) * 1000. : 0.0;       // XMOLWT *= 1000 :877
+    }
+    __syncthreads();
+    // ---- phase 2: one thread per integrated quantity ----------------------------------------------------
+    const int NQ = 5 + 2 * V + D;
+    for (int q = tid; q < NQ; q += blockDim.x) {
+        auto yval = [&](int k) -> double {
+            const double h = hh[k];
+            const int ix = idx[k];
+            if (q == 0) return duds[k];
+            if (q == 1) return h * duds[k];
+            if (q == 2) return pp[k] * duds[k];
+            if (q == 3) return lay_interp(H, T, 1, ix, h) * duds[k];
+            if (q == 4) return (PH2 ? lay_interp(H, PH2, 1, ix, h) : 0.0) * duds[k];
+            if (q < 5 + V) return lay_interp(H, VMR + (q - 5), V, ix, h) * duds[k];
+            if (q < 5 + 2 * V) return (lay_interp(H, VMR + (q - 5 - V), V, ix, h) * pp[k]) * duds[k];
+            const int J = q - 5 - 2 * V;
+            const double dd = lay_interp(H, DUST + J, D, ix, h);
+            return (p.dust_units && p.dust_units[J] == -1) ? dd * duds[k] * mw[k] / AVOGAD : dd;
+        };
+        double r = 0.0;
+        if (p.LAYINT == 0) {
+            r = yval(0);   // point value; combined below
+        } else {
+            for (int i = 0; i + 2 < npts; i += 2) {   // scipy _basic_simpson, unequal-spacing form
+                const double h0 = S[i + 1] - S[i], h1 = S[i + 2] - S[i + 1];
+                const double hsum = h0 + h1, hprod = h0 * h1;
+                const double h0divh1 = (h1 != 0) ? h0 / h1 : 0.0;
+                const double inv = (h0divh1 != 0) ? 1.0 / h0divh1 : 0.0;
+                const double hq = (hprod != 0) ? hsum / hprod : 0.0;
+                r += hsum / 6.0 * (yval(i) * (2.0 - inv) + yval(i + 1) * (hsum * hq) + yval(i + 2) * (2.0 - h0divh1));
+            }
+        }
+        res[q] = r;
+    }
+    __syncthreads();
+    // ---- combine -----------------------------------------------------------------------------------------
+    const size_t o = (size_t)m * NL + I;
+    if (p.LAYINT == 0) {
+        const double DUDS = res[0], TOT = DUDS * DELS;
+        const double hmid = hh[0], PR = pp[0];
+        const int ix = idx[0];
+        if (tid == 0) {
+            p.HEIGHT[o] = hmid; p.PRESS[o] = PR; p.TEMP[o] = lay_interp(H, T, 1, ix, hmid);
+            p.FRAC[o] = PH2 ? lay_interp(H, PH2, 1, ix, hmid) : 0.0;
+            p.TOTAM[o] = TOT / LAYSF;
+            p.DELH[o] = DELH; p.LAYSF[o] = LAYSF; p.BASET[o] = lay_interp(H, T, 1, lay_bracket(H, NPRO, BASEH[I]), BASEH[I]);
+        }
+        for (int J = tid; J < V; J += blockDim.x) {
+            const double a = lay_interp(H, VMR + J, V, ix, hmid);
+            p.PP[o * V + J] = a * PR;
+            p.AMOUNT[o * V + J] = (a * TOT) * pow(LAYSF, -1.0);
+        }
+        for (int J = tid; J < D; J += blockDim.x) {
+            const double dd = lay_interp(H, DUST + J, D, ix, hmid);
+            const double c = (p.dust_units && p.dust_units[J] == -1) ? dd * TOT * mw[0] / AVOGAD : dd * DELS;
+            p.CONT[o * D + J] = c * pow(LAYSF, -1.0);
+        }
+    } else {
+        const double TOT = res[0];
+        if (tid == 0) {
+            p.TOTAM[o] = TOT / LAYSF;
+            p.HEIGHT[o] = res[1] / TOT; p.PRESS[o] = res[2] / TOT; p.TEMP[o] = res[3] / TOT; p.FRAC[o] = res[4] / TOT;
+            p.DELH[o] = DELH; p.LAYSF[o] = LAYSF; p.BASET[o] = lay_interp(H, T, 1, lay_bracket(H, NPRO, BASEH[I]), BASEH[I]);
+        }
+        for (int J = tid; J < V; J += blockDim.x) {
+            p.AMOUNT[o * V + J] = res[5 + J] * pow(LAYSF, -1.0);
+            p.PP[o * V + J] = res[5 + V + J] / TOT;
+        }
+        for (int J = tid; J < D; J += blockDim.x) p.CONT[o * D + J] = res[5 + 2 * V + J] * pow(LAYSF, -1.0);
+    }
+}
+
+}  // namespace ansfm

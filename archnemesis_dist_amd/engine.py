@@ -266,6 +266,32 @@ class AnsfmEngine:
         self._check(rc, "add_line_set_monochromatic_absorption")
         return out
 
+    def layer_average(self, RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP=None, LAYANG=0.0, LAYINT=0, LAYHT=0.0,
+                      NINT=101, DUST_UNITS=None, XMOLWT=None):
+        """Layer_0.layer_average (:755), same argument order (ID and BASEP are unused there too).  A leading
+        state axis on H/P/T/VMR/DUST/PARAH2/BASEH batches the call.  Returns
+        HEIGHT,PRESS,TEMP,TOTAM,AMOUNT,PP,CONT,FRAC,DELH,BASET,LAYSF."""
+        H = _np(H); single = H.ndim == 1
+        H2 = np.atleast_2d(H); n, NPRO = H2.shape
+        P2 = _np(P).reshape(n, NPRO); T2 = _np(T).reshape(n, NPRO)
+        V2 = _np(VMR).reshape(n, NPRO, -1); NV = V2.shape[2]
+        D2 = None if DUST is None else _np(DUST).reshape(n, NPRO, -1)
+        ND = 0 if D2 is None else D2.shape[2]
+        PH = None if PARAH2 is None else _np(PARAH2).reshape(n, NPRO)
+        XM = None if XMOLWT is None else _np(np.broadcast_to(_np(XMOLWT).reshape(-1, NPRO), (n, NPRO)))
+        BH = _np(np.broadcast_to(_np(BASEH).reshape(-1, np.shape(BASEH)[-1]), (n, np.shape(BASEH)[-1]))); NL = BH.shape[1]
+        mk = lambda *shape: np.empty(shape)
+        HEIGHT, PRESS, TEMP, TOTAM, FRAC, DELH, BASET, LAYSF = (mk(n, NL) for _ in range(8))
+        AMOUNT, PPo, CONT = mk(n, NL, NV), mk(n, NL, NV), mk(n, NL, ND)
+        rc = self._lib.ansfm_layer_average(
+            self._ctx, n, float(RADIUS), NPRO, _ptr(H2), _ptr(P2), _ptr(T2), NV, _ptr(V2), ND, _ptr(D2), _ptr(PH), NL, _ptr(BH),
+            float(LAYANG), int(LAYINT), float(LAYHT), int(NINT), _ptr(_np(DUST_UNITS, np.int32)), _ptr(XM), _ptr(HEIGHT),
+            _ptr(PRESS), _ptr(TEMP), _ptr(TOTAM), _ptr(AMOUNT), _ptr(PPo), _ptr(CONT), _ptr(FRAC), _ptr(DELH), _ptr(BASET),
+            _ptr(LAYSF))
+        self._check(rc, "layer_average")
+        out = (HEIGHT, PRESS, TEMP, TOTAM, AMOUNT, PPo, CONT, FRAC, DELH, BASET, LAYSF)
+        return tuple(a[0] for a in out) if single else out
+
     def get_taugas(self, L, model=0):
         W, G = self.dims[0], self.dims[1]
         out = np.empty((W, G, L))

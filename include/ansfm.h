@@ -208,6 +208,21 @@ int ansfm_add_line_set_monochromatic_absorption(
     const double *nu, const double *sw, const double *e_lower, const double *stim_ref, double *out,
     double *store, double s_floor, double wn_calc_window, double wn_approx_window);
 
+/* ---- layering ---------------------------------------------------------------------------------------
+ * Layer_0.layer_average (Layer_0.py:755-1030), batched over n_models atmospheric states (the states of a
+ * numerical Jacobian): LAYINT 0 = MID_PATH, 1 = ABSORBER_WEIGHTED_AVERAGE (Curtis-Godson, :949-1010).
+ *   H,P,T[n][NPRO]; VMR[n][NPRO][NVMR]; DUST[n][NPRO][NDUST] or NULL; PARAH2[n][NPRO] or NULL;
+ *   BASEH[n][NLAY] (layer_split output); DUST_UNITS[NDUST] (int32) / XMOLWT[n][NPRO] (kg/mol) or NULL
+ *   -> HEIGHT,PRESS,TEMP,TOTAM,FRAC,DELH,BASET,LAYSF [n][NLAY]; AMOUNT,PP [n][NLAY][NVMR]; CONT [n][NLAY][NDUST].
+ * NINT must be odd (scipy.integrate.simpson's even-N end correction is not built). */
+int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, const double *H,
+                        const double *P, const double *T, int NVMR, const double *VMR, int NDUST,
+                        const double *DUST, const double *PARAH2, int NLAY, const double *BASEH,
+                        double LAYANG, int LAYINT, double LAYHT, int NINT, const int32_t *DUST_UNITS,
+                        const double *XMOLWT, double *HEIGHT, double *PRESS, double *TEMP, double *TOTAM,
+                        double *AMOUNT, double *PP, double *CONT, double *FRAC, double *DELH,
+                        double *BASET, double *LAYSF);
+
 /* Vertical gas opacity of the last cirsrad call's first model, TAUGAS[W][G][L]
  * (what CIRSrad leaves in LayerX.TAUGAS, ForwardModel_0.py:3925) -- host pointer out. */
 int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS);

@@ -1,0 +1,148 @@
+/*
+ * ansfm_oracle_layer.c -- CPU restatement of Layer_0.layer_average (archnemesis/Layer_0.py:755-1030),
+ * both LAYINT schemes (MID_PATH = 0, ABSORBER_WEIGHTED_AVERAGE = 1: the Curtis-Godson branch :949-1010).
+ * TEST INFRASTRUCTURE ONLY.
+ *
+ * Third-party arithmetic on the path (scipy un-pinned by the reference; 1.15.3 in the build container):
+ *   scipy.interpolate.interp1d(kind='linear', fill_value='extrapolate')  (Layer_0.interp :645)
+ *       -> idx = clip(searchsorted(x, xnew), 1, n-1); slope*(xnew - x_lo) + y_lo
+ *   scipy.integrate.simpson(y, x=S) for an odd number of points (:969-1010)
+ *       -> scipy/integrate/_quadrature.py::_basic_simpson with the unequal-spacing weights
+ *   numpy.linspace (step*arange + start, last point forced to stop)
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#define ORC_API __attribute__((visibility("default")))
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+static double interp_lin(const double *x, const double *y, int n, double xn)
+{
+    int lo = 0, hi = n;                       /* searchsorted side='left' */
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (x[mid] < xn) lo = mid + 1; else hi = mid; }
+    int idx = lo;
+    if (idx < 1) idx = 1;
+    if (idx > n - 1) idx = n - 1;
+    double slope = (y[idx] - y[idx - 1]) / (x[idx] - x[idx - 1]);
+    return slope * (xn - x[idx - 1]) + y[idx - 1];
+}
+
+static double simpson_x(const double *y, const double *x, int n)
+{   /* n odd */
+    double res = 0.0;
+    for (int i = 0; i + 2 < n; i += 2) {
+        double h0 = x[i + 1] - x[i], h1 = x[i + 2] - x[i + 1];
+        double hsum = h0 + h1, hprod = h0 * h1;
+        double h0divh1 = (h1 != 0) ? h0 / h1 : 0.0;
+        double inv = (h0divh1 != 0) ? 1.0 / h0divh1 : 0.0;
+        double hq = (hprod != 0) ? hsum / hprod : 0.0;
+        res += hsum / 6.0 * (y[i] * (2.0 - inv) + y[i + 1] * (hsum * hq) + y[i + 2] * (2.0 - h0divh1));
+    }
+    return res;
+}
+
+/* Returns 0, or 5 when NINT is even (scipy then adds a Cartwright end correction, not restated). */
+ORC_API int orc_layer_average(
+    double RADIUS, int NPRO, const double *H, const double *P, const double *T, int NVMR, const double *VMR /*[NPRO][NVMR]*/,
+    int NDUST, const double *DUST /*[NPRO][NDUST] or NULL*/, const double *PARAH2 /*[NPRO] or NULL*/, int NLAY,
+    const double *BASEH, double LAYANG, int LAYINT, double LAYHT, int NINT, const int *DUST_UNITS /*[NDUST] or NULL*/,
+    const double *XMOLWT_kg /*[NPRO] or NULL*/, double *HEIGHT, double *PRESS, double *TEMP, double *TOTAM,
+    double *AMOUNT /*[NLAY][NVMR]*/, double *PP /*[NLAY][NVMR]*/, double *CONT /*[NLAY][NDUST]*/, double *FRAC, double *DELH,
+    double *BASET, double *LAYSF)
+{
+    const double k_B = 1.38065e-23, AVOGAD = 6.02214076e23;      /* Layer_0.py:828, :36 */
+    if (LAYINT == 1 && (NINT % 2) == 0) return 5;
+    const double sn = sin(LAYANG * M_PI / 180), cs = cos(LAYANG * M_PI / 180);
+    const double z0 = RADIUS + LAYHT, zmax = RADIUS + H[NPRO - 1];
+    const double SMAX = sqrt(zmax * zmax - (z0 * sn) * (z0 * sn)) - z0 * cs;
+    double *BASES = (double *)malloc(sizeof(double) * NLAY), *DELS = (double *)malloc(sizeof(double) * NLAY);
+    double *zero = (double *)calloc(NPRO, sizeof(double)), *molwt_g = (double *)calloc(NPRO, sizeof(double));
+    if (DUST_UNITS && XMOLWT_kg) for (int i = 0; i < NPRO; ++i) molwt_g[i] = XMOLWT_kg[i] * 1000.;
+    const double *parah2 = PARAH2 ? PARAH2 : zero;
+    for (int i = 0; i < NLAY; ++i) BASES[i] = sqrt((RADIUS + BASEH[i]) * (RADIUS + BASEH[i]) - (z0 * sn) * (z0 * sn)) - z0 * cs;
+    for (int i = 0; i < NLAY; ++i) {
+        DELH[i] = (i < NLAY - 1) ? BASEH[i + 1] - BASEH[i] : H[NPRO - 1] - BASEH[NLAY - 1];
+        DELS[i] = (i < NLAY - 1) ? BASES[i + 1] - BASES[i] : SMAX - BASES[NLAY - 1];
+        LAYSF[i] = DELS[i] / DELH[i];
+        BASET[i] = interp_lin(H, T, NPRO, BASEH[i]);
+    }
+    double *col = (double *)malloc(sizeof(double) * NPRO);
+    if (LAYINT == 0) {
+        for (int I = 0; I < NLAY; ++I) {
+            double S = (I < NLAY - 1) ? (BASES[I + 1] + BASES[I]) / 2 : (SMAX + BASES[NLAY - 1]) / 2;
+            double hh = sqrt(S * S + z0 * z0 + 2 * S * z0 * cs) - RADIUS;
+            HEIGHT[I] = hh;
+            PRESS[I] = interp_lin(H, P, NPRO, hh);
+            TEMP[I] = interp_lin(H, T, NPRO, hh);
+            FRAC[I] = interp_lin(H, parah2, NPRO, hh);
+            double MOLWT = interp_lin(H, molwt_g, NPRO, hh);
+            double DUDS = PRESS[I] / (k_B * TEMP[I]);
+            TOTAM[I] = DUDS * DELS[I];
+            for (int J = 0; J < NVMR; ++J) {
+                for (int k = 0; k < NPRO; ++k) col[k] = VMR[(size_t)k * NVMR + J];
+                double a = interp_lin(H, col, NPRO, hh);
+                PP[(size_t)I * NVMR + J] = a * PRESS[I];
+                AMOUNT[(size_t)I * NVMR + J] = a * TOTAM[I];
+            }
+            for (int J = 0; J < NDUST; ++J) {
+                for (int k = 0; k < NPRO; ++k) col[k] = DUST[(size_t)k * NDUST + J];
+                double DD = interp_lin(H, col, NPRO, hh);
+                if (DUST_UNITS && DUST_UNITS[J] == -1) CONT[(size_t)I * NDUST + J] = DD * TOTAM[I] * MOLWT / AVOGAD;
+                else CONT[(size_t)I * NDUST + J] = DD * DELS[I];
+            }
+        }
+    } else {
+        double *S = (double *)malloc(sizeof(double) * NINT), *h = (double *)malloc(sizeof(double) * NINT);
+        double *p = (double *)malloc(sizeof(double) * NINT), *tt = (double *)malloc(sizeof(double) * NINT);
+        double *duds = (double *)malloc(sizeof(double) * NINT), *f = (double *)malloc(sizeof(double) * NINT);
+        double *mw = (double *)malloc(sizeof(double) * NINT), *a = (double *)malloc(sizeof(double) * NINT);
+        for (int I = 0; I < NLAY; ++I) {
+            double S0 = BASES[I], S1 = (I < NLAY - 1) ? BASES[I + 1] : SMAX;
+            double step = (S1 - S0) / (NINT - 1);
+            for (int k = 0; k < NINT; ++k) S[k] = k * step + S0;     /* np.linspace */
+            S[NINT - 1] = S1;
+            for (int k = 0; k < NINT; ++k) {
+                h[k] = sqrt(S[k] * S[k] + z0 * z0 + 2 * S[k] * z0 * cs) - RADIUS;
+                p[k] = interp_lin(H, P, NPRO, h[k]);
+                tt[k] = interp_lin(H, T, NPRO, h[k]);
+                mw[k] = interp_lin(H, molwt_g, NPRO, h[k]);
+                duds[k] = p[k] / (k_B * tt[k]);
+            }
+            TOTAM[I] = simpson_x(duds, S, NINT);
+            for (int k = 0; k < NINT; ++k) f[k] = h[k] * duds[k];
+            HEIGHT[I] = simpson_x(f, S, NINT) / TOTAM[I];
+            for (int k = 0; k < NINT; ++k) f[k] = p[k] * duds[k];
+            PRESS[I] = simpson_x(f, S, NINT) / TOTAM[I];
+            for (int k = 0; k < NINT; ++k) f[k] = tt[k] * duds[k];
+            TEMP[I] = simpson_x(f, S, NINT) / TOTAM[I];
+            for (int k = 0; k < NINT; ++k) f[k] = interp_lin(H, parah2, NPRO, h[k]) * duds[k];
+            FRAC[I] = simpson_x(f, S, NINT) / TOTAM[I];
+            for (int J = 0; J < NVMR; ++J) {
+                for (int k = 0; k < NPRO; ++k) col[k] = VMR[(size_t)k * NVMR + J];
+                for (int k = 0; k < NINT; ++k) { a[k] = interp_lin(H, col, NPRO, h[k]); f[k] = a[k] * duds[k]; }
+                AMOUNT[(size_t)I * NVMR + J] = simpson_x(f, S, NINT);
+                for (int k = 0; k < NINT; ++k) f[k] = (a[k] * p[k]) * duds[k];
+                PP[(size_t)I * NVMR + J] = simpson_x(f, S, NINT) / TOTAM[I];
+            }
+            for (int J = 0; J < NDUST; ++J) {
+                for (int k = 0; k < NPRO; ++k) col[k] = DUST[(size_t)k * NDUST + J];
+                for (int k = 0; k < NINT; ++k) {
+                    double dd = interp_lin(H, col, NPRO, h[k]);
+                    f[k] = (DUST_UNITS && DUST_UNITS[J] == -1) ? dd * duds[k] * mw[k] / AVOGAD : dd;
+                }
+                CONT[(size_t)I * NDUST + J] = simpson_x(f, S, NINT);
+            }
+        }
+        free(S); free(h); free(p); free(tt); free(duds); free(f); free(mw); free(a);
+    }
+    for (int I = 0; I < NLAY; ++I) {   /* scale back to vertical layers :1013-1023 */
+        TOTAM[I] = TOTAM[I] / LAYSF[I];
+        double inv = pow(LAYSF[I], -1);
+        for (int J = 0; J < NVMR; ++J) AMOUNT[(size_t)I * NVMR + J] *= inv;
+        for (int J = 0; J < NDUST; ++J) CONT[(size_t)I * NDUST + J] *= inv;
+    }
+    free(BASES); free(DELS); free(zero); free(molwt_g); free(col);
+    return 0;
+}

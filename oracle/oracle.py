@@ -17,7 +17,7 @@ _d = np.float64
 
 def build(force=False):
     so = os.path.join(_HERE, "libansfm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("ansfm_oracle.c", "ansfm_oracle_ms.c", "ansfm_oracle_lbl.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ansfm_oracle.c", "ansfm_oracle_ms.c", "ansfm_oracle_lbl.c", "ansfm_oracle_layer.c", "Makefile")]
     if force or (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -248,3 +248,23 @@ def add_line_set_monochromatic_absorption(wn_grid, lineshape_id, t_calc, t_ref, 
         _p(bp), _p(nu), _p(sw), _p(el), _p(sr), _p(out), _p(store), C.c_double(s_floor), C.c_double(wn_calc_window),
         C.c_double(wn_approx_window))
     return out
+
+
+def layer_average(RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP, LAYANG=0.0, LAYINT=0, LAYHT=0.0, NINT=101,
+                  DUST_UNITS=None, XMOLWT=None):
+    """Layer_0.layer_average (:755) -> HEIGHT,PRESS,TEMP,TOTAM,AMOUNT,PP,CONT,FRAC,DELH,BASET,LAYSF."""
+    H = _c(H); P = _c(P); T = _c(T); BASEH = _c(BASEH)
+    VMR = _c(VMR).reshape(H.size, -1); NV = VMR.shape[1]
+    ND = 0 if DUST is None else _c(DUST).reshape(H.size, -1).shape[1]
+    D = None if DUST is None else _c(DUST).reshape(H.size, -1)
+    NL = BASEH.size
+    o = [np.zeros(NL) for _ in range(4)]
+    AM = np.zeros((NL, NV)); PPo = np.zeros((NL, NV)); CO = np.zeros((NL, ND)); FR = np.zeros(NL)
+    DELH = np.zeros(NL); BASET = np.zeros(NL); LAYSF = np.zeros(NL)
+    rc = lib().orc_layer_average(C.c_double(RADIUS), H.size, _p(H), _p(P), _p(T), NV, _p(VMR), ND, _p(D), _p(_c(PARAH2)), NL,
+                                 _p(BASEH), C.c_double(LAYANG), int(LAYINT), C.c_double(LAYHT), int(NINT),
+                                 _p(_c(DUST_UNITS, np.int32)), _p(_c(XMOLWT)), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(AM),
+                                 _p(PPo), _p(CO), _p(FR), _p(DELH), _p(BASET), _p(LAYSF))
+    if rc:
+        raise NotImplementedError("layer_average: even NINT not restated")
+    return o[0], o[1], o[2], o[3], AM, PPo, CO, FR, DELH, BASET, LAYSF

@@ -323,3 +323,25 @@ def test_lbl_runtime_batched_unsorted_vs_oracle(eng, oracle, golden_dir):
         oracle.add_line_set_monochromatic_absorption(wn, 0, t[l], 296.0, p[l], 1.0, q[l], 0.9, 28.0, z["mol_mix_frac"],
                                                      bp[:, srt], nu[srt], sw[srt], el[srt], sr[srt], ref[l])
     np.testing.assert_allclose(out, ref, rtol=1e-10)
+
+
+@pytest.mark.parametrize("case", ["cg_nadir", "cg_slant", "mid_slant", "cg_dustunits"])
+def test_layer_average_golden(eng, golden_dir, case):
+    """Layer_0.layer_average (Curtis-Godson / mid-path) vs the reference (golden), single state and a batch."""
+    from test_layer_oracle import NAMES, CASES
+    z = _load(golden_dir, "layer_average")
+    kw = dict(CASES[case]); du = kw.pop("dust_units", False)
+    args = dict(LAYHT=-6.0e4, NINT=101, DUST_UNITS=np.array([-1, 0]) if du else None, XMOLWT=z["XMOLWT"] if du else None, **kw)
+    r = eng.layer_average(float(z["RADIUS"]), z["H"], z["P"], z["T"], None, z["VMR"], z["DUST"], z["PARAH2"], z["split1_BASEH"],
+                          z["split1_BASEP"], **args)
+    for n, v in zip(NAMES, r):
+        np.testing.assert_allclose(v, z[f"{case}_{n}"], rtol=1e-10, err_msg=n)
+    # batch of 3 states: state 1 has a warmer profile; state 0 and 2 must reproduce the golden
+    T3 = np.stack([z["T"], z["T"] * 1.05, z["T"]])
+    rep = lambda a: np.repeat(np.asarray(a)[None], 3, 0)
+    rb = eng.layer_average(float(z["RADIUS"]), rep(z["H"]), rep(z["P"]), T3, None, rep(z["VMR"]), rep(z["DUST"]),
+                           rep(z["PARAH2"]), z["split1_BASEH"], None, **args)
+    for n, v in zip(NAMES, rb):
+        np.testing.assert_allclose(v[0], z[f"{case}_{n}"], rtol=1e-10, err_msg=n)
+        np.testing.assert_allclose(v[2], z[f"{case}_{n}"], rtol=1e-10, err_msg=n)
+    assert np.all(rb[2][1] > rb[2][0])          # TEMP of the warmed state
