@@ -261,8 +261,7 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
         p.g_ord[G] = 1.0;
         p.g_ord[G + 1] = __builtin_inf();
     }
-    const size_t lds = (size_t)G * kWave * (3 * sizeof(double)) +
-                       (size_t)(2 * kMaxG + 2) * sizeof(double);
+    const size_t lds = (size_t)(3 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
@@ -270,10 +269,15 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     long grid = (long)ctx->num_cus * per_cu;
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
-    HIPCHK(ctx->scratch.reserve((size_t)grid * 2 * G * kWave * sizeof(double)));
+    HIPCHK(ctx->scratch.reserve((size_t)grid * 6 * G * kWave * sizeof(double)));
     p.scratch = ctx->scratch.as<double>();
 #define LAUNCH_OV(D, FK)                                                                              \
-    hipLaunchKernelGGL((k_ck_overlap<D, FK>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p)
+    do {                                                                                              \
+        if (ctx->delg_f32)                                                                            \
+            hipLaunchKernelGGL((k_ck_overlap<D, FK, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p);  \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_ck_overlap<D, FK, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p); \
+    } while (0)
     if (from_k) {
         switch (p.depth) {
             case 1: LAUNCH_OV(1, true); break;

@@ -296,28 +296,119 @@ __device__ __forceinline__ double fast_div(double n, double d)
     return fma(fma(-d, q, n), r, q);
 }
 
-template <int DEPTH, bool FROM_K>
-__global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
+// One popped element of the merge with everything the replay and the rank walk need, fetched from LDS
+// as soon as the winner key is known (software pipelining: the walk of element t runs while the
+// operands of element t+1 are in flight).
+template <int DEPTH>
+struct MergeElem {
+    double ai, bc, bn, w;
+    double tv[DEPTH];
+    int off[DEPTH];   // LDS element offsets of the tree path (re-used for the write-back)
+    int ci, np;
+};
+
+template <int DEPTH, bool W32>
+__device__ __forceinline__ void merge_fetch(double key, int G, int lane, const double *A, const double *B,
+                                            const double *NV, const double *DG, MergeElem<DEPTH> &e)
+{
+    const unsigned kb = (unsigned)__double_as_longlong(key);
+    const int ci = kb & 31, cp = (kb >> 5) & 63;
+    e.ci = ci;
+    e.np = cp + 1;
+    e.ai = A[ci * kWave + lane];
+    e.bc = B[cp * kWave + lane];
+    e.bn = B[(cp + 1) * kWave + lane];          // B[G] = sentinel column: an exhausted row re-enters as "huge"
+    double w = DG[ci] * DG[cp];                  // exact in double when both are float32 values
+    if constexpr (W32) w = (double)(float)w;     // -> the float32 product NumPy forms (DELG float32)
+    e.w = w;
+    const int x0 = (G + ci) >> 1;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        e.off[d] = (x0 >> d) * kWave + lane;
+        e.tv[d] = NV[e.off[d]];
+    }
+}
+
+// keys: value with the low 11 mantissa bits = (col << 5) | row   (col <= 32, row <= 31)
+__device__ __forceinline__ double pack_key11(double v, int row, int col)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    b = (b & ~0x7FFULL) | (unsigned long long)((col << 5) | row);
+    return __longlong_as_double((long long)b);
+}
+
+// rank() walk state of one lane (ForwardModel_0.py:6155-6170).  Bin boundaries are recorded and resolved
+// after the loop: frac needs a division, and the next bin's (1-frac) share is added there too -- the same
+// sums in a different association.
+struct WalkState {
+    double gd, kacc, sum1, gnext;
+    int ig;
+};
+
+template <int DEPTH>
+__device__ __forceinline__ void merge_walk(const MergeElem<DEPTH> &e, WalkState &ws, double *rec, const double *GORD,
+                                           int lane)
+{
+    const double cv = e.ai + e.bc;
+    const double w = e.w;
+    const double gdn = ws.gd + w;
+    const double cw = cv * w;
+    if (gdn < ws.gnext) {
+        ws.kacc += cw;
+        ws.sum1 += w;
+    } else {
+        double *rp = rec + (size_t)ws.ig * 6 * kWave + lane;
+        rp[0] = ws.kacc; rp[kWave] = ws.sum1; rp[2 * kWave] = cw; rp[3 * kWave] = w;
+        rp[4 * kWave] = ws.gd; rp[5 * kWave] = gdn;
+        ws.kacc = 0.0; ws.sum1 = 0.0;
+        ws.ig += 1;
+        ws.gnext = GORD[ws.ig + 1];             // GORD[G+1] = +inf: nothing crosses after the last bin
+    }
+    ws.gd = gdn;
+}
+
+template <int DEPTH, bool W32>
+__device__ __forceinline__ void merge_step(MergeElem<DEPTH> &e, MergeElem<DEPTH> &en, WalkState &ws, int G, int lane,
+                                           const double *A, const double *B, double *NV, const double *DG,
+                                           const double *GORD, double *rec)
+{
+    // 1. replay the tree path of the popped leaf with the row's next element
+    double car = pack_key11(e.ai + e.bn, e.ci, e.np);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        double lo, hi;
+        minmax_f64(e.tv[d], car, lo, hi);
+        NV[e.off[d]] = hi;
+        car = lo;
+    }
+    // 2. fetch the operands of the new winner (LDS reads in flight during the walk)
+    merge_fetch<DEPTH, W32>(car, G, lane, A, B, NV, DG, en);
+    // 3. rank walk on the element just consumed
+    merge_walk<DEPTH>(e, ws, rec, GORD, lane);
+}
+
+template <int DEPTH, bool FROM_K, bool W32>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_ck_overlap(OverlapParams p)
 {
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
     const int G = p.G;
     double *A = smem;
-    double *B = A + G * kWave;
-    double *NV = B + G * kWave;
+    double *B = A + G * kWave;                   // G+1 rows
+    double *NV = B + (G + 1) * kWave;
     double *DG = NV + G * kWave;
     double *GORD = DG + kMaxG;
-    // shared tables: del_g and g_ord = [0, cumsum(del_g)], g_ord[G] = 1   (ForwardModel_0.py:6141-6143)
     if (lane < G) DG[lane] = p.del_g[lane];
     if (lane < G + 2) GORD[lane] = p.g_ord[lane];
+    const double HUGE_KEY = __longlong_as_double(0x7FE0000000000000LL);   // finite, above any optical depth
+    B[G * kWave + lane] = HUGE_KEY;
     __syncthreads();
-    const bool w32 = p.delg_f32 != 0;
     double wsum = 0.0;
     for (int g = 0; g < G; ++g) wsum += DG[g];
     const double wtot = wsum * wsum;  // stands in for gdist[-1] (python wrap at iloop==0)
 
-    double *scrK = p.scratch + (size_t)blockIdx.x * 2 * G * kWave;
-    double *scrS = scrK + G * kWave;
+    // per-block scratch: closed-bin records [bin][6][lane]: kacc, sum1, cw, w, gprev, gdn
+    double *rec = p.scratch + (size_t)blockIdx.x * 6 * G * kWave;
     const int NVT = p.Wpad / kWave;
     const long ntiles = (long)p.n_models * NVT * p.L;
 
@@ -348,68 +439,43 @@ __global__ __launch_bounds__(kWave) void k_ck_overlap(OverlapParams p)
                 const double b0 = B[lane];
                 for (int x = 1; x < G; ++x) {
                     const int row = p.init_loser[x];
-                    NV[x * kWave + lane] = pack_key(A[row * kWave + lane] + b0, row, 0);
+                    NV[x * kWave + lane] = pack_key11(A[row * kWave + lane] + b0, row, 0);
                 }
-                NV[lane] = sentinel_key(31);  // node 0: dummy level for the shallower leaves
-                for (int g = 0; g < G; ++g) { scrK[g * kWave + lane] = 0.0; scrS[g * kWave + lane] = 1.0; }
-                double ckey = pack_key(A[lane] + b0, 0, 0);  // current winner
-                // ---- rank() walk state -----------------------------------------------------------
-                double gd = 0.0, kacc = 0.0, sum1 = 0.0, gnext = GORD[1];
-                int ig = 0;
+                NV[lane] = HUGE_KEY;  // node 0: dummy level for the shallower leaves
+                MergeElem<DEPTH> e0, e1;
+                merge_fetch<DEPTH, W32>(pack_key11(A[lane] + b0, 0, 0), G, lane, A, B, NV, DG, e0);
+                WalkState ws{0.0, 0.0, 0.0, GORD[1], 0};
                 const int nloop = G * G;
-                for (int it = 0; it < nloop; ++it) {
-                    const unsigned kb = (unsigned)__double_as_longlong(ckey);
-                    const int ci = kb & 31, cp = (kb >> 5) & 31;
-                    const int np = cp + 1;
-                    const int npc = np < G ? np : G - 1;
-                    const double ai = A[ci * kWave + lane];
-                    const double bc = B[cp * kWave + lane];
-                    const double bn = B[npc * kWave + lane];
-                    double w = DG[ci] * DG[cp];           // exact in double when both are float32 values
-                    if (w32) w = (double)(float)w;          // -> the float32 product NumPy forms
-                    const int x0 = (G + ci) >> 1;
-                    double tv[DEPTH];
-#pragma unroll
-                    for (int d = 0; d < DEPTH; ++d) tv[d] = NV[(x0 >> d) * kWave + lane];
-                    // advance the winner's row and replay its tree path
-                    double car = (np < G) ? pack_key(ai + bn, ci, np) : sentinel_key(ci);
-#pragma unroll
-                    for (int d = 0; d < DEPTH; ++d) {
-                        double lo, hi;
-                        minmax_f64(tv[d], car, lo, hi);
-                        NV[(x0 >> d) * kWave + lane] = hi;
-                        car = lo;
-                    }
-                    ckey = car;
-                    // rank walk on element (cv, w)        ForwardModel_0.py:6155-6170
-                    const double cv = ai + bc;
-                    const double gdn = gd + w;
-                    const double cw = cv * w;
-                    if (ig < G) {
-                        if (gdn < gnext) {
-                            kacc += cw;
-                            sum1 += w;
-                        } else {
-                            const double gprev = (it == 0) ? wtot : gd;
-                            const double frac = fast_div(gnext - gprev, gdn - gprev);
-                            scrK[ig * kWave + lane] = kacc + frac * cw;
-                            scrS[ig * kWave + lane] = sum1 + frac * w;
-                            ig += 1;
-                            sum1 = (1.0 - frac) * w;
-                            kacc = (1.0 - frac) * cw;
-                            gnext = GORD[ig + 1];
-                        }
-                    }
-                    gd = gdn;
+                int it = 0;
+                for (; it + 1 < nloop; it += 2) {   // ping-pong: no register rotation
+                    merge_step<DEPTH, W32>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec);
+                    merge_step<DEPTH, W32>(e1, e0, ws, G, lane, A, B, NV, DG, GORD, rec);
                 }
-                // trailing `if ig == ng-1` (ForwardModel_0.py:6171); an unfinished earlier bin stays
-                // un-normalised exactly like the reference leaves it
-                if (ig < G) {
-                    scrK[ig * kWave + lane] = kacc;
-                    scrS[ig * kWave + lane] = (ig == G - 1) ? sum1 : 1.0;
+                if (it < nloop) merge_step<DEPTH, W32>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec);
+                // ---- resolve the bins --------------------------------------------------------------------
+                double ck = 0.0, cs = 0.0;   // (1-frac) share carried into the next bin
+                const int ig = ws.ig;
+                for (int b = 0; b < G; ++b) {
+                    double outv = 0.0;
+                    if (b < ig) {
+                        const double *rp = rec + (size_t)b * 6 * kWave + lane;
+                        const double ka = rp[0], s1 = rp[kWave], cw = rp[2 * kWave], w = rp[3 * kWave];
+                        // a crossing at the very first element (nothing accumulated yet) sees python's gdist[-1]
+                        const double gprev = (b == 0 && s1 == 0.0) ? wtot : rp[4 * kWave];
+                        const double gdn = rp[5 * kWave];
+                        const double frac = (GORD[b + 1] - gprev) / (gdn - gprev);
+                        const double kb = (ck + ka) + frac * cw;
+                        const double sb = (cs + s1) + frac * w;
+                        outv = kb / sb;
+                        ck = (1.0 - frac) * cw;
+                        cs = (1.0 - frac) * w;
+                    } else if (b == ig) {
+                        // trailing `if ig == ng-1` (:6171); an unfinished earlier bin stays un-normalised
+                        const double kb = ck + ws.kacc, sb = cs + ws.sum1;
+                        outv = (b == G - 1) ? kb / sb : kb;
+                    }
+                    A[b * kWave + lane] = outv;
                 }
-                for (int g = 0; g < G; ++g)
-                    A[g * kWave + lane] = scrK[g * kWave + lane] / scrS[g * kWave + lane];
             }
         }
         if (unsorted) atomicOr(p.err_flag, 1);
