@@ -321,10 +321,10 @@ __device__ __forceinline__ void merge_fetch(double key, int G, int lane, const d
     double w = DG[ci] * DG[cp];                  // exact in double when both are float32 values
     if constexpr (W32) w = (double)(float)w;     // -> the float32 product NumPy forms (DELG float32)
     e.w = w;
-    const int x0 = (G + ci) >> 1;
+    const unsigned t = (unsigned)(G + ci);
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-        e.off[d] = (x0 >> d) * kWave + lane;
+        e.off[d] = (int)__builtin_amdgcn_ubfe(t, d + 1, 6) * kWave + lane;   // node (G+ci) >> (d+1)
         e.tv[d] = NV[e.off[d]];
     }
 }
@@ -353,17 +353,16 @@ __device__ __forceinline__ void merge_walk(const MergeElem<DEPTH> &e, WalkState 
     const double w = e.w;
     const double gdn = ws.gd + w;
     const double cw = cv * w;
-    if (gdn < ws.gnext) {
-        ws.kacc += cw;
-        ws.sum1 += w;
-    } else {
+    double kn = ws.kacc + cw, sn = ws.sum1 + w;
+    if (!(gdn < ws.gnext)) {                    // this element straddles the bin boundary
         double *rp = rec + (size_t)ws.ig * 6 * kWave + lane;
         rp[0] = ws.kacc; rp[kWave] = ws.sum1; rp[2 * kWave] = cw; rp[3 * kWave] = w;
-        rp[4 * kWave] = ws.gd; rp[5 * kWave] = gdn;
-        ws.kacc = 0.0; ws.sum1 = 0.0;
+        rp[4 * kWave] = ws.gd;
+        kn = 0.0; sn = 0.0;
         ws.ig += 1;
         ws.gnext = GORD[ws.ig + 1];             // GORD[G+1] = +inf: nothing crosses after the last bin
     }
+    ws.kacc = kn; ws.sum1 = sn;
     ws.gd = gdn;
 }
 
@@ -407,7 +406,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     for (int g = 0; g < G; ++g) wsum += DG[g];
     const double wtot = wsum * wsum;  // stands in for gdist[-1] (python wrap at iloop==0)
 
-    // per-block scratch: closed-bin records [bin][6][lane]: kacc, sum1, cw, w, gprev, gdn
+    // per-block scratch: closed-bin records [bin][6][lane]: kacc, sum1, cw, w, gd (slot 5 unused)
     double *rec = p.scratch + (size_t)blockIdx.x * 6 * G * kWave;
     const int NVT = p.Wpad / kWave;
     const long ntiles = (long)p.n_models * NVT * p.L;
@@ -461,8 +460,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                         const double *rp = rec + (size_t)b * 6 * kWave + lane;
                         const double ka = rp[0], s1 = rp[kWave], cw = rp[2 * kWave], w = rp[3 * kWave];
                         // a crossing at the very first element (nothing accumulated yet) sees python's gdist[-1]
-                        const double gprev = (b == 0 && s1 == 0.0) ? wtot : rp[4 * kWave];
-                        const double gdn = rp[5 * kWave];
+                        const double gd0 = rp[4 * kWave];
+                        const double gprev = (b == 0 && s1 == 0.0) ? wtot : gd0;
+                        const double gdn = gd0 + w;                 // the same add the walk made
                         const double frac = (GORD[b + 1] - gprev) / (gdn - gprev);
                         const double kb = (ck + ka) + frac * cw;
                         const double sb = (cs + s1) + frac * w;
