@@ -247,6 +247,8 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     p.del_g = del_g_dev;
     p.tau = tau;
     p.err_flag = ctx->d_flag.as<int>() + 1;
+    p.tile_counter = reinterpret_cast<unsigned int *>(ctx->d_flag.as<int>() + 2);
+    HIPCHK(hipMemsetAsync(p.tile_counter, 0, sizeof(unsigned int), ctx->stream));
     p.W = W; p.Wpad = Wpad; p.G = G; p.NT = ctx->NT; p.S = S; p.L = L; p.n_models = n_models;
     loser_tree_init(G, p.init_loser, &p.depth);
     p.delg_f32 = ctx->delg_f32;

@@ -230,6 +230,7 @@ struct OverlapParams {
     double *tau;              // [n][L][G][Wpad]
     double *scratch;          // [gridDim.x][2][G][64]
     int *err_flag;            // bit0: unsorted input k-distribution
+    unsigned int *tile_counter;  // dynamic tile queue (zeroed before every launch)
     int W, Wpad, G, NT, S, L, n_models, depth;
     int delg_f32;             // DELG is a float32 array: del_g[i]*del_g[j] is a float32 product
     unsigned char init_loser[kMaxG];
@@ -411,7 +412,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     const int NVT = p.Wpad / kWave;
     const long ntiles = (long)p.n_models * NVT * p.L;
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Dynamic tile queue: with 5 resident waves per CU one SIMD hosts two waves that run slower than the
+    // solo ones; static striding would make the launch wait for them.  One relaxed atomic per tile (~2800*7
+    // merge steps of work) -- every wave exits when the counter passes ntiles.
+    for (;;) {
+        unsigned int tq = 0;
+        if (lane == 0) tq = atomicAdd(p.tile_counter, 1u);
+        const long tile = (long)__builtin_amdgcn_readfirstlane(tq);
+        if (tile >= ntiles) break;
         const int l = (int)(tile % p.L);
         const long r = tile / p.L;
         const int vt = (int)(r % NVT);
