@@ -267,6 +267,7 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
+    if (const char *ev = getenv("ANSFM_WAVES_PER_CU")) { int v = atoi(ev); if (v >= 1 && v < per_cu) per_cu = v; }
     const long ntiles = (long)n_models * (Wpad / kWave) * L;
     long grid = (long)ctx->num_cus * per_cu;
     if (grid > ntiles) grid = ntiles;

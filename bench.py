@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--jac-models", type=int, default=201)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-jacobian", action="store_true")
-    ap.add_argument("--cpu-sample-waves", type=int, default=2048)
+    ap.add_argument("--cpu-sample-waves", type=int, default=10000)
     args = ap.parse_args()
 
     import torch
@@ -223,8 +223,9 @@ def main():
         got = d_out1[0, :Wc].cpu().numpy()
         perr = float(np.max(np.abs(got - ref) / np.abs(ref)))
         cpu = {"value": (Wc / W) / ct, "unit": "forward-models/s", "cores": int(cores), "kind": "port",
-               "sample": f"first {Wc} of {W} wavenumbers x {L} layers x {S} gases (G={G}), oracle/ansfm_oracle.c, "
-                         f"OpenMP over wavenumbers, {ct:.2f} s wall; value scaled by {Wc}/{W}",
+               "sample": (f"{'the whole' if Wc == W else f'first {Wc} of {W} wavenumbers of the'} C2 forward model "
+                          f"({Wc} wavenumbers x {L} layers x {S} gases, G={G}) through oracle/ansfm_oracle.c, OpenMP over "
+                          f"wavenumbers, {ct:.2f} s wall x {cores} threads" + ("" if Wc == W else f"; value scaled by {Wc}/{W}")),
                "gpu_vs_oracle_max_rel_err_on_sample": perr}
 
     line = {
