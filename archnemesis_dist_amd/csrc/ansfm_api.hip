@@ -188,12 +188,12 @@ int ansfm_upload_ktable_dev(ansfm_ctx *ctx, int W, int G, int NP, int NT, int S,
     HIPCHK(ctx->d_temp.reserve(NT * sizeof(double)));
     HIPCHK(ctx->d_wave.reserve((size_t)W * sizeof(double)));
     HIPCHK(ctx->d_delg.reserve(kMaxG * sizeof(double)));
-    HIPCHK(ctx->d_flag.reserve(4 * sizeof(int)));
+    HIPCHK(ctx->d_flag.reserve(16 * sizeof(int)));
     HIPCHK(hipMemcpyAsync(ctx->d_press.p, PRESS, NP * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_temp.p, TEMP, NT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_wave.p, WAVE, (size_t)W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_delg.p, DELG, G * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_flag.p, 0, 4 * sizeof(int), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_flag.p, 0, 16 * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_table_relayout, dim3(nblk(total, 256)), dim3(256), 0, ctx->stream, K_dev,
                        ctx->lnK.as<double>(), W, Wpad, G, NP, NT, S, ctx->d_flag.as<int>());
     HIPCHK(hipGetLastError());
@@ -247,8 +247,8 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     p.del_g = del_g_dev;
     p.tau = tau;
     p.err_flag = ctx->d_flag.as<int>() + 1;
-    p.tile_counter = reinterpret_cast<unsigned int *>(ctx->d_flag.as<int>() + 2);
-    HIPCHK(hipMemsetAsync(p.tile_counter, 0, sizeof(unsigned int), ctx->stream));
+    p.tile_counter = reinterpret_cast<unsigned int *>(ctx->d_flag.as<int>() + 4);
+    HIPCHK(hipMemsetAsync(p.tile_counter, 0, 8 * sizeof(unsigned int), ctx->stream));
     p.W = W; p.Wpad = Wpad; p.G = G; p.NT = ctx->NT; p.S = S; p.L = L; p.n_models = n_models;
     loser_tree_init(G, p.init_loser, &p.depth);
     p.delg_f32 = ctx->delg_f32;
@@ -536,7 +536,7 @@ int ansfm_k_overlap(ansfm_ctx *ctx, int W, int G, int L, int S, const double *de
     if ((rc = h2d(ctx, ctx->hb[0], k, nk * sizeof(double), &dk))) return rc;
     if ((rc = h2d(ctx, ctx->hb[1], amount, (size_t)S * L * sizeof(double), &dam))) return rc;
     if ((rc = h2d(ctx, ctx->hb[2], del_g, (size_t)G * sizeof(double), &ddg))) return rc;
-    HIPCHK(ctx->d_flag.reserve(4 * sizeof(int)));
+    HIPCHK(ctx->d_flag.reserve(16 * sizeof(int)));
     HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
     const size_t nkin = (size_t)S * L * G * Wpad;
     HIPCHK(ctx->tmp_in.reserve(nkin * sizeof(double)));
@@ -855,7 +855,7 @@ int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *d
     if ((rc = h2d(ctx, ctx->hb[3], dkdT, nk * sizeof(double), &ddk))) return rc;
     if ((rc = h2d(ctx, ctx->hb[1], amount, (size_t)S * L * sizeof(double), &dam))) return rc;
     if ((rc = h2d(ctx, ctx->hb[2], del_g, (size_t)G * sizeof(double), &ddg))) return rc;
-    HIPCHK(ctx->d_flag.reserve(4 * sizeof(int)));
+    HIPCHK(ctx->d_flag.reserve(16 * sizeof(int)));
     HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
     const size_t nkin = (size_t)S * L * G * Wpad;
     HIPCHK(ctx->tmp_in.reserve(nkin * sizeof(double)));

@@ -230,7 +230,7 @@ struct OverlapParams {
     double *tau;              // [n][L][G][Wpad]
     double *scratch;          // [gridDim.x][2][G][64]
     int *err_flag;            // bit0: unsorted input k-distribution
-    unsigned int *tile_counter;  // dynamic tile queue (zeroed before every launch)
+    unsigned int *tile_counter;  // [8] dynamic tile queues, one per XCD (zeroed before every launch)
     int W, Wpad, G, NT, S, L, n_models, depth;
     int delg_f32;             // DELG is a float32 array: del_g[i]*del_g[j] is a float32 product
     unsigned char init_loser[kMaxG];
@@ -261,7 +261,9 @@ __device__ __forceinline__ void load_gas(const OverlapParams &p, const LayerInte
         const double *c4 = p.lnK + ((size_t)q.iph * p.NT + q.ith) * strideT + off;
         for (int g = 0; g < G; ++g) {
             size_t go = (size_t)g * p.Wpad;
-            double kk = interp_k(c1[go], c2[go], c3[go], c4[go], q.v, q.u) * amt;
+            // streamed once per tile: non-temporal so the table does not push the merge scratch out of L2
+            double kk = interp_k(__builtin_nontemporal_load(c1 + go), __builtin_nontemporal_load(c2 + go),
+                                 __builtin_nontemporal_load(c3 + go), __builtin_nontemporal_load(c4 + go), q.v, q.u) * amt;
             DST[g * kWave + lane] = kk;
             unsorted |= (kk < prev);
             prev = kk;
@@ -415,15 +417,34 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     // Dynamic tile queue: with 5 resident waves per CU one SIMD hosts two waves that run slower than the
     // solo ones; static striding would make the launch wait for them.  One relaxed atomic per tile (~2800*7
     // merge steps of work) -- every wave exits when the counter passes ntiles.
+    // Eight queues, queue q = wavenumber tiles vt with vt % 8 == q (layer fastest): the layers of one
+    // wavenumber tile share k-table corner rows, so they are kept on one XCD's L2.  A wave starts on the queue
+    // of the XCD it runs on (HW_REG_XCC_ID; affinity only, any placement is correct) and steals from the others
+    // when its own is empty.
+    const int myq = (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 7);
+    (void)ntiles;
+    int qoff = 0;
     for (;;) {
-        unsigned int tq = 0;
-        if (lane == 0) tq = atomicAdd(p.tile_counter, 1u);
-        const long tile = (long)__builtin_amdgcn_readfirstlane(tq);
-        if (tile >= ntiles) break;
-        const int l = (int)(tile % p.L);
-        const long r = tile / p.L;
-        const int vt = (int)(r % NVT);
-        const int m = (int)(r / NVT);
+        long tile = -1;
+        int vt = 0, m = 0, l = 0;
+        while (qoff < 8) {
+            const int qq = (myq + qoff) & 7;
+            const int nvt_q = (NVT - qq + 7) / 8;                     // tiles vt = qq, qq+8, ...
+            const long nq = (long)p.n_models * nvt_q * p.L;
+            unsigned int tq = 0;
+            if (lane == 0 && nq > 0) tq = atomicAdd(p.tile_counter + qq, 1u);
+            const long t = (long)__builtin_amdgcn_readfirstlane(tq);
+            if (nq > 0 && t < nq) {
+                l = (int)(t % p.L);
+                const long r = t / p.L;
+                vt = qq + 8 * (int)(r % nvt_q);
+                m = (int)(r / nvt_q);
+                tile = t;
+                break;
+            }
+            ++qoff;
+        }
+        if (tile < 0) break;
         const int nu = vt * kWave + lane;
         LayerInterp q;
         if constexpr (!FROM_K) q = p.li[(size_t)m * p.L + l];
