@@ -201,3 +201,61 @@ def make_gpu_forward_model(reference_forward_model_cls, device=0):
     """Subclass of the reference's ForwardModel_0 with the GPU CIRSrad seam."""
     return type("ForwardModel_0", (CIRSradGPU, reference_forward_model_cls),
                 {"ansfm_device": device, "__doc__": reference_forward_model_cls.__doc__})
+
+
+def install_gpu_scattering_core(device=0):
+    """Route the reference's multiple-scattering core through the GPU.
+
+    ForwardModel_0.scloud11wave (ForwardModel_0.py:5018) prepares RADGROUND/BB/FRAC/OMEGA/PHASE_ARRAY on the host
+    and imports `scloud11wave_core` from archnemesis.Multiple_Scattering_Core at call time (:5050); replacing that
+    module attribute keeps all of the reference's host preparation and swaps only the core (K7).  Geometries the GPU
+    core does not cover yet (look-up) go to the reference's own function."""
+    import importlib
+    msc = importlib.import_module("archnemesis.Multiple_Scattering_Core")
+    eng = get_engine(device)
+    ref_core = getattr(msc, "_ansfm_reference_core", None) or msc.scloud11wave_core
+
+    def scloud11wave_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, lowbc, brdf_matrix, mu1, wt1, nf, vwaves, bnu,
+                          taus, tauray, omegas_s, nphi, iray, imie, lfrac):
+        try:
+            return eng.scloud11wave_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, int(lowbc), brdf_matrix, mu1, wt1,
+                                         nf, vwaves, bnu, taus, tauray, omegas_s, nphi, int(iray), int(imie), lfrac)
+        except NotImplementedError:
+            return ref_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, lowbc, brdf_matrix, mu1, wt1, nf, vwaves, bnu,
+                            taus, tauray, omegas_s, nphi, iray, imie, lfrac)
+
+    msc._ansfm_reference_core = ref_core
+    msc.scloud11wave_core = scloud11wave_core
+    return scloud11wave_core
+
+
+def install_gpu_line_kernel(device=0):
+    """Route LineData_0.add_line_set_monochromatic_absorption (LineData_0.py:280) through the GPU for the line shapes
+    that are built (voigt / lorentz / gaussian); other `lineshape_fn` objects go to the reference's own kernel."""
+    import importlib
+    ld = importlib.import_module("archnemesis.LineData_0")
+    ls = importlib.import_module("archnemesis.lineshape")
+    eng = get_engine(device)
+    ref_fn = getattr(ld, "_ansfm_reference_line_kernel", None) or ld.add_line_set_monochromatic_absorption
+    ids = {id(ls.voigt): 0, id(ls.lorentz): 4, id(ls.gaussian): 12}
+
+    def add_line_set_monochromatic_absorption(wn_grid, lineshape_fn, t_calc, t_ref, p_calc, p_ref, q_ratio,
+                                              isotopic_abundance, isotopic_mass, mol_mix_frac, broadening_params, nu, sw,
+                                              e_lower, stimulated_emission_at_t_ref, out, store=None, s_floor=0,
+                                              wn_calc_window=25.0, wn_approx_window=75.0):
+        lid = ids.get(id(lineshape_fn))
+        ok = (lid is not None and isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous
+              and (store is None or (store.dtype == np.float64 and store.flags.c_contiguous)))
+        if not ok:
+            return ref_fn(wn_grid, lineshape_fn, t_calc, t_ref, p_calc, p_ref, q_ratio, isotopic_abundance, isotopic_mass,
+                          mol_mix_frac, broadening_params, nu, sw, e_lower, stimulated_emission_at_t_ref, out, store, s_floor,
+                          wn_calc_window, wn_approx_window)
+        eng.add_line_set_monochromatic_absorption(wn_grid, lid, t_calc, t_ref, p_calc, p_ref, q_ratio, isotopic_abundance,
+                                                  isotopic_mass, mol_mix_frac, broadening_params, nu, sw, e_lower,
+                                                  stimulated_emission_at_t_ref, out, store, s_floor, wn_calc_window,
+                                                  wn_approx_window)
+        return
+
+    ld._ansfm_reference_line_kernel = ref_fn
+    ld.add_line_set_monochromatic_absorption = add_line_set_monochromatic_absorption
+    return add_line_set_monochromatic_absorption

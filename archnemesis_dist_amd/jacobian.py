@@ -67,3 +67,46 @@ def gather_columns(local_block, nfm, rank, world_size, group=None):
     dist.all_gather_into_tensor(out, pad, group=group)
     parts = [out[r * nmax: r * nmax + (e - s)] for r, (s, e) in enumerate(sizes)]
     return torch.cat(parts, dim=0)
+
+
+def jacobian_nemesis_sharded(fm, rank=0, world_size=1, device=None, analytical_gradient=False, group=None, **flags):
+    """Numerical Jacobian with the forward models sharded over ranks (one process per GPU).
+
+    Mirrors ForwardModel_0.jacobian_nemesis (ForwardModel_0.py:2184-2361) for the numerical part: builds the
+    perturbed states (:2234-2242), picks ixrun (:2291-2302), gives rank r the reference's contiguous chunk
+    (:2322-2330) -- each forward model is `fm.nemesisfm()` with `fm.Variables.XN` set like execute_fm does
+    (:2154), i.e. the reference's host code with CIRSrad on this rank's GPU -- and replaces the sum of
+    zero-padded matrices (:2336-2337) by one all_gather.  Returns (YN, KK) on every rank.
+
+    `fm` needs: Variables.{XN, NX, NUM, FIX, calc_DSTEP(), DSTEP}, Measurement.{NY, NGEOM, NCONV}, nemesisfm().
+    analytical_gradient=True defers to the reference's own jacobian_nemesis (nemesisfmg path)."""
+    import torch
+    V, M = fm.Variables, fm.Measurement
+    if analytical_gradient:
+        return fm.jacobian_nemesis(analytical_gradient=True, **flags)
+    V.calc_DSTEP()
+    XN = np.array(V.XN, dtype=float)
+    xnx = perturbed_states(XN, V.DSTEP)
+    inum = np.where((np.ones_like(np.asarray(V.NUM)) == 1) & (np.asarray(V.FIX) == 0))[0]   # NUM[:] = 1 (:2254-2255)
+    nfm = len(inum) + 1
+    ixrun = np.zeros(nfm, dtype="int32")
+    ixrun[1:nfm] = inum[:] + 1
+    s, e = chunk_range(nfm, world_size, rank)
+    NY = int(M.NY)
+    local = np.zeros((e - s, NY))
+    for k, ifm in enumerate(range(s, e)):
+        V.XN = xnx[:, ixrun[ifm]]
+        SPECMOD = fm.nemesisfm()
+        if SPECMOD is None:
+            raise RuntimeError(f"Something went wrong when calculating forward model {ifm + 1}/{nfm}.")   # :2177
+        ik = 0
+        for igeom in range(M.NGEOM):
+            nc = int(M.NCONV[igeom])
+            local[k, ik:ik + nc] = SPECMOD[0:nc, igeom]
+            ik += nc
+    V.XN = XN
+    dev = device if device is not None else "cpu"
+    block = torch.as_tensor(local, dtype=torch.float64, device=dev)
+    allY = gather_columns(block, nfm, rank, world_size, group=group).cpu().numpy()     # (nfm, NY)
+    YN, KK = finite_difference_jacobian(np.ascontiguousarray(allY.T), XN, inum, iYN=0, FIX=np.asarray(V.FIX))
+    return YN, KK

@@ -100,3 +100,67 @@ def test_gather_columns_gloo_world2(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+class _LinearFM:
+    """Stand-in forward model with the attributes jacobian_nemesis reads: a linear model y = A x (2 geometries)."""
+    def __init__(self, A, XN, ncalls):
+        from types import SimpleNamespace
+        self.A = A
+        self.ncalls = ncalls
+        NX = XN.size
+        V = SimpleNamespace(XN=XN.copy(), NX=NX, NUM=np.zeros(NX, dtype=int), FIX=np.zeros(NX, dtype=int), DSTEP=None)
+        V.FIX[2] = 1
+        V.calc_DSTEP = lambda: setattr(V, "DSTEP", 0.05 * V.XN)          # Variables_0.calc_DSTEP :535
+        self.Variables = V
+        self.Measurement = SimpleNamespace(NY=A.shape[0], NGEOM=2, NCONV=np.array([A.shape[0] // 2, A.shape[0] - A.shape[0] // 2]))
+
+    def nemesisfm(self):
+        self.ncalls.append(1)
+        y = self.A @ self.Variables.XN
+        n0 = self.Measurement.NCONV[0]
+        out = np.zeros((max(self.Measurement.NCONV), 2))
+        out[:n0, 0] = y[:n0]; out[:self.Measurement.NCONV[1], 1] = y[n0:]
+        return out
+
+
+def test_jacobian_nemesis_sharded_serial():
+    from archnemesis_dist_amd.jacobian import jacobian_nemesis_sharded
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(7, 5)); XN = np.array([1.0, -2.0, 0.5, 3.0, 4.0])
+    calls = []
+    YN, KK = jacobian_nemesis_sharded(_LinearFM(A, XN, calls))
+    assert len(calls) == 5                       # 1 + 4 free elements (element 2 is FIXed)
+    np.testing.assert_allclose(YN, A @ XN)
+    free = [0, 1, 3, 4]
+    np.testing.assert_allclose(KK[:, free], A[:, free], rtol=1e-12)
+    assert np.all(KK[:, 2] == 0.0)
+
+
+def test_jacobian_nemesis_sharded_gloo_world2(tmp_path):
+    script = textwrap.dedent(f'''
+        import os, sys
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+        import numpy as np, torch.distributed as dist
+        from archnemesis_dist_amd.jacobian import jacobian_nemesis_sharded
+        from test_abi_and_host import _LinearFM
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        rng = np.random.default_rng(0)
+        A = rng.normal(size=(7, 5)); XN = np.array([1.0, -2.0, 0.5, 3.0, 4.0])
+        calls = []
+        YN, KK = jacobian_nemesis_sharded(_LinearFM(A, XN, calls), rank=rank, world_size=world)
+        assert len(calls) in (2, 3), calls                      # 5 forward models over 2 ranks: 3 + 2
+        np.testing.assert_allclose(YN, A @ XN)
+        np.testing.assert_allclose(KK[:, [0, 1, 3, 4]], A[:, [0, 1, 3, 4]], rtol=1e-12)
+        dist.destroy_process_group()
+        print("rank", rank, "ok", len(calls))
+    ''')
+    f = tmp_path / "j.py"
+    f.write_text(script)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29618", str(f)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
