@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""Secondary timings on one MI355X (not the driver's bench contract): analytic-gradient CIRSrad at C2,
+the multiple-scattering core on a C4-like stack, runtime line-by-line on a reduced C5, batched layering.
+Host-pointer entry points: PCIe staging is included in the wall times (noted per line)."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import archnemesis_dist_amd as pkg
+from archnemesis_dist_amd import synthetic as syn
+
+
+def timeit(f, n=3):
+    f(); ts = []
+    for _ in range(n):
+        t = time.perf_counter(); f(); ts.append(time.perf_counter() - t)
+    return float(np.median(ts))
+
+
+def main():
+    eng = pkg.AnsfmEngine(0)
+    out = {}
+    # ---- analytic Jacobian at C2 ------------------------------------------------------------------
+    W, G, S, L, NP, NT = 10000, 20, 8, 100, 20, 15
+    _, delg = syn.gauss_legendre_01(G, True)
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S)
+    WAVE = 200.0 + 0.1 * np.arange(W)
+    eng.upload_ktable(K, PRESS, TEMP, WAVE, delg); del K
+    atm = syn.synth_atmosphere(L, S)
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L)
+    EMTEMP = atm["lay_temp"][:, LAYINC[:, 0]][:, :, None]
+    NVMR, NPAR = S, S + 2
+    ig = np.arange(S, dtype=np.int32)
+    f = lambda: eng.cirsradg_ck_thermal(0, atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0], None, None, NVMR, NPAR,
+                                        ig, NLAYIN, LAYINC, SCALE, EMTEMP[0], -1.0)
+    t = timeit(f)
+    k = eng.last_kernel_ms()
+    out["cirsradg_C2"] = {"wall_s_host_ptr": t, "overlapg_kernel_ms": k["overlap_ms"], "rtg_kernel_ms": k["rt_ms"],
+                          "note": "W=1e4,L=100,S=8,G=20, NPAR=10: SPECOUT + dSPECOUT(1e4,10,100,1) + dTSURF"}
+    # ---- multiple scattering, C4-like -----------------------------------------------------------------
+    rng = np.random.default_rng(0)
+    Wm, Gm, Lm, M, NF, NC = 256, 20, 100, 16, 8, 1
+    x, w = np.polynomial.legendre.leggauss(2 * M)
+    mu1 = np.sort(np.abs(x[x > 0])); wt1 = w[x > 0][np.argsort(np.abs(x[x > 0]))]
+    TH = np.linspace(0, 180, 41)
+    ph = np.zeros((NC, Wm, 2, TH.size)); c = np.cos(np.deg2rad(TH))
+    ph[:, :, 0, :] = ((1 - 0.36) / (1 + 0.36 - 1.2 * c) ** 1.5 / (4 * np.pi))[None, None, :]
+    ph[:, :, 1, :] = c[None, None, :]
+    ph = np.ascontiguousarray(ph[:, :, :, ::-1])
+    taus = 10.0 ** rng.uniform(-3, 0.5, (Wm, Gm, Lm)); tauray = 10.0 ** rng.uniform(-6, -3, (Wm, Lm))
+    tausc = 10.0 ** rng.uniform(-4, -1, (Wm, Lm)); taus = np.maximum(taus, (tausc + tauray)[:, None, :] * 1.05)
+    om = np.broadcast_to((tausc + tauray)[:, None, :], taus.shape) / taus
+    args = (ph, np.full((Wm, M), 1e-7), np.array([30.0]), np.array([20.0]), np.full(Wm, 1e-8), np.array([45.0]), 0,
+            np.zeros((Wm, M, M, NF + 1)), mu1, wt1, NF, 500.0 + np.arange(Wm), np.full((Wm, Lm), 1e-7), taus, tauray, om, 101, 1, 1,
+            np.ones((Wm, NC, Lm)))
+    t = timeit(lambda: eng.scloud11wave_core(*args), n=2)
+    nn = np.maximum((np.log2(taus) + 12).astype(int), 0)
+    flops = float(((nn * 6.67 + 5) * 2 * M ** 3).sum() * (NF + 1))
+    out["scloud11wave_C4like"] = {"wall_s": t, "waves": Wm, "g": Gm, "layers": Lm, "nmu": M, "nf": NF,
+                                  "approx_flops": flops, "TFLOPs": flops / t / 1e12,
+                                  "scaled_to_W1e4_s": t * 1e4 / Wm}
+    # ---- runtime LBL, reduced C5 ---------------------------------------------------------------------------
+    nw, N, Ll = 200000, 20000, 5
+    wn = 2000.0 + 1e-3 * np.arange(nw)
+    nu = np.sort(rng.uniform(1925.0, 2275.0, N)); sw = 10.0 ** rng.uniform(-28, -19, N); el = rng.uniform(0, 3000, N)
+    bp = np.zeros((3, N)); bp[0] = rng.uniform(0.02, 0.1, N); bp[1] = rng.uniform(0.5, 0.8, N); bp[2] = rng.uniform(-0.01, 0.01, N)
+    c2 = 2.99792458E10 * 6.62607015E-27 / 1.380649E-16
+    sr = 1 - np.exp(-c2 * nu / 296.0)
+    tt = np.linspace(150, 300, Ll); pp = np.logspace(-4, 0, Ll); qq = np.ones(Ll)
+    o = np.zeros((Ll, nw))
+    t = timeit(lambda: eng.add_line_set_monochromatic_absorption(wn, 0, tt, 296.0, pp, 1.0, qq, 1.0, 28.0, np.array([1.0]), bp, nu,
+                                                                 sw, el, sr, o), n=2)
+    evals = float(N) * (150.0 / 1e-3) * Ll * (200.0 / 350.0)     # lines whose window overlaps the grid, roughly
+    out["lbl_runtime_reducedC5"] = {"wall_s": t, "grid": nw, "lines": N, "layers": Ll, "approx_profile_evals": evals,
+                                    "Gevals_per_s": evals / t / 1e9}
+    # ---- batched layering ---------------------------------------------------------------------------------------
+    n, NPRO, V, D, NL = 201, 120, 8, 1, 100
+    H = np.linspace(0, 6e5, NPRO); P = 1e6 * np.exp(-H / 3e4); T = 150 + 50 * np.sin(H / 1e5)
+    rep = lambda a: np.repeat(np.asarray(a)[None], n, 0)
+    VM = np.full((NPRO, V), 1e-4); DU = np.full((NPRO, D), 10.0)
+    BH = np.linspace(0, 5.9e5, NL)
+    t = timeit(lambda: eng.layer_average(7.1e7, rep(H), rep(P), rep(T), None, rep(VM), rep(DU), None, BH, None, LAYINT=1, NINT=101))
+    out["layer_average_batch"] = {"wall_s": t, "states": n, "layers": NL, "nint": 101, "states_layers_per_s": n * NL / t}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
