@@ -48,7 +48,7 @@ def finite_difference_jacobian(YNtot, XN, inum, iYN=0, FIX=None):
     return YN, KK
 
 
-def gather_columns(local_block, nfm, rank, world_size, group=None):
+def gather_columns(local_block, nfm, rank, world_size, group=None, force=False):
     """All-gather of the per-rank spectra blocks.
 
     local_block: torch tensor (nfm_local, NY) holding forward models chunk_range(nfm, world, rank).
@@ -56,7 +56,7 @@ def gather_columns(local_block, nfm, rank, world_size, group=None):
     chunks are padded to the largest chunk."""
     import torch
     import torch.distributed as dist
-    if world_size == 1:
+    if world_size == 1 and not force:     # force: run the collective anyway (exercises RCCL on a 1-GPU box)
         return local_block
     sizes = [chunk_range(nfm, world_size, r) for r in range(world_size)]
     nmax = max(e - s for s, e in sizes)
