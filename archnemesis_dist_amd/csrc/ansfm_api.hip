@@ -962,8 +962,11 @@ int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const
         }
         HIPCHK(hipGetLastError());
     }
-    const size_t lds = (12 * nn + 6 * kMsMaxMu + 2) * D;
-    hipLaunchKernelGGL(k_ms_chain, dim3((unsigned)((size_t)nwave * ng * (nf + 1))), dim3(64), lds, ctx->stream, p);
+    const dim3 cgrid((unsigned)((size_t)nwave * ng * (nf + 1)));
+    if (nmu == 16)   // matrix-core products (v_mfma_f64_16x16x4_f64), 7 LDS matrices with leading dimension 17
+        hipLaunchKernelGGL(k_ms_chain16, cgrid, dim3(64), (7 * 16 * 17 + 4 * 16) * D, ctx->stream, p);
+    else
+        hipLaunchKernelGGL(k_ms_chain, cgrid, dim3(64), (12 * nn + 6 * kMsMaxMu + 2) * D, ctx->stream, p);
     HIPCHK(hipGetLastError());
     const size_t tot = (size_t)nwave * ng * ngeom;
     hipLaunchKernelGGL(k_ms_fourier, dim3(nblk(tot, 128)), dim3(128), 0, ctx->stream, p);

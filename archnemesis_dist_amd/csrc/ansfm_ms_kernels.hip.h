@@ -13,10 +13,10 @@
 //   k_ms_chain   one wavefront per (wave, g, ic): per layer doubling (double1/add) and adding
 //                (addp) of the (R,T,J) operators, nmu x nmu float64 matrices in LDS; then the
 //                2x2 (mu0,mu) samples of R u0+ + T u- + J for every path -> drad[wave][g][ic][path].
+//   k_ms_chain16 the same chain for nmu == 16 with the stream x stream products on the matrix cores
+//                (v_mfma_f64_16x16x4_f64), operands chained in the accumulator layout.
 //   k_ms_fourier one thread per (wave, g, path): the Fourier sum with the reference's early-out
 //                (:949-958) -> rad[path][g][wave].
-// First correct version: VALU matmuls out of LDS.  The stream x stream products are the place for
-// v_mfma_f64_16x16x4 when nmu = 16.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -167,62 +167,72 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
         }
 }
 
-// ---- small dense helpers on LDS matrices (one wavefront = one block) ----------------------------------
-__device__ __forceinline__ void ms_mm(int n, const double *A, const double *B, double *C, int lane)
+// ---- small dense helpers on LDS matrices (one wavefront = one block), any nmu <= 20 -------------------
+typedef double ms_v4f64 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ms_mm(int n, int ld, const double *A, const double *B, double *C, int lane)
 {   // C = A B   (C distinct from A and B)
     for (int e = lane; e < n * n; e += 64) {
         const int i = e / n, j = e % n;
         double s = 0.0;
-        for (int k = 0; k < n; ++k) s += A[i * n + k] * B[k * n + j];
-        C[e] = s;
+        for (int k = 0; k < n; ++k) s += A[i * ld + k] * B[k * ld + j];
+        C[i * ld + j] = s;
     }
     __syncthreads();
 }
-__device__ __forceinline__ void ms_mv(int n, const double *A, const double *x, double *y, int lane)
+__device__ __forceinline__ void ms_mv(int n, int ld, const double *A, const double *x, double *y, int lane)
 {   // y = A x   (y distinct from x)
     if (lane < n) {
         double s = 0.0;
-        for (int k = 0; k < n; ++k) s += A[lane * n + k] * x[k];
+        for (int k = 0; k < n; ++k) s += A[lane * ld + k] * x[k];
         y[lane] = s;
     }
     __syncthreads();
 }
-__device__ __forceinline__ double ms_frob(int n, const double *r, int lane)
+__device__ __forceinline__ double ms_frob(int n, int ld, const double *r, int lane)
 {
     double s = 0.0;
-    for (int e = lane; e < n * n; e += 64) s += r[e] * r[e];
+    for (int e = lane; e < n * n; e += 64) { const double v = r[(e / n) * ld + (e % n)]; s += v * v; }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     return sqrt(s);
 }
-// Ainv = inverse(A) by Gauss-Jordan with partial pivoting; A is destroyed.  col = scratch[n], piv_s = scratch int
-__device__ __forceinline__ void ms_inv(int n, double *A, double *Ainv, double *col, int *piv_s, int lane)
+// Ainv = inverse(A) by Gauss-Jordan with partial pivoting (first largest |.|, like LAPACK's idamax); A is
+// destroyed.  col = scratch[n].  The pivot search is a wavefront arg-max over the n candidate rows.
+__device__ __forceinline__ void ms_inv(int n, int ld, double *A, double *Ainv, double *col, int lane)
 {
-    for (int e = lane; e < n * n; e += 64) Ainv[e] = ((e / n) == (e % n)) ? 1.0 : 0.0;
+    for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e % n; Ainv[i * ld + j] = (i == j) ? 1.0 : 0.0; }
     __syncthreads();
     for (int c = 0; c < n; ++c) {
-        if (lane == 0) {
-            int piv = c;
-            double best = fabs(A[c * n + c]);
-            for (int r = c + 1; r < n; ++r) { double v = fabs(A[r * n + c]); if (v > best) { best = v; piv = r; } }
-            *piv_s = piv;
+        double best = (lane >= c && lane < n) ? fabs(A[lane * ld + c]) : -1.0;
+        int piv = lane;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {     // n <= 20 < 32: lanes 0..31 hold every candidate
+            const double ob = __shfl_xor(best, off, 64);
+            const int op = __shfl_xor(piv, off, 64);
+            if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+        }
+        piv = __builtin_amdgcn_readfirstlane(piv);
+        if (lane < n) {
+            double ac = A[c * ld + lane], wc = Ainv[c * ld + lane];
+            if (piv != c) {
+                const double ap = A[piv * ld + lane], wp = Ainv[piv * ld + lane];
+                A[piv * ld + lane] = ac; Ainv[piv * ld + lane] = wc;
+                ac = ap; wc = wp;
+            }
+            // pivot element after the swap, read by every lane from the (not yet scaled) row
+            const double d = 1.0 / __shfl(ac, c, 64);
+            A[c * ld + lane] = ac * d;
+            Ainv[c * ld + lane] = wc * d;
         }
         __syncthreads();
-        const int piv = *piv_s;
-        if (piv != c && lane < n) {
-            double t = A[c * n + lane]; A[c * n + lane] = A[piv * n + lane]; A[piv * n + lane] = t;
-            t = Ainv[c * n + lane]; Ainv[c * n + lane] = Ainv[piv * n + lane]; Ainv[piv * n + lane] = t;
-        }
-        __syncthreads();
-        const double d = 1.0 / A[c * n + c];
-        __syncthreads();
-        if (lane < n) { A[c * n + lane] *= d; Ainv[c * n + lane] *= d; col[lane] = A[lane * n + c]; }
+        if (lane < n) col[lane] = A[lane * ld + c];
         __syncthreads();
         for (int e = lane; e < n * n; e += 64) {
             const int r = e / n, j = e % n;
             if (r != c) {
                 const double f = col[r];
-                A[e] -= f * A[c * n + j];
-                Ainv[e] -= f * Ainv[c * n + j];
+                A[r * ld + j] -= f * A[c * ld + j];
+                Ainv[r * ld + j] -= f * Ainv[c * ld + j];
             }
         }
         __syncthreads();
@@ -235,25 +245,28 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
     extern __shared__ double sm[];
     const int lane = threadIdx.x;
     const int n = p.nmu, nn = n * n;
+    const int ld = n;
+    const int msz = n * ld;
     const int ic = blockIdx.x % (p.nf + 1);
     const int ig = (blockIdx.x / (p.nf + 1)) % p.ng;
     const int widx = blockIdx.x / ((p.nf + 1) * p.ng);
     const double pi = 3.141592653589793;
     // LDS carve-up
-    double *rc = sm, *tc = rc + nn, *r1 = tc + nn, *t1 = r1 + nn, *pp = t1 + nn, *pm = pp + nn;
-    double *m0 = pm + nn, *m1 = m0 + nn, *m2 = m1 + nn, *m3 = m2 + nn, *m4 = m3 + nn, *m5 = m4 + nn;
-    double *jc = m5 + nn, *j1 = jc + kMsMaxMu, *v0 = j1 + kMsMaxMu, *v1 = v0 + kMsMaxMu, *col = v1 + kMsMaxMu;
+    double *rc = sm, *tc = rc + msz, *r1 = tc + msz, *t1 = r1 + msz, *pp = t1 + msz, *pm = pp + msz;
+    double *m0 = pm + msz, *m1 = m0 + msz, *m2 = m1 + msz, *m3 = m2 + msz, *m4 = m3 + msz, *m5 = m4 + msz;
+    double *jc = m5 + msz, *j1 = jc + kMsMaxMu, *v0 = j1 + kMsMaxMu, *v1 = v0 + kMsMaxMu, *col = v1 + kMsMaxMu;
     double *radg = col + kMsMaxMu;
-    int *piv_s = reinterpret_cast<int *>(radg + kMsMaxMu);
+    (void)m5;
+#define MS_FOR_IJ for (int e = lane, i = e / n, j = e % n; e < nn; e += 64, i = e / n, j = e % n)
+#define MS_AT(M, i, j) M[(i) * ld + (j)]
 
     if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // radg[:, ::-1] :765
     __syncthreads();
     bool defined = false;
     if (p.lowbc > 0) {  // surface operator first :824-836
-        for (int e = lane; e < nn; e += 64) {
-            const int i = e / n, j = e % n;
-            rc[e] = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
-            tc[e] = 0.0;
+        MS_FOR_IJ {
+            MS_AT(rc, i, j) = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
+            MS_AT(tc, i, j) = 0.0;
         }
         if (lane < n) jc[lane] = radg[lane];
         defined = true;
@@ -278,23 +291,23 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
         int iscl = 0;
         omega = (tauscat + taur) / taut;
         if (taut == 0) {
-            for (int e = lane; e < nn; e += 64) { r1[e] = 0.0; t1[e] = ((e / n) == (e % n)) ? 1.0 : 0.0; }
+            MS_FOR_IJ { MS_AT(r1, i, j) = 0.0; MS_AT(t1, i, j) = (i == j) ? 1.0 : 0.0; }
             if (lane < n) j1[lane] = 0.0;
             __syncthreads();
         } else if (omega == 0) {
-            for (int e = lane; e < nn; e += 64) { r1[e] = 0.0; t1[e] = 0.0; }
+            MS_FOR_IJ { MS_AT(r1, i, j) = 0.0; MS_AT(t1, i, j) = 0.0; }
             __syncthreads();
             if (lane < n) {
                 const double tex = -(1. / p.mu[lane]) * taut;
                 const double tt = (tex > -200.0) ? exp(tex) : 0.0;
-                t1[lane * n + lane] = tt;
+                MS_AT(t1, lane, lane) = tt;
                 j1[lane] = bc * (1.0 - tt);
             }
             __syncthreads();
         } else {
             iscl = 1;
             const double fr = taur / (tauscat + taur), fs = tauscat / (tauscat + taur);
-            for (int e = lane; e < nn; e += 64) {
+            MS_FOR_IJ {
                 double a = (p.iray > 0) ? fr * (PPL[(size_t)p.ncont * nn + e] * FC[(size_t)p.ncont * nn + e]) : 0.0;
                 double b = (p.iray > 0) ? fr * PMI[(size_t)p.ncont * nn + e] : 0.0;
                 for (int c = 0; c < p.ncont; ++c) {
@@ -302,8 +315,8 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
                     a += fs * (PPL[(size_t)c * nn + e] * FC[(size_t)c * nn + e]) * f;
                     b += fs * PMI[(size_t)c * nn + e] * f;
                 }
-                pp[e] = a;
-                pm[e] = b;
+                MS_AT(pp, i, j) = a;
+                MS_AT(pm, i, j) = b;
             }
             __syncthreads();
             // ---- double1 :321-362 --------------------------------------------------------------------------
@@ -312,79 +325,77 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
             const int nd = (int)(log2(taut) + 12);   // python int(): truncation toward zero
             const double tau0 = taut * ((nd >= 1) ? 1.0 / exp2((double)nd) : 1.0);
             // Gamma++ = M^-1 (E - con P++ C) ;  Gamma+- = M^-1 con P+- C   (C, M^-1 diagonal)
-            for (int e = lane; e < nn; e += 64) {
-                const int i = e / n, j = e % n;
-                const double gpp = (1. / p.mu[i]) * (((i == j) ? 1.0 : 0.0) - (pp[e] * p.wtmu[j]) * con);
-                const double gpm = (1. / p.mu[i]) * ((pm[e] * p.wtmu[j]) * con);
-                t1[e] = ((i == j) ? 1.0 : 0.0) - tau0 * gpp;
-                r1[e] = tau0 * gpm;
+            MS_FOR_IJ {
+                const double gpp = (1. / p.mu[i]) * (((i == j) ? 1.0 : 0.0) - (MS_AT(pp, i, j) * p.wtmu[j]) * con);
+                const double gpm = (1. / p.mu[i]) * ((MS_AT(pm, i, j) * p.wtmu[j]) * con);
+                MS_AT(t1, i, j) = ((i == j) ? 1.0 : 0.0) - tau0 * gpp;
+                MS_AT(r1, i, j) = tau0 * gpm;
             }
             if (lane < n) j1[lane] = (ic == 0) ? (1.0 - omega) * bc * tau0 * (1. / p.mu[lane]) : 0.0;
             __syncthreads();
             for (int it = 0; it < nd; ++it) {   // add :275-297
-                ms_mm(n, r1, r1, m0, lane);                       // bcom
-                if (ms_frob(n, r1, lane) > 0.1) {
-                    for (int e = lane; e < nn; e += 64) m1[e] = (((e / n) == (e % n)) ? 1.0 : 0.0) - m0[e];
+                ms_mm(n, ld, r1, r1, m0, lane);               // bcom
+                if (ms_frob(n, ld, r1, lane) > 0.1) {
+                    MS_FOR_IJ MS_AT(m1, i, j) = ((i == j) ? 1.0 : 0.0) - MS_AT(m0, i, j);
                     __syncthreads();
-                    ms_inv(n, m1, m2, col, piv_s, lane);          // acom = inv(e - bcom)
+                    ms_inv(n, ld, m1, m2, col, lane);             // acom = inv(e - bcom)
                 } else {
-                    for (int e = lane; e < nn; e += 64) m2[e] = (((e / n) == (e % n)) ? 1.0 : 0.0) + m0[e];
+                    MS_FOR_IJ MS_AT(m2, i, j) = ((i == j) ? 1.0 : 0.0) + MS_AT(m0, i, j);
                     __syncthreads();
                 }
-                ms_mm(n, t1, m2, m3, lane);                       // ccom = t1 acom
-                ms_mm(n, m3, r1, m0, lane);                       // rans = ccom r1
-                ms_mm(n, m0, t1, m1, lane);                       // acom = rans t1
-                ms_mm(n, m3, t1, m4, lane);                       // tans = ccom t1
+                ms_mm(n, ld, t1, m2, m3, lane);               // ccom = t1 acom
+                ms_mm(n, ld, m3, r1, m0, lane);               // rans = ccom r1
+                ms_mm(n, ld, m0, t1, m1, lane);               // acom = rans t1
+                ms_mm(n, ld, m3, t1, m4, lane);               // tans = ccom t1
                 if (ic == 0) {
-                    ms_mv(n, r1, j1, v0, lane);                   // jcom = r1 j1 + j1
+                    ms_mv(n, ld, r1, j1, v0, lane);               // jcom = r1 j1 + j1
                     if (lane < n) v0[lane] = v0[lane] + j1[lane];
                     __syncthreads();
-                    ms_mv(n, m3, v0, v1, lane);                   // jans = ccom jcom + j1
+                    ms_mv(n, ld, m3, v0, v1, lane);               // jans = ccom jcom + j1
                     if (lane < n) j1[lane] = v1[lane] + j1[lane];
                 }
-                for (int e = lane; e < nn; e += 64) { r1[e] = r1[e] + m1[e]; t1[e] = m4[e]; }
+                MS_FOR_IJ { MS_AT(r1, i, j) = MS_AT(r1, i, j) + MS_AT(m1, i, j); MS_AT(t1, i, j) = MS_AT(m4, i, j); }
                 __syncthreads();
             }
         }
         // ---- combine with the stack below :868-875 ------------------------------------------------------------
         if (l == 0 && !defined) {
-            for (int e = lane; e < nn; e += 64) { rc[e] = r1[e]; tc[e] = t1[e]; }
+            MS_FOR_IJ { MS_AT(rc, i, j) = MS_AT(r1, i, j); MS_AT(tc, i, j) = MS_AT(t1, i, j); }
             if (lane < n) jc[lane] = j1[lane];
             __syncthreads();
         } else if (iscl == 1) {   // addp, scattering layer :486-511 (rsub,tsub,jsub) = (rc,tc,jc)
-            ms_mm(n, rc, r1, m0, lane);                           // rsq = rsub r1
-            if (ms_frob(n, m0, lane) > 0.01) {
-                for (int e = lane; e < nn; e += 64) m1[e] = (((e / n) == (e % n)) ? 1.0 : 0.0) - m0[e];
+            ms_mm(n, ld, rc, r1, m0, lane);                   // rsq = rsub r1
+            if (ms_frob(n, ld, m0, lane) > 0.01) {
+                MS_FOR_IJ MS_AT(m1, i, j) = ((i == j) ? 1.0 : 0.0) - MS_AT(m0, i, j);
                 __syncthreads();
-                ms_inv(n, m1, m2, col, piv_s, lane);
+                ms_inv(n, ld, m1, m2, col, lane);
             } else {
-                for (int e = lane; e < nn; e += 64) m2[e] = (((e / n) == (e % n)) ? 1.0 : 0.0) + m0[e];
+                MS_FOR_IJ MS_AT(m2, i, j) = ((i == j) ? 1.0 : 0.0) + MS_AT(m0, i, j);
                 __syncthreads();
             }
-            ms_mm(n, t1, m2, m3, lane);                           // ccom = t1 acom
-            ms_mm(n, m3, rc, m0, lane);                           // rans = ccom rsub
-            ms_mm(n, m0, t1, m1, lane);                           // bcom = rans t1
-            ms_mm(n, m3, tc, m4, lane);                           // tans = ccom tsub
-            ms_mv(n, rc, j1, v0, lane);                           // jcom = rsub j1 + jsub
+            ms_mm(n, ld, t1, m2, m3, lane);                   // ccom = t1 acom
+            ms_mm(n, ld, m3, rc, m0, lane);                   // rans = ccom rsub
+            ms_mm(n, ld, m0, t1, m1, lane);                   // bcom = rans t1
+            ms_mm(n, ld, m3, tc, m4, lane);                   // tans = ccom tsub
+            ms_mv(n, ld, rc, j1, v0, lane);                       // jcom = rsub j1 + jsub
             if (lane < n) v0[lane] += jc[lane];
             __syncthreads();
-            ms_mv(n, m3, v0, v1, lane);                           // jans = ccom jcom + j1
+            ms_mv(n, ld, m3, v0, v1, lane);                       // jans = ccom jcom + j1
             if (lane < n) jc[lane] = v1[lane] + j1[lane];
-            for (int e = lane; e < nn; e += 64) { rc[e] = r1[e] + m1[e]; tc[e] = m4[e]; }
+            MS_FOR_IJ { MS_AT(rc, i, j) = MS_AT(r1, i, j) + MS_AT(m1, i, j); MS_AT(tc, i, j) = MS_AT(m4, i, j); }
             __syncthreads();
         } else {                  // addp, non-scattering layer :513-530
-            ms_mv(n, rc, j1, v0, lane);
+            ms_mv(n, ld, rc, j1, v0, lane);
             if (lane < n) v0[lane] += jc[lane];
             __syncthreads();
-            for (int e = lane; e < nn; e += 64) {
-                const int i = e / n, j = e % n;
-                const double ta = t1[i * n + i], tb = t1[j * n + j];
-                m0[e] = tc[e] * ta;
-                m1[e] = rc[e] * ta * tb;
+            MS_FOR_IJ {
+                const double ta = MS_AT(t1, i, i), tb = MS_AT(t1, j, j);
+                MS_AT(m0, i, j) = MS_AT(tc, i, j) * ta;
+                MS_AT(m1, i, j) = MS_AT(rc, i, j) * ta * tb;
             }
-            if (lane < n) v1[lane] = j1[lane] + t1[lane * n + lane] * v0[lane];
+            if (lane < n) v1[lane] = j1[lane] + MS_AT(t1, lane, lane) * v0[lane];
             __syncthreads();
-            for (int e = lane; e < nn; e += 64) { tc[e] = m0[e]; rc[e] = m1[e]; }
+            MS_FOR_IJ { MS_AT(tc, i, j) = MS_AT(m0, i, j); MS_AT(rc, i, j) = MS_AT(m1, i, j); }
             if (lane < n) jc[lane] = v1[lane];
             __syncthreads();
         }
@@ -412,8 +423,8 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
             const double s0 = solar1 / (2.0 * pi * p.wtmu[imu0]);
             for (int imu = iemm; imu < iemm + 2; ++imu) {
                 double bcom = 0.0;   // (T utmi)[imu], utmi = radg for ic == 0 else 0
-                if (ic == 0) for (int kk = 0; kk < n; ++kk) bcom += tc[imu * n + kk] * radg[kk];
-                yx[ico++] = (rc[imu * n + imu0] * s0 + bcom) + jc[imu];
+                if (ic == 0) for (int kk = 0; kk < n; ++kk) bcom += MS_AT(tc, imu, kk) * radg[kk];
+                yx[ico++] = (MS_AT(rc, imu, imu0) * s0 + bcom) + jc[imu];
             }
         }
         double drad = ((1 - t) * (1 - u) * yx[0] + t * (1 - u) * yx[1] + t * u * yx[3] + (1 - t) * u * yx[2]) *
@@ -421,6 +432,335 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
         if (ic > 0) drad *= 2;
         p.drad[(((size_t)widx * p.ng + ig) * (p.nf + 1) + ic) * p.ngeom + ipath] = drad;
     }
+#undef MS_FOR_IJ
+#undef MS_AT
+}
+
+// ---- nmu == 16: the same chain on the matrix cores ----------------------------------------------------------
+// Every 16x16 float64 matrix lives in LDS (leading dimension 17) and, while it is being worked on, in the
+// MFMA accumulator layout ("D layout": lane (c = l&15, q = l>>4) holds rows q, q+4, q+8, q+12 of column c).
+// v_mfma_f64_16x16x4_f64 takes B operands in exactly that layout, so products chain in registers; only a
+// LEFT operand has to be read back from LDS transposed-wise (a[kb] = M[c][q+4kb]).  Mat-vec products reuse
+// the a-operand registers (4 FMAs + a reduction over q).  One wavefront per block: LDS is in-order per
+// wave, so a compiler fence replaces the barriers.
+#define MS16_FENCE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
+struct Ms16 {
+    int c, q;
+    __device__ __forceinline__ void load_a(const double *M, double a[4]) const
+    {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) a[kb] = M[c * 17 + q + 4 * kb];
+    }
+    __device__ __forceinline__ ms_v4f64 load_d(const double *M) const
+    {
+        ms_v4f64 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = M[(q + 4 * r) * 17 + c];
+        return v;
+    }
+    __device__ __forceinline__ void store_d(double *M, ms_v4f64 v) const
+    {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[(q + 4 * r) * 17 + c] = v[r];
+    }
+    __device__ __forceinline__ static ms_v4f64 mm(const double a[4], ms_v4f64 b)
+    {
+        ms_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], b[kb], acc, 0, 0, 0);
+        return acc;
+    }
+    // (M x)[c] for the matrix whose a-operands are given; x in LDS.  Same value in the four lanes of column c.
+    __device__ __forceinline__ double mv(const double a[4], const double *x) const
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) s += a[kb] * x[q + 4 * kb];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        return s;
+    }
+    __device__ __forceinline__ static double frob(ms_v4f64 v)
+    {
+        double s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        return sqrt(s);
+    }
+    __device__ __forceinline__ ms_v4f64 eye_plus(ms_v4f64 v, double sgn) const
+    {   // E + sgn * v
+        ms_v4f64 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = ((q + 4 * r == c) ? 1.0 : 0.0) + sgn * v[r];
+        return o;
+    }
+};
+
+// inverse of the 16x16 matrix in LDS A (ld 17) -> Ainv; Gauss-Jordan, partial pivoting (first largest |.|).
+// A is destroyed.  Lane (c0,q) updates rows q+4r of column c0 in both matrices.
+__device__ __forceinline__ void ms_inv16(double *A, double *Ainv, int lane)
+{
+    const int c0 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ainv[(q + 4 * r) * 17 + c0] = (q + 4 * r == c0) ? 1.0 : 0.0;
+    MS16_FENCE();
+    for (int c = 0; c < 16; ++c) {
+        double best = (c0 >= c) ? fabs(A[c0 * 17 + c]) : -1.0;    // every 16-lane row group searches alike
+        int piv = c0;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 64);
+            const int op = __shfl_xor(piv, off, 64);
+            if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+        }
+        piv = __builtin_amdgcn_readfirstlane(piv);
+        // rows c and piv of both matrices: swap, then scale the pivot row
+        const double ac = A[c * 17 + c0], wc = Ainv[c * 17 + c0];
+        const double ap = A[piv * 17 + c0], wp = Ainv[piv * 17 + c0];
+        const double d = 1.0 / A[piv * 17 + c];
+        const double pa = ap * d, pw = wp * d;
+        MS16_FENCE();
+        if (q == 0) {
+            A[piv * 17 + c0] = ac; Ainv[piv * 17 + c0] = wc;      // no-op content when piv == c, overwritten next
+            A[c * 17 + c0] = pa; Ainv[c * 17 + c0] = pw;
+        }
+        MS16_FENCE();
+        double f[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[r] = A[(q + 4 * r) * 17 + c];
+        MS16_FENCE();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = q + 4 * r;
+            if (row != c) {
+                A[row * 17 + c0] -= f[r] * pa;
+                Ainv[row * 17 + c0] -= f[r] * pw;
+            }
+        }
+        MS16_FENCE();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
+{
+    extern __shared__ double sm[];
+    const int lane = threadIdx.x;
+    constexpr int n = 16, nn = 256, ld = 17, msz = 16 * 17;
+    const Ms16 L{lane & 15, lane >> 4};
+    const int c = L.c, q = L.q;
+    const int ic = blockIdx.x % (p.nf + 1);
+    const int ig = (blockIdx.x / (p.nf + 1)) % p.ng;
+    const int widx = blockIdx.x / ((p.nf + 1) * p.ng);
+    const double pi = 3.141592653589793;
+    double *rc = sm, *tc = rc + msz, *r1 = tc + msz, *t1 = r1 + msz, *mA = t1 + msz, *mB = mA + msz, *mC = mB + msz;
+    double *jc = mC + msz, *j1 = jc + 16, *v0 = j1 + 16, *radg = v0 + 16;
+#define MS_AT(M, i, j) M[(i) * ld + (j)]
+
+    if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // radg[:, ::-1] :765
+    bool defined = false;
+    if (p.lowbc > 0) {  // surface operator first :824-836
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = q + 4 * r, j = c;
+            MS_AT(rc, i, j) = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
+            MS_AT(tc, i, j) = 0.0;
+        }
+        if (lane < n) jc[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];
+        defined = true;
+    }
+    MS16_FENCE();
+    const double *PPL = p.ppl + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
+    const double *PMI = p.pmi + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
+    const double *FC = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp) * nn;   // ppl *= fc (:232)
+    const double rmu_c = 1. / p.mu[c];
+
+    for (int l = 0; l < p.nlay; ++l) {
+        const int k = l;  // look-down: bottom layer first (:842-845)
+        const double taut = p.taus[((size_t)widx * p.ng + ig) * p.nlay + k];
+        const double bc = p.bnu[(size_t)widx * p.nlay + k];
+        double omega = p.omegas[((size_t)widx * p.ng + ig) * p.nlay + k];
+        if (omega < 0) omega = 0.0;
+        if (omega > 1) omega = 1.0;
+        double tauscat = taut * omega;
+        const double taur = p.tauray[(size_t)widx * p.nlay + k];
+        tauscat = tauscat - taur;
+        if (tauscat < 0) tauscat = 0.0;
+        // ---- calc_rtj_matrix :566-647 -> (r1, t1, j1), iscl ------------------------------------------------
+        int iscl = 0;
+        omega = (tauscat + taur) / taut;
+        if (taut == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { MS_AT(r1, q + 4 * r, c) = 0.0; MS_AT(t1, q + 4 * r, c) = (q + 4 * r == c) ? 1.0 : 0.0; }
+            if (lane < n) j1[lane] = 0.0;
+            MS16_FENCE();
+        } else if (omega == 0) {
+            const double tex = -rmu_c * taut;
+            const double tt = (tex > -200.0) ? exp(tex) : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { MS_AT(r1, q + 4 * r, c) = 0.0; MS_AT(t1, q + 4 * r, c) = (q + 4 * r == c) ? tt : 0.0; }
+            if (lane < n) j1[lane] = bc * (1.0 - tt);
+            MS16_FENCE();
+        } else {
+            iscl = 1;
+            const double fr = taur / (tauscat + taur), fs = tauscat / (tauscat + taur);
+            // ---- double1 :321-362: starting (r,t,j) of the 2^-nd sub-layer, built straight in D layout -----
+            double con = omega * pi;
+            con *= (ic == 0) ? 2.0 : 1.0;
+            const int nd = (int)(log2(taut) + 12);   // python int(): truncation toward zero
+            const double tau0 = taut * ((nd >= 1) ? 1.0 / exp2((double)nd) : 1.0);
+            ms_v4f64 bR, bT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = q + 4 * r, j = c, e = i * 16 + j;
+                double a = (p.iray > 0) ? fr * (PPL[(size_t)p.ncont * nn + e] * FC[(size_t)p.ncont * nn + e]) : 0.0;
+                double b = (p.iray > 0) ? fr * PMI[(size_t)p.ncont * nn + e] : 0.0;
+                for (int cc = 0; cc < p.ncont; ++cc) {
+                    const double f = p.lfrac[((size_t)widx * p.ncont + cc) * p.nlay + k];
+                    a += fs * (PPL[(size_t)cc * nn + e] * FC[(size_t)cc * nn + e]) * f;
+                    b += fs * PMI[(size_t)cc * nn + e] * f;
+                }
+                // Gamma++ = M^-1 (E - con P++ C) ;  Gamma+- = M^-1 con P+- C   (C, M^-1 diagonal)
+                const double gpp = (1. / p.mu[i]) * (((i == j) ? 1.0 : 0.0) - (a * p.wtmu[j]) * con);
+                const double gpm = (1. / p.mu[i]) * ((b * p.wtmu[j]) * con);
+                bT[r] = ((i == j) ? 1.0 : 0.0) - tau0 * gpp;
+                bR[r] = tau0 * gpm;
+            }
+            double jv = (ic == 0) ? (1.0 - omega) * bc * tau0 * rmu_c : 0.0;    // j1[c], same in the 4 lanes of c
+            L.store_d(r1, bR); L.store_d(t1, bT);
+            if (q == 0) j1[c] = jv;
+            MS16_FENCE();
+            for (int it = 0; it < nd; ++it) {   // add :275-297
+                double aR[4], aT[4], aC[4], aS[4];
+                L.load_a(r1, aR);
+                const ms_v4f64 bcom = Ms16::mm(aR, bR);                       // r1 r1
+                ms_v4f64 acom;
+                if (Ms16::frob(bR) > 0.1) {
+                    L.store_d(mA, L.eye_plus(bcom, -1.0));
+                    MS16_FENCE();
+                    ms_inv16(mA, mB, lane);                                   // inv(e - bcom)
+                    acom = L.load_d(mB);
+                } else
+                    acom = L.eye_plus(bcom, 1.0);
+                L.load_a(t1, aT);
+                const ms_v4f64 ccom = Ms16::mm(aT, acom);                     // t1 acom
+                L.store_d(mC, ccom);
+                double jcom = 0.0;
+                if (ic == 0) {
+                    jcom = L.mv(aR, j1) + jv;                                 // r1 j1 + j1
+                    if (q == 0) v0[c] = jcom;
+                }
+                MS16_FENCE();
+                L.load_a(mC, aC);
+                const ms_v4f64 rans = Ms16::mm(aC, bR);                       // ccom r1
+                L.store_d(mA, rans);
+                const ms_v4f64 tans = Ms16::mm(aC, bT);                       // ccom t1
+                MS16_FENCE();
+                if (ic == 0) jv = L.mv(aC, v0) + jv;                          // ccom jcom + j1
+                L.load_a(mA, aS);
+                const ms_v4f64 acc = Ms16::mm(aS, bT);                        // rans t1
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bR[r] = bR[r] + acc[r];
+                bT = tans;
+                MS16_FENCE();
+                L.store_d(r1, bR); L.store_d(t1, bT);
+                if (q == 0) j1[c] = jv;
+                MS16_FENCE();
+            }
+        }
+        // ---- combine with the stack below :868-875 ------------------------------------------------------------
+        if (l == 0 && !defined) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { MS_AT(rc, q + 4 * r, c) = MS_AT(r1, q + 4 * r, c); MS_AT(tc, q + 4 * r, c) = MS_AT(t1, q + 4 * r, c); }
+            if (lane < n) jc[lane] = j1[lane];
+            MS16_FENCE();
+        } else if (iscl == 1) {   // addp, scattering layer :486-511 (rsub,tsub,jsub) = (rc,tc,jc)
+            double aRc[4], aT[4], aC[4], aS[4];
+            const ms_v4f64 bR1 = L.load_d(r1), bT1 = L.load_d(t1), bRc = L.load_d(rc), bTc = L.load_d(tc);
+            const double j1v = j1[c];
+            L.load_a(rc, aRc);
+            const ms_v4f64 rsq = Ms16::mm(aRc, bR1);                          // rsub r1
+            ms_v4f64 acom;
+            if (Ms16::frob(rsq) > 0.01) {
+                L.store_d(mA, L.eye_plus(rsq, -1.0));
+                MS16_FENCE();
+                ms_inv16(mA, mB, lane);
+                acom = L.load_d(mB);
+            } else
+                acom = L.eye_plus(rsq, 1.0);
+            L.load_a(t1, aT);
+            const ms_v4f64 ccom = Ms16::mm(aT, acom);                         // t1 acom
+            L.store_d(mC, ccom);
+            const double jcom = L.mv(aRc, j1) + jc[c];                        // rsub j1 + jsub
+            if (q == 0) v0[c] = jcom;
+            MS16_FENCE();
+            L.load_a(mC, aC);
+            const ms_v4f64 rans = Ms16::mm(aC, bRc);                          // ccom rsub
+            L.store_d(mA, rans);
+            const ms_v4f64 tans = Ms16::mm(aC, bTc);                          // ccom tsub
+            MS16_FENCE();
+            const double jans = L.mv(aC, v0) + j1v;                           // ccom jcom + j1
+            L.load_a(mA, aS);
+            const ms_v4f64 bcomm = Ms16::mm(aS, bT1);                         // rans t1
+            ms_v4f64 rnew;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rnew[r] = bR1[r] + bcomm[r];
+            MS16_FENCE();
+            L.store_d(rc, rnew); L.store_d(tc, tans);
+            if (q == 0) jc[c] = jans;
+            MS16_FENCE();
+        } else {                  // addp, non-scattering layer :513-530
+            double aRc[4];
+            L.load_a(rc, aRc);
+            const double jcom = L.mv(aRc, j1) + jc[c];
+            const double tcc = MS_AT(t1, c, c);
+            const double jn = j1[c] + tcc * jcom;
+            ms_v4f64 tn, rn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = q + 4 * r;
+                const double ta = MS_AT(t1, i, i);
+                tn[r] = MS_AT(tc, i, c) * ta;
+                rn[r] = MS_AT(rc, i, c) * ta * tcc;
+            }
+            MS16_FENCE();
+            L.store_d(tc, tn); L.store_d(rc, rn);
+            if (q == 0) jc[c] = jn;
+            MS16_FENCE();
+        }
+    }
+    if (ic != 0 && lane < n) jc[lane] = 0.0;   // :881-882
+    __syncthreads();
+    // ---- per path: the four (mu0, mu) samples and the bilinear interpolation :886-945 ---------------------------
+    if (lane < p.ngeom) {
+        const int ipath = lane;
+        const double sol_ang = p.sol_ang[ipath], emiss_ang = p.emiss_ang[ipath];
+        double zmu0, solar1;
+        if (sol_ang > 90.0) { zmu0 = cos((180 - sol_ang) * pi / 180.0); solar1 = p.solar[widx] * 0.0; }
+        else { zmu0 = cos(sol_ang * pi / 180.0); solar1 = p.solar[widx]; }
+        const double zmu = cos(emiss_ang * pi / 180.0);
+        int isol = 0, iemm = 0;
+        for (int j = 0; j < n - 1; ++j) if (zmu0 <= p.mu[j] && zmu0 > p.mu[j + 1]) isol = j;
+        if (zmu0 <= p.mu[n - 1]) isol = n - 2;
+        for (int j = 0; j < n - 1; ++j) if (zmu <= p.mu[j] && zmu > p.mu[j + 1]) iemm = j;
+        if (zmu <= p.mu[n - 1]) iemm = n - 2;
+        const double u = (p.mu[isol] - zmu0) / (p.mu[isol] - p.mu[isol + 1]);
+        const double t = (p.mu[iemm] - zmu) / (p.mu[iemm] - p.mu[iemm + 1]);
+        double yx[4];
+        int ico = 0;
+        for (int imu0 = isol; imu0 < isol + 2; ++imu0) {
+            const double s0 = solar1 / (2.0 * pi * p.wtmu[imu0]);
+            for (int imu = iemm; imu < iemm + 2; ++imu) {
+                double bcom = 0.0;   // (T utmi)[imu], utmi = radg for ic == 0 else 0
+                if (ic == 0) for (int kk = 0; kk < n; ++kk) bcom += MS_AT(tc, imu, kk) * radg[kk];
+                yx[ico++] = (MS_AT(rc, imu, imu0) * s0 + bcom) + jc[imu];
+            }
+        }
+        double drad = ((1 - t) * (1 - u) * yx[0] + t * (1 - u) * yx[1] + t * u * yx[3] + (1 - t) * u * yx[2]) *
+                      cos(ic * p.aphi[ipath] * pi / 180.0);
+        if (ic > 0) drad *= 2;
+        p.drad[(((size_t)widx * p.ng + ig) * (p.nf + 1) + ic) * p.ngeom + ipath] = drad;
+    }
+#undef MS_AT
 }
 
 // ---- Fourier sum with the reference's convergence early-out :903-958 -----------------------------------------

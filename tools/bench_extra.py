@@ -18,8 +18,22 @@ def timeit(f, n=3):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None       # "grad" | "ms" | "lbl" | "layer"
     eng = pkg.AnsfmEngine(0)
     out = {}
+    rng = np.random.default_rng(0)
+    if only in (None, "grad"):
+        bench_grad(eng, out)
+    if only in (None, "ms"):
+        bench_ms(eng, out, rng)
+    if only in (None, "lbl"):
+        bench_lbl(eng, out, rng)
+    if only in (None, "layer"):
+        bench_layer(eng, out)
+    print(json.dumps(out, indent=1))
+
+
+def bench_grad(eng, out):
     # ---- analytic Jacobian at C2 ------------------------------------------------------------------
     W, G, S, L, NP, NT = 10000, 20, 8, 100, 20, 15
     _, delg = syn.gauss_legendre_01(G, True)
@@ -37,8 +51,10 @@ def main():
     k = eng.last_kernel_ms()
     out["cirsradg_C2"] = {"wall_s_host_ptr": t, "overlapg_kernel_ms": k["overlap_ms"], "rtg_kernel_ms": k["rt_ms"],
                           "note": "W=1e4,L=100,S=8,G=20, NPAR=10: SPECOUT + dSPECOUT(1e4,10,100,1) + dTSURF"}
+
+
+def bench_ms(eng, out, rng):
     # ---- multiple scattering, C4-like -----------------------------------------------------------------
-    rng = np.random.default_rng(0)
     Wm, Gm, Lm, M, NF, NC = 256, 20, 100, 16, 8, 1
     x, w = np.polynomial.legendre.leggauss(2 * M)
     mu1 = np.sort(np.abs(x[x > 0])); wt1 = w[x > 0][np.argsort(np.abs(x[x > 0]))]
@@ -59,6 +75,9 @@ def main():
     out["scloud11wave_C4like"] = {"wall_s": t, "waves": Wm, "g": Gm, "layers": Lm, "nmu": M, "nf": NF,
                                   "approx_flops": flops, "TFLOPs": flops / t / 1e12,
                                   "scaled_to_W1e4_s": t * 1e4 / Wm}
+
+
+def bench_lbl(eng, out, rng):
     # ---- runtime LBL, reduced C5 ---------------------------------------------------------------------------
     nw, N, Ll = 200000, 20000, 5
     wn = 2000.0 + 1e-3 * np.arange(nw)
@@ -73,6 +92,9 @@ def main():
     evals = float(N) * (150.0 / 1e-3) * Ll * (200.0 / 350.0)     # lines whose window overlaps the grid, roughly
     out["lbl_runtime_reducedC5"] = {"wall_s": t, "grid": nw, "lines": N, "layers": Ll, "approx_profile_evals": evals,
                                     "Gevals_per_s": evals / t / 1e9}
+
+
+def bench_layer(eng, out):
     # ---- batched layering ---------------------------------------------------------------------------------------
     n, NPRO, V, D, NL = 201, 120, 8, 1, 100
     H = np.linspace(0, 6e5, NPRO); P = 1e6 * np.exp(-H / 3e4); T = 150 + 50 * np.sin(H / 1e5)
@@ -81,7 +103,6 @@ def main():
     BH = np.linspace(0, 5.9e5, NL)
     t = timeit(lambda: eng.layer_average(7.1e7, rep(H), rep(P), rep(T), None, rep(VM), rep(DU), None, BH, None, LAYINT=1, NINT=101))
     out["layer_average_batch"] = {"wall_s": t, "states": n, "layers": NL, "nint": 101, "states_layers_per_s": n * NL / t}
-    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
