@@ -953,13 +953,10 @@ int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const
             hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, 1), dim3(256), 0, ctx->stream, pr);
         }
         HIPCHK(hipGetLastError());
+        // one sequential walk per scatterer, all scatterers side by side (Rayleigh = slot ncont)
         p.hansen_comp0 = 0;
-        if (ncont > 0) hipLaunchKernelGGL(k_ms_hansen_seq, dim3((unsigned)ncont), dim3(64), 0, ctx->stream, p);
-        if (iray > 0) {
-            MsParams pr = p;
-            pr.hansen_comp0 = ncont;
-            hipLaunchKernelGGL(k_ms_hansen_seq, dim3(1), dim3(64), 0, ctx->stream, pr);
-        }
+        if (nmu == 16) hipLaunchKernelGGL(k_ms_hansen_seq<16>, dim3((unsigned)ncomp_run), dim3(64), 0, ctx->stream, p);
+        else hipLaunchKernelGGL(k_ms_hansen_seq<0>, dim3((unsigned)ncomp_run), dim3(64), 0, ctx->stream, p);
         HIPCHK(hipGetLastError());
     }
     const dim3 cgrid((unsigned)((size_t)nwave * ng * (nf + 1)));

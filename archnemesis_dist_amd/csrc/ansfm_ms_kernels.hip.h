@@ -114,57 +114,84 @@ __global__ __launch_bounds__(256) void k_ms_phase(MsParams p)
 // next (g, wave) in loop order (:780-815); the normalisation has no unique solution, so the result depends
 // on that history (a 1e-4 effect on the radiance).  Reproduced: one wavefront per scatterer walks the
 // (g outer, wave inner) sequence and stores fc[g][wave][comp][nmu*nmu].
+template <int NMU>   // NMU = 16: compile-time size (unrolled sums, all LDS reads in flight); 0: any nmu <= 20
 __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
 {
-    __shared__ double ppl[kMsMaxMu * kMsMaxMu], pmi[kMsMaxMu * kMsMaxMu], fc[kMsMaxMu * kMsMaxMu];
+    __shared__ double ppl_s[2][kMsMaxMu * kMsMaxMu], pmi_s[2][kMsMaxMu * kMsMaxMu], fc[kMsMaxMu * kMsMaxMu];
     __shared__ double rsum[kMsMaxMu], tsum[kMsMaxMu];
-    __shared__ double test_s;
     const int comp = blockIdx.x + p.hansen_comp0;
-    const int n = p.nmu, nn = n * n, tid = threadIdx.x;
+    const int n = NMU ? NMU : p.nmu, nn = n * n, tid = threadIdx.x;
     const double x1 = 2.0 * 3.141592653589793;
+    constexpr int NE = NMU ? (NMU * NMU + 63) / 64 : (20 * 20 + 63) / 64;   // matrix elements per lane
+    double nppl[NE], npmi[NE];
+    // The walk is latency-bound: matrices are fetched two iterations ahead (registers), staged into the
+    // other LDS buffer one iteration ahead.
+    auto fetch = [&](int widx) {
+        const double *gppl = p.ppl + (((size_t)widx * (p.nf + 1) + 0) * p.ncomp + comp) * nn;
+        const double *gpmi = p.pmi + (((size_t)widx * (p.nf + 1) + 0) * p.ncomp + comp) * nn;
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            const int e = tid + 64 * r;
+            if (e < nn) { nppl[r] = gppl[e]; npmi[r] = gpmi[e]; }
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            const int e = tid + 64 * r;
+            if (e < nn) { ppl_s[buf][e] = nppl[r]; pmi_s[buf][e] = npmi[r]; }
+        }
+    };
     for (int e = tid; e < nn; e += 64) fc[e] = 1.0;
-    __syncthreads();
-    for (int ig = 0; ig < p.ng; ++ig)
-        for (int widx = 0; widx < p.nwave; ++widx) {
-            const double *gppl = p.ppl + (((size_t)widx * (p.nf + 1) + 0) * p.ncomp + comp) * nn;
-            const double *gpmi = p.pmi + (((size_t)widx * (p.nf + 1) + 0) * p.ncomp + comp) * nn;
-            for (int e = tid; e < nn; e += 64) { ppl[e] = gppl[e]; pmi[e] = gpmi[e]; }
-            __syncthreads();
+    const long total = (long)p.ng * p.nwave;
+    fetch(0);
+    stage(0);
+    if (total > 1) fetch(1 % p.nwave);
+    int ig = 0, widx = 0;
+    for (long iter = 0; iter < total; ++iter) {
+        const int buf = (int)(iter & 1);
+        const double *ppl = ppl_s[buf], *pmi = pmi_s[buf];
+        if (iter + 1 < total) stage(buf ^ 1);                   // data of iter+1 (its readers are two syncs away)
+        if (iter + 2 < total) fetch((int)((iter + 2) % p.nwave));
+        __syncthreads();
+        double rs = 0.0;
+        if (tid < n) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < n; ++i) s += pmi[i * n + tid] * p.wtmu[i];
+            rs = s * x1;
+            rsum[tid] = rs;
+        }
+        for (int niter = 0; niter < 10000; ++niter) {
+            double dev = 0.0;
             if (tid < n) {
                 double s = 0.0;
-                for (int i = 0; i < n; ++i) s += pmi[i * n + tid] * p.wtmu[i];
-                rsum[tid] = s * x1;
+#pragma unroll
+                for (int i = 0; i < n; ++i) s += ppl[i * n + tid] * p.wtmu[i] * fc[i * n + tid];
+                const double ts = s * x1;
+                tsum[tid] = ts;
+                dev = fabs(rs + ts - 1.0);
             }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_xor(dev, off, 64));
             __syncthreads();
-            for (int niter = 0; niter < 10000; ++niter) {
-                if (tid < n) {
-                    double s = 0.0;
-                    for (int i = 0; i < n; ++i) s += ppl[i * n + tid] * p.wtmu[i] * fc[i * n + tid];
-                    tsum[tid] = s * x1;
+            if (dev < 1e-14) break;
+            for (int e = tid; e < nn; e += 64) {
+                const int i = e / n, j = e % n;
+                if (i <= j) {
+                    const double xj = (1.0 - rsum[j]) / tsum[j], xi = (1.0 - rsum[i]) / tsum[i];
+                    const double v = 0.5 * (fc[i * n + j] * xj + fc[j * n + i] * xi);
+                    fc[i * n + j] = v;
+                    fc[j * n + i] = v;
                 }
-                __syncthreads();
-                if (tid == 0) {
-                    double t = 0.0;
-                    for (int j = 0; j < n; ++j) { double v = fabs(rsum[j] + tsum[j] - 1.0); if (v > t) t = v; }
-                    test_s = t;
-                }
-                __syncthreads();
-                if (test_s < 1e-14) break;
-                for (int e = tid; e < nn; e += 64) {
-                    const int i = e / n, j = e % n;
-                    if (i <= j) {
-                        const double xj = (1.0 - rsum[j]) / tsum[j], xi = (1.0 - rsum[i]) / tsum[i];
-                        const double v = 0.5 * (fc[i * n + j] * xj + fc[j * n + i] * xi);
-                        fc[i * n + j] = v;
-                        fc[j * n + i] = v;
-                    }
-                }
-                __syncthreads();
             }
-            double *ofc = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp + comp) * nn;
-            for (int e = tid; e < nn; e += 64) ofc[e] = fc[e];
             __syncthreads();
         }
+        double *ofc = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp + comp) * nn;
+        for (int e = tid; e < nn; e += 64) ofc[e] = fc[e];
+        if (++widx == p.nwave) { widx = 0; ++ig; }
+        __syncthreads();
+    }
 }
 
 // ---- small dense helpers on LDS matrices (one wavefront = one block), any nmu <= 20 -------------------
