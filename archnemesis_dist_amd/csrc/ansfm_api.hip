@@ -57,7 +57,7 @@ struct ansfm_ctx {
 
     // workspaces
     DevBuf li, tau, scratch, cont_t, tmp_in, tmp_out, misc;
-    DevBuf gscratch, dkbuf, trold_ws, dspec_i, dcont_t, tmp_in2, tmp_out2, lbl_li;
+    DevBuf gscratch, perm, dkbuf, trold_ws, dspec_i, dcont_t, tmp_in2, tmp_out2, lbl_li;
     DevBuf hb[24];  // staging buffers of the host-pointer entry points
     int last_n = 0, last_L = 0;
 
@@ -666,7 +666,7 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     pg.dk = dk;
     const int NP1 = S + 1;
     if (NP1 > 21) FAIL(ANSFM_ERR_UNSUPPORTED, "gradient path supports at most 20 spectroscopic gases");
-    const size_t lds = (size_t)G * kWave * (3 * sizeof(double)) + (size_t)(2 * kMaxG + 2) * sizeof(double);
+    const size_t lds = (size_t)(3 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
@@ -674,17 +674,31 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     long grid = (long)ctx->num_cus * per_cu;
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
-    HIPCHK(ctx->scratch.reserve((size_t)grid * 2 * G * kWave * sizeof(double)));
-    HIPCHK(ctx->gscratch.reserve((size_t)grid * (2 + 2 * (size_t)NP1) * G * kWave * sizeof(double)));
+    HIPCHK(ctx->scratch.reserve((size_t)grid * 6 * (G + 1) * kWave * sizeof(double)));
+    HIPCHK(ctx->gscratch.reserve((size_t)grid * (3 + 2 * (size_t)NP1) * G * kWave * sizeof(double)));
+    HIPCHK(ctx->perm.reserve((size_t)grid * ((G * G + 3) / 4) * kWave * sizeof(unsigned long long)));
     p.scratch = ctx->scratch.as<double>();
     pg.gscratch = ctx->gscratch.as<double>();
-#define LAUNCH_OVG(MP, FK)                                                                                  \
-    hipLaunchKernelGGL((k_ck_overlapg<5, MP, FK>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg)
-    if (from_k) {
-        if (NP1 <= 5) LAUNCH_OVG(5, true); else if (NP1 <= 9) LAUNCH_OVG(9, true); else LAUNCH_OVG(21, true);
-    } else {
-        if (NP1 <= 5) LAUNCH_OVG(5, false); else if (NP1 <= 9) LAUNCH_OVG(9, false); else LAUNCH_OVG(21, false);
+    pg.perm = ctx->perm.as<unsigned long long>();
+    p.tile_counter = reinterpret_cast<unsigned int *>(ctx->d_flag.as<int>() + 4);
+    HIPCHK(hipMemsetAsync(p.tile_counter, 0, 8 * sizeof(unsigned int), ctx->stream));
+#define LAUNCH_OVG(D, FK)                                                                                           \
+    do {                                                                                                            \
+        if (ctx->delg_f32)                                                                                          \
+            hipLaunchKernelGGL((k_ck_overlapg<D, FK, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);  \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_ck_overlapg<D, FK, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg); \
+    } while (0)
+#define LAUNCH_OVG_D(FK)                                                                                            \
+    switch (p.depth) {                                                                                              \
+    case 1: LAUNCH_OVG(1, FK); break;                                                                               \
+    case 2: LAUNCH_OVG(2, FK); break;                                                                               \
+    case 3: LAUNCH_OVG(3, FK); break;                                                                               \
+    case 4: LAUNCH_OVG(4, FK); break;                                                                               \
+    default: LAUNCH_OVG(5, FK); break;                                                                              \
     }
+    if (from_k) { LAUNCH_OVG_D(true); } else { LAUNCH_OVG_D(false); }
+#undef LAUNCH_OVG_D
 #undef LAUNCH_OVG
     HIPCHK(hipGetLastError());
     return ANSFM_OK;

@@ -237,6 +237,12 @@ struct OverlapParams {
     double g_ord[kMaxG + 2];  // [0, cumsum(del_g)] (float32 cumsum when delg_f32), g_ord[G]=1, +inf
 };
 
+// Table reads of one gas for one (64-wavenumber, layer) tile.  The loads of kLoadBatch g-ordinates (4 corner
+// rows each) are all issued before the first value is used: one memory round trip per batch instead of one per
+// g-ordinate (a wave has at most one sibling on its SIMD to hide it behind).  Indices are clamped, not
+// predicated, so the batch stays branch-free.
+constexpr int kLoadBatch = 10;
+
 template <bool FROM_K>
 __device__ __forceinline__ void load_gas(const OverlapParams &p, const LayerInterp &q, int m, int l,
                                          int s, int nu, double *DST, int lane, bool &unsorted)
@@ -246,11 +252,21 @@ __device__ __forceinline__ void load_gas(const OverlapParams &p, const LayerInte
     double prev = -__builtin_inf();
     if constexpr (FROM_K) {
         const double *src = p.kin + (((size_t)s * p.L + l) * G) * p.Wpad + nu;
-        for (int g = 0; g < G; ++g) {
-            double kk = src[(size_t)g * p.Wpad] * amt;
-            DST[g * kWave + lane] = kk;
-            unsorted |= (kk < prev);
-            prev = kk;
+        for (int g0 = 0; g0 < G; g0 += kLoadBatch) {
+            double r[kLoadBatch];
+#pragma unroll
+            for (int k = 0; k < kLoadBatch; ++k) {
+                const int gi = (g0 + k < G) ? g0 + k : G - 1;
+                r[k] = src[(size_t)gi * p.Wpad];
+            }
+#pragma unroll
+            for (int k = 0; k < kLoadBatch; ++k)
+                if (g0 + k < G) {
+                    const double kk = r[k] * amt;
+                    DST[(g0 + k) * kWave + lane] = kk;
+                    unsorted |= (kk < prev);
+                    prev = kk;
+                }
         }
     } else {
         const size_t strideT = (size_t)p.S * G * p.Wpad;
@@ -259,14 +275,26 @@ __device__ __forceinline__ void load_gas(const OverlapParams &p, const LayerInte
         const double *c2 = p.lnK + ((size_t)q.ipl * p.NT + q.ith) * strideT + off;
         const double *c3 = p.lnK + ((size_t)q.iph * p.NT + q.itl) * strideT + off;
         const double *c4 = p.lnK + ((size_t)q.iph * p.NT + q.ith) * strideT + off;
-        for (int g = 0; g < G; ++g) {
-            size_t go = (size_t)g * p.Wpad;
-            // streamed once per tile: non-temporal so the table does not push the merge scratch out of L2
-            double kk = interp_k(__builtin_nontemporal_load(c1 + go), __builtin_nontemporal_load(c2 + go),
-                                 __builtin_nontemporal_load(c3 + go), __builtin_nontemporal_load(c4 + go), q.v, q.u) * amt;
-            DST[g * kWave + lane] = kk;
-            unsorted |= (kk < prev);
-            prev = kk;
+        for (int g0 = 0; g0 < G; g0 += kLoadBatch) {
+            double r1[kLoadBatch], r2[kLoadBatch], r3[kLoadBatch], r4[kLoadBatch];
+#pragma unroll
+            for (int k = 0; k < kLoadBatch; ++k) {
+                const int gi = (g0 + k < G) ? g0 + k : G - 1;
+                const size_t go = (size_t)gi * p.Wpad;
+                // streamed once per tile: non-temporal so the table does not push the merge scratch out of L2
+                r1[k] = __builtin_nontemporal_load(c1 + go);
+                r2[k] = __builtin_nontemporal_load(c2 + go);
+                r3[k] = __builtin_nontemporal_load(c3 + go);
+                r4[k] = __builtin_nontemporal_load(c4 + go);
+            }
+#pragma unroll
+            for (int k = 0; k < kLoadBatch; ++k)
+                if (g0 + k < G) {
+                    const double kk = interp_k(r1[k], r2[k], r3[k], r4[k], q.v, q.u) * amt;
+                    DST[(g0 + k) * kWave + lane] = kk;
+                    unsorted |= (kk < prev);
+                    prev = kk;
+                }
         }
     }
 }
@@ -348,8 +376,8 @@ struct WalkState {
     int ig;
 };
 
-template <int DEPTH>
-__device__ __forceinline__ void merge_walk(const MergeElem<DEPTH> &e, WalkState &ws, double *rec, const double *GORD,
+template <int DEPTH, bool REC_CODE>
+__device__ __forceinline__ bool merge_walk(const MergeElem<DEPTH> &e, WalkState &ws, double *rec, const double *GORD,
                                            int lane)
 {
     const double cv = e.ai + e.bc;
@@ -357,22 +385,28 @@ __device__ __forceinline__ void merge_walk(const MergeElem<DEPTH> &e, WalkState 
     const double gdn = ws.gd + w;
     const double cw = cv * w;
     double kn = ws.kacc + cw, sn = ws.sum1 + w;
-    if (!(gdn < ws.gnext)) {                    // this element straddles the bin boundary
+    const bool cross = !(gdn < ws.gnext);
+    if (cross) {                                // this element straddles the bin boundary
         double *rp = rec + (size_t)ws.ig * 6 * kWave + lane;
         rp[0] = ws.kacc; rp[kWave] = ws.sum1; rp[2 * kWave] = cw; rp[3 * kWave] = w;
         rp[4 * kWave] = ws.gd;
+        if constexpr (REC_CODE)   // gradient kernel: which element closed the bin
+            rp[5 * kWave] = __longlong_as_double((long long)(e.ci | ((e.np - 1) << 5)));
         kn = 0.0; sn = 0.0;
         ws.ig += 1;
         ws.gnext = GORD[ws.ig + 1];             // GORD[G+1] = +inf: nothing crosses after the last bin
     }
     ws.kacc = kn; ws.sum1 = sn;
     ws.gd = gdn;
+    return cross;
 }
 
-template <int DEPTH, bool W32>
-__device__ __forceinline__ void merge_step(MergeElem<DEPTH> &e, MergeElem<DEPTH> &en, WalkState &ws, int G, int lane,
-                                           const double *A, const double *B, double *NV, const double *DG,
-                                           const double *GORD, double *rec)
+// Returns the consumed element's (row, column) and whether it closed a bin, as 16 bits: the gradient kernel
+// records them and replays the sorted order for the gradient rows.
+template <int DEPTH, bool W32, bool REC_CODE = false>
+__device__ __forceinline__ unsigned merge_step(MergeElem<DEPTH> &e, MergeElem<DEPTH> &en, WalkState &ws, int G,
+                                               int lane, const double *A, const double *B, double *NV,
+                                               const double *DG, const double *GORD, double *rec)
 {
     // 1. replay the tree path of the popped leaf with the row's next element
     double car = pack_key11(e.ai + e.bn, e.ci, e.np);
@@ -386,8 +420,46 @@ __device__ __forceinline__ void merge_step(MergeElem<DEPTH> &e, MergeElem<DEPTH>
     // 2. fetch the operands of the new winner (LDS reads in flight during the walk)
     merge_fetch<DEPTH, W32>(car, G, lane, A, B, NV, DG, en);
     // 3. rank walk on the element just consumed
-    merge_walk<DEPTH>(e, ws, rec, GORD, lane);
+    const bool cross = merge_walk<DEPTH, REC_CODE>(e, ws, rec, GORD, lane);
+    return (unsigned)(e.ci | ((e.np - 1) << 5) | (cross ? 0x8000 : 0));
 }
+
+// Dynamic tile queues.  With 5 resident waves per CU one SIMD hosts two waves that run slower than the solo
+// ones; static striding would make the launch wait for them.  One relaxed atomic per tile (~2800*7 merge steps
+// of work) -- every wave exits when the counters pass the tile counts.
+// Eight queues, queue q = wavenumber tiles vt with vt % 8 == q (layer fastest): the layers of one wavenumber
+// tile share k-table corner rows, so they are kept on one XCD's L2.  A wave starts on the queue of the XCD it
+// runs on (HW_REG_XCC_ID; affinity only, any placement is correct) and steals from the others when its own
+// is empty.
+struct TileQueue {
+    int myq, qoff;
+    __device__ __forceinline__ void init()
+    {
+        myq = (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 7);
+        qoff = 0;
+    }
+    __device__ __forceinline__ bool next(const OverlapParams &p, int lane, int &vt, int &m, int &l)
+    {
+        const int NVT = p.Wpad / kWave;
+        while (qoff < 8) {
+            const int qq = (myq + qoff) & 7;
+            const int nvt_q = (NVT - qq + 7) / 8;                     // tiles vt = qq, qq+8, ...
+            const long nq = (long)p.n_models * nvt_q * p.L;
+            unsigned int tq = 0;
+            if (lane == 0 && nq > 0) tq = atomicAdd(p.tile_counter + qq, 1u);
+            const long t = (long)__builtin_amdgcn_readfirstlane(tq);
+            if (nq > 0 && t < nq) {
+                l = (int)(t % p.L);
+                const long r = t / p.L;
+                vt = qq + 8 * (int)(r % nvt_q);
+                m = (int)(r / nvt_q);
+                return true;
+            }
+            ++qoff;
+        }
+        return false;
+    }
+};
 
 template <int DEPTH, bool FROM_K, bool W32>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_ck_overlap(OverlapParams p)
@@ -411,40 +483,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
 
     // per-block scratch: closed-bin records [bin][6][lane]: kacc, sum1, cw, w, gd (slot 5 unused)
     double *rec = p.scratch + (size_t)blockIdx.x * 6 * G * kWave;
-    const int NVT = p.Wpad / kWave;
-    const long ntiles = (long)p.n_models * NVT * p.L;
-
-    // Dynamic tile queue: with 5 resident waves per CU one SIMD hosts two waves that run slower than the
-    // solo ones; static striding would make the launch wait for them.  One relaxed atomic per tile (~2800*7
-    // merge steps of work) -- every wave exits when the counter passes ntiles.
-    // Eight queues, queue q = wavenumber tiles vt with vt % 8 == q (layer fastest): the layers of one
-    // wavenumber tile share k-table corner rows, so they are kept on one XCD's L2.  A wave starts on the queue
-    // of the XCD it runs on (HW_REG_XCC_ID; affinity only, any placement is correct) and steals from the others
-    // when its own is empty.
-    const int myq = (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 7);
-    (void)ntiles;
-    int qoff = 0;
+    TileQueue tq;
+    tq.init();
     for (;;) {
-        long tile = -1;
         int vt = 0, m = 0, l = 0;
-        while (qoff < 8) {
-            const int qq = (myq + qoff) & 7;
-            const int nvt_q = (NVT - qq + 7) / 8;                     // tiles vt = qq, qq+8, ...
-            const long nq = (long)p.n_models * nvt_q * p.L;
-            unsigned int tq = 0;
-            if (lane == 0 && nq > 0) tq = atomicAdd(p.tile_counter + qq, 1u);
-            const long t = (long)__builtin_amdgcn_readfirstlane(tq);
-            if (nq > 0 && t < nq) {
-                l = (int)(t % p.L);
-                const long r = t / p.L;
-                vt = qq + 8 * (int)(r % nvt_q);
-                m = (int)(r / nvt_q);
-                tile = t;
-                break;
-            }
-            ++qoff;
-        }
-        if (tile < 0) break;
+        if (!tq.next(p, lane, vt, m, l)) break;
         const int nu = vt * kWave + lane;
         LayerInterp q;
         if constexpr (!FROM_K) q = p.li[(size_t)m * p.L + l];
@@ -483,27 +526,41 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 // ---- resolve the bins --------------------------------------------------------------------
                 double ck = 0.0, cs = 0.0;   // (1-frac) share carried into the next bin
                 const int ig = ws.ig;
-                for (int b = 0; b < G; ++b) {
-                    double outv = 0.0;
-                    if (b < ig) {
-                        const double *rp = rec + (size_t)b * 6 * kWave + lane;
-                        const double ka = rp[0], s1 = rp[kWave], cw = rp[2 * kWave], w = rp[3 * kWave];
-                        // a crossing at the very first element (nothing accumulated yet) sees python's gdist[-1]
-                        const double gd0 = rp[4 * kWave];
-                        const double gprev = (b == 0 && s1 == 0.0) ? wtot : gd0;
-                        const double gdn = gd0 + w;                 // the same add the walk made
-                        const double frac = (GORD[b + 1] - gprev) / (gdn - gprev);
-                        const double kb = (ck + ka) + frac * cw;
-                        const double sb = (cs + s1) + frac * w;
-                        outv = kb / sb;
-                        ck = (1.0 - frac) * cw;
-                        cs = (1.0 - frac) * w;
-                    } else if (b == ig) {
-                        // trailing `if ig == ng-1` (:6171); an unfinished earlier bin stays un-normalised
-                        const double kb = ck + ws.kacc, sb = cs + ws.sum1;
-                        outv = (b == G - 1) ? kb / sb : kb;
+                constexpr int kRB = 5;       // records of kRB bins are fetched together (one round trip)
+                for (int b0 = 0; b0 < G; b0 += kRB) {
+                    double rka[kRB], rs1[kRB], rcw[kRB], rw[kRB], rgd[kRB];
+#pragma unroll
+                    for (int k = 0; k < kRB; ++k) {
+                        const int bi = (b0 + k < G) ? b0 + k : G - 1;
+                        const double *rp = rec + (size_t)bi * 6 * kWave + lane;
+                        rka[k] = rp[0]; rs1[k] = rp[kWave]; rcw[k] = rp[2 * kWave]; rw[k] = rp[3 * kWave];
+                        rgd[k] = rp[4 * kWave];
                     }
-                    A[b * kWave + lane] = outv;
+#pragma unroll
+                    for (int k = 0; k < kRB; ++k) {
+                        const int b = b0 + k;
+                        if (b < G) {
+                            double outv = 0.0;
+                            if (b < ig) {
+                                const double ka = rka[k], s1 = rs1[k], cw = rcw[k], w = rw[k];
+                                // a crossing at the very first element (nothing accumulated yet) sees python's gdist[-1]
+                                const double gd0 = rgd[k];
+                                const double gprev = (b == 0 && s1 == 0.0) ? wtot : gd0;
+                                const double gdn = gd0 + w;                 // the same add the walk made
+                                const double frac = (GORD[b + 1] - gprev) / (gdn - gprev);
+                                const double kb = (ck + ka) + frac * cw;
+                                const double sb = (cs + s1) + frac * w;
+                                outv = kb / sb;
+                                ck = (1.0 - frac) * cw;
+                                cs = (1.0 - frac) * w;
+                            } else if (b == ig) {
+                                // trailing `if ig == ng-1` (:6171); an unfinished earlier bin stays un-normalised
+                                const double kb = ck + ws.kacc, sb = cs + ws.sum1;
+                                outv = (b == G - 1) ? kb / sb : kb;
+                            }
+                            A[b * kWave + lane] = outv;
+                        }
+                    }
                 }
             }
         }
@@ -515,17 +572,27 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
 
 // ------------------------------------------------------------------------------------------------
 // K1g+K2g fused: calc_kg + k_overlapg/rankg (ForwardModel_0.py:5842-6026).   "ck_overlapg"
-// Same streaming merge; the gradient rows random_grad[iloop,:n] (:5918-5921, :5946-5949) of the
-// element being consumed are formed on the fly from the previous stage's dk_g_param rows
-// (D[p][g], global ping-pong workspace, gathered by row index) and the new gas's k / dkdT*amount,
-// and accumulated per bin exactly like rankg (:6002-6025).  Slot bookkeeping of the skip
-// branches (:5897-5937) is reproduced, including the stale slots they leave behind.
+//
+// rankg accumulates, per output bin, weight * gradient-row of every element in sorted order
+// (:6002-6025).  The gradient row of element (i, j) is (:5918-5921, :5946-5949)
+//      slot pp <= igas : D_old[pp][i]          (previous stage's dk_g_param, by ROW)
+//      slot igas+1     : k_new[j]              (by COLUMN)
+//      slot igas+2     : D_old[igas+1][i] + dkdT_new[j]*amount
+// so every slot is a weighted gather of a G-vector along the sorted order.  The merge runs ONCE (the
+// forward kernel's loop) and records the order as 16 bits per step; the slots are then produced by
+// replaying that order with up to three G-vectors staged in the LDS the merge no longer needs
+// (gathers out of LDS [index][lane] are conflict-free; out of global memory they touch ~40 cache
+// lines per wave-load).  Bin boundaries are deferred exactly like the forward walk: the replay stores the
+// raw partial sums, a uniform 20-iteration pass applies frac / (1-frac) carry / normalisation.
+// Slot bookkeeping of the skip branches (:5897-5937) is reproduced, including the stale slots they
+// leave behind.
 // ------------------------------------------------------------------------------------------------
 struct OverlapGParams {
-    OverlapParams o;
-    const double *dkin;   // FROM_K: dkdT[S][L][G][Wpad]
-    double *dk;           // out [n][L][S+1][G][Wpad]
-    double *gscratch;     // [gridDim.x][ (2 + 2*(S+1)) ][G][64]   KRB, DTB, Dbuf0, Dbuf1
+    OverlapParams o;          // o.scratch: [grid][G+1][6][64] bin records
+    const double *dkin;       // FROM_K: dkdT[S][L][G][Wpad]
+    double *dk;               // out [n][L][S+1][G][Wpad]
+    double *gscratch;         // [grid][2 + 2*(S+1) + 1][G][64]   KRB, DTB, Dbuf0, Dbuf1, Asave
+    unsigned long long *perm; // [grid][ceil(G*G/4)][64]: four 16-bit step codes per word
 };
 
 template <bool FROM_K>
@@ -538,15 +605,25 @@ __device__ __forceinline__ void load_gas_g(const OverlapGParams &pg, const Layer
     double prev = -__builtin_inf();
     if constexpr (FROM_K) {
         const size_t base = (((size_t)s * p.L + l) * G) * p.Wpad + nu;
-        for (int g = 0; g < G; ++g) {
-            const double kraw = p.kin[base + (size_t)g * p.Wpad];
-            const double dkr = pg.dkin[base + (size_t)g * p.Wpad];
-            const double kk = kraw * amt;
-            DST[g * kWave + lane] = kk;
-            KR[g * kWave + lane] = kraw;
-            DT[g * kWave + lane] = dkr * amt;
-            unsorted |= (kk < prev);
-            prev = kk;
+        for (int g0 = 0; g0 < G; g0 += kLoadBatch) {
+            double r1[kLoadBatch], r2[kLoadBatch];
+#pragma unroll
+            for (int k = 0; k < kLoadBatch; ++k) {
+                const int gi = (g0 + k < G) ? g0 + k : G - 1;
+                r1[k] = p.kin[base + (size_t)gi * p.Wpad];
+                r2[k] = pg.dkin[base + (size_t)gi * p.Wpad];
+            }
+#pragma unroll
+            for (int k = 0; k < kLoadBatch; ++k)
+                if (g0 + k < G) {
+                    const int g = g0 + k;
+                    const double kk = r1[k] * amt;
+                    DST[g * kWave + lane] = kk;
+                    KR[g * kWave + lane] = r1[k];
+                    DT[g * kWave + lane] = r2[k] * amt;
+                    unsorted |= (kk < prev);
+                    prev = kk;
+                }
         }
     } else {
         const size_t strideT = (size_t)p.S * G * p.Wpad;
@@ -555,22 +632,149 @@ __device__ __forceinline__ void load_gas_g(const OverlapGParams &pg, const Layer
         const double *c2 = p.lnK + ((size_t)q.ipl * p.NT + q.ith) * strideT + off;
         const double *c3 = p.lnK + ((size_t)q.iph * p.NT + q.itl) * strideT + off;
         const double *c4 = p.lnK + ((size_t)q.iph * p.NT + q.ith) * strideT + off;
-        for (int g = 0; g < G; ++g) {
-            size_t go = (size_t)g * p.Wpad;
-            double kraw, dkr;
-            interp_kg(c1[go], c2[go], c3[go], c4[go], q.v, q.u, q.dudt, kraw, dkr);
-            const double kk = kraw * amt;
-            DST[g * kWave + lane] = kk;
-            KR[g * kWave + lane] = kraw;
-            DT[g * kWave + lane] = dkr * amt;
-            unsorted |= (kk < prev);
-            prev = kk;
+        for (int g0 = 0; g0 < G; g0 += kLoadBatch) {
+            double r1[kLoadBatch], r2[kLoadBatch], r3[kLoadBatch], r4[kLoadBatch];
+#pragma unroll
+            for (int k = 0; k < kLoadBatch; ++k) {
+                const int gi = (g0 + k < G) ? g0 + k : G - 1;
+                const size_t go = (size_t)gi * p.Wpad;
+                r1[k] = __builtin_nontemporal_load(c1 + go);
+                r2[k] = __builtin_nontemporal_load(c2 + go);
+                r3[k] = __builtin_nontemporal_load(c3 + go);
+                r4[k] = __builtin_nontemporal_load(c4 + go);
+            }
+#pragma unroll
+            for (int k = 0; k < kLoadBatch; ++k)
+                if (g0 + k < G) {
+                    const int g = g0 + k;
+                    double kraw, dkr;
+                    interp_kg(r1[k], r2[k], r3[k], r4[k], q.v, q.u, q.dudt, kraw, dkr);
+                    const double kk = kraw * amt;
+                    DST[g * kWave + lane] = kk;
+                    KR[g * kWave + lane] = kraw;
+                    DT[g * kWave + lane] = dkr * amt;
+                    unsorted |= (kk < prev);
+                    prev = kk;
+                }
         }
     }
 }
 
-template <int DEPTH, int MAXP, bool FROM_K>
-__global__ __launch_bounds__(kWave) void k_ck_overlapg(OverlapGParams pg)
+// global [G][64] -> LDS [G][64], loads batched (one round trip per kLoadBatch rows)
+__device__ __forceinline__ void stage_slice(double *dst_lds, const double *__restrict__ src, int G, int lane)
+{
+    for (int g0 = 0; g0 < G; g0 += kLoadBatch) {
+        double r[kLoadBatch];
+#pragma unroll
+        for (int k = 0; k < kLoadBatch; ++k) r[k] = src[((g0 + k < G) ? g0 + k : G - 1) * kWave + lane];
+#pragma unroll
+        for (int k = 0; k < kLoadBatch; ++k)
+            if (g0 + k < G) dst_lds[(g0 + k) * kWave + lane] = r[k];
+    }
+}
+
+// Replay of the recorded order for one gathered vector: SL0[row], or (DUAL, the temperature slot)
+// SL0[row] + SL1[col].  Store-free and branch-free: the running sum is written every step to the LDS row of
+// the lane's current bin, so each row ends up holding the sum before the element that closed the bin; global
+// stores inside this loop would sit in front of the code-word loads in the (in-order) vmcnt queue.
+// OUTL has G+1 rows (row G collects what follows the last bin).  Returns the sum after the last boundary.
+template <bool DUAL, bool W32>
+__device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigned long long *__restrict__ perm,
+                                              const double *SL0, const double *SL1, double *OUTL, const double *DG)
+{
+    double acc = 0.0;
+    int bo = lane;                                  // b * 64 + lane
+    // four steps of one code word: all LDS operands first (one LDS round trip per word), then the dependent part
+    auto group = [&](unsigned long long word, int nst) {
+        double g[4], wr[4], wc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned code = (unsigned)(word >> (16 * k)) & 0xFFFFu;
+            const int row = code & 31, col = (code >> 5) & 31;
+            wr[k] = DG[row];
+            wc[k] = DG[col];
+            g[k] = SL0[row * kWave + lane];
+            if constexpr (DUAL) g[k] += SL1[col * kWave + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < nst) {
+                const bool cross = ((word >> (16 * k + 15)) & 1ULL) != 0;
+                double w = wr[k] * wc[k];
+                if constexpr (W32) w = (double)(float)w;
+                OUTL[bo] = acc;
+                const double an = acc + g[k] * w;
+                acc = cross ? 0.0 : an;
+                bo += cross ? kWave : 0;
+            }
+        }
+    };
+    const int nfull = nloop >> 2, ngrp = (nloop + 3) >> 2;
+    // Code words are fetched kPF words (4*kPF steps) ahead into kPF statically named registers: no register
+    // rotation (a move of the newest word would wait for its load) and no predicated loads (clamped index).
+    constexpr int kPF = 4;
+    unsigned long long q[kPF];
+    const unsigned long long *pl = perm + lane;
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) q[k] = pl[(size_t)(k < ngrp ? k : ngrp - 1) * kWave];
+    int gidx = 0;
+    for (; gidx + kPF <= nfull; gidx += kPF) {
+#pragma unroll
+        for (int j = 0; j < kPF; ++j) {
+            const unsigned long long word = q[j];
+            const int nxt = gidx + j + kPF;
+            q[j] = pl[(size_t)(nxt < ngrp ? nxt : ngrp - 1) * kWave];
+            group(word, 4);
+        }
+    }
+    // remaining full words and the partial last one (their loads are already in flight / clamped duplicates)
+#pragma unroll
+    for (int j = 0; j < kPF; ++j) {
+        if (gidx + j < ngrp) {
+            const int nst = (nloop - 4 * (gidx + j)) < 4 ? (nloop - 4 * (gidx + j)) : 4;
+            group(q[j], nst);
+        }
+    }
+    return acc;
+}
+
+// deferred bin boundaries of one replayed vector: rec[b] = (frac, 1/weight-sum, -, w, -, code) from the merge
+template <bool DUAL>
+__device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const double *__restrict__ rec,
+                                             const double *SL0, const double *SL1, const double *OUTL, double tail,
+                                             double *__restrict__ OUT)
+{
+    double carry = 0.0;
+    constexpr int kRB = 5;
+    for (int b0 = 0; b0 < G; b0 += kRB) {
+        double rfr[kRB], rri[kRB], rw[kRB], rcd[kRB];
+#pragma unroll
+        for (int k = 0; k < kRB; ++k) {
+            const double *rp = rec + (size_t)((b0 + k < G) ? b0 + k : G - 1) * 6 * kWave + lane;
+            rfr[k] = rp[0]; rri[k] = rp[kWave]; rw[k] = rp[3 * kWave]; rcd[k] = rp[5 * kWave];
+        }
+#pragma unroll
+        for (int k = 0; k < kRB; ++k) {
+            const int b = b0 + k;
+            if (b < G) {
+                double v = 0.0;
+                if (b < ig) {
+                    const unsigned code = (unsigned)__double_as_longlong(rcd[k]);
+                    double g = SL0[(code & 31) * kWave + lane];
+                    if constexpr (DUAL) g += SL1[((code >> 5) & 31) * kWave + lane];
+                    const double gw = g * rw[k];
+                    v = ((carry + OUTL[b * kWave + lane]) + rfr[k] * gw) * rri[k];
+                    carry = (1.0 - rfr[k]) * gw;
+                } else if (b == ig)
+                    v = (carry + tail) * rri[k];
+                OUT[b * kWave + lane] = v;
+            }
+        }
+    }
+}
+
+template <int DEPTH, bool FROM_K, bool W32>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_ck_overlapg(OverlapGParams pg)
 {
     const OverlapParams &p = pg.o;
     extern __shared__ double smem[];
@@ -578,32 +782,32 @@ __global__ __launch_bounds__(kWave) void k_ck_overlapg(OverlapGParams pg)
     const int G = p.G;
     const int NP1 = p.S + 1;
     double *A = smem;
-    double *B = A + G * kWave;
-    double *NV = B + G * kWave;
+    double *B = A + G * kWave;                   // G+1 rows
+    double *NV = B + (G + 1) * kWave;
     double *DG = NV + G * kWave;
     double *GORD = DG + kMaxG;
     if (lane < G) DG[lane] = p.del_g[lane];
     if (lane < G + 2) GORD[lane] = p.g_ord[lane];
+    const double HUGE_KEY = __longlong_as_double(0x7FE0000000000000LL);
     __syncthreads();
-    const bool w32 = p.delg_f32 != 0;
     double wsum = 0.0;
     for (int g = 0; g < G; ++g) wsum += DG[g];
     const double wtot = wsum * wsum;
 
-    double *scrK = p.scratch + (size_t)blockIdx.x * 2 * G * kWave;
-    double *scrS = scrK + G * kWave;
+    double *rec = p.scratch + (size_t)blockIdx.x * 6 * (G + 1) * kWave;
     const size_t GW = (size_t)G * kWave;
-    double *gs = pg.gscratch + (size_t)blockIdx.x * (2 + 2 * (size_t)NP1) * GW;
+    double *gs = pg.gscratch + (size_t)blockIdx.x * (3 + 2 * (size_t)NP1) * GW;
     double *KRB = gs, *DTB = gs + GW;
     double *Dbuf[2] = {gs + 2 * GW, gs + (2 + (size_t)NP1) * GW};
-    const int NVT = p.Wpad / kWave;
-    const long ntiles = (long)p.n_models * NVT * p.L;
+    double *ASAVE = gs + (2 + 2 * (size_t)NP1) * GW;
+    const int nloop = G * G;
+    unsigned long long *perm = pg.perm + (size_t)blockIdx.x * ((nloop + 3) >> 2) * kWave;
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int l = (int)(tile % p.L);
-        const long r = tile / p.L;
-        const int vt = (int)(r % NVT);
-        const int m = (int)(r / NVT);
+    TileQueue tq;
+    tq.init();
+    for (;;) {
+        int vt = 0, m = 0, l = 0;
+        if (!tq.next(p, lane, vt, m, l)) break;
         const int nu = vt * kWave + lane;
         LayerInterp q;
         if constexpr (!FROM_K) q = p.li[(size_t)m * p.L + l];
@@ -644,104 +848,98 @@ __global__ __launch_bounds__(kWave) void k_ck_overlapg(OverlapGParams pg)
                 if (takeB)
                     for (int g = 0; g < G; ++g) A[g * kWave + lane] = B[g * kWave + lane];
             } else {
+                // ---- the forward merge, recording the order -------------------------------------------------
+                B[G * kWave + lane] = HUGE_KEY;
                 const double b0 = B[lane];
                 for (int x = 1; x < G; ++x) {
                     const int row = p.init_loser[x];
-                    NV[x * kWave + lane] = pack_key(A[row * kWave + lane] + b0, row, 0);
+                    NV[x * kWave + lane] = pack_key11(A[row * kWave + lane] + b0, row, 0);
                 }
-                NV[lane] = sentinel_key(31);
-                for (int g = 0; g < G; ++g) { scrK[g * kWave + lane] = 0.0; scrS[g * kWave + lane] = 1.0; }
-                for (int pp = 0; pp < NP1; ++pp)
+                NV[lane] = HUGE_KEY;
+                MergeElem<DEPTH> e0, e1;
+                merge_fetch<DEPTH, W32>(pack_key11(A[lane] + b0, 0, 0), G, lane, A, B, NV, DG, e0);
+                WalkState ws{0.0, 0.0, 0.0, GORD[1], 0};
+                unsigned long long *pw = perm + lane;
+                int it = 0;
+                for (; it + 3 < nloop; it += 4) {
+                    const unsigned long long c0 = merge_step<DEPTH, W32, true>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec);
+                    const unsigned long long c1 = merge_step<DEPTH, W32, true>(e1, e0, ws, G, lane, A, B, NV, DG, GORD, rec);
+                    const unsigned long long c2 = merge_step<DEPTH, W32, true>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec);
+                    const unsigned long long c3 = merge_step<DEPTH, W32, true>(e1, e0, ws, G, lane, A, B, NV, DG, GORD, rec);
+                    *pw = c0 | (c1 << 16) | (c2 << 32) | (c3 << 48);
+                    pw += kWave;
+                }
+                if (it < nloop) {   // G*G not a multiple of 4: a partial last word
+                    unsigned long long word = 0;
+                    for (int k = 0; it < nloop; ++it, ++k) {
+                        const unsigned long long c = (k & 1) ? merge_step<DEPTH, W32, true>(e1, e0, ws, G, lane, A, B, NV, DG, GORD, rec)
+                                                             : merge_step<DEPTH, W32, true>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec);
+                        word |= c << (16 * k);
+                    }
+                    *pw = word;
+                }
+                // ---- resolve the bins: merged k -> ASAVE, (frac, 1/sum) -> rec ------------------------------
+                double ck = 0.0, cs = 0.0;
+                const int ig = ws.ig;
+                constexpr int kRB = 5;
+                for (int b0 = 0; b0 < G; b0 += kRB) {
+                    double rka[kRB], rs1[kRB], rcw[kRB], rw[kRB], rgd[kRB];
+#pragma unroll
+                    for (int k = 0; k < kRB; ++k) {
+                        const double *rp = rec + (size_t)((b0 + k < G) ? b0 + k : G - 1) * 6 * kWave + lane;
+                        rka[k] = rp[0]; rs1[k] = rp[kWave]; rcw[k] = rp[2 * kWave]; rw[k] = rp[3 * kWave];
+                        rgd[k] = rp[4 * kWave];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kRB; ++k) {
+                        const int b = b0 + k;
+                        if (b < G) {
+                            double outv = 0.0, fr = 0.0, rinv = 1.0;
+                            if (b < ig) {
+                                const double ka = rka[k], s1 = rs1[k], cw = rcw[k], w = rw[k], gd0 = rgd[k];
+                                const double gprev = (b == 0 && s1 == 0.0) ? wtot : gd0;
+                                const double gdn = gd0 + w;
+                                fr = (GORD[b + 1] - gprev) / (gdn - gprev);
+                                const double kb = (ck + ka) + fr * cw;
+                                const double sb = (cs + s1) + fr * w;
+                                rinv = 1.0 / sb;
+                                outv = kb / sb;
+                                ck = (1.0 - fr) * cw;
+                                cs = (1.0 - fr) * w;
+                            } else if (b == ig) {
+                                const double kb = ck + ws.kacc, sb = cs + ws.sum1;
+                                if (b == G - 1) { outv = kb / sb; rinv = 1.0 / sb; } else outv = kb;
+                            }
+                            double *rp = rec + (size_t)b * 6 * kWave + lane;
+                            ASAVE[b * kWave + lane] = outv;
+                            rp[0] = fr; rp[kWave] = rinv;
+                        }
+                    }
+                }
+                // ---- replay, one slot per pass: slices in A / NV, bin sums in B (G+1 rows) ------------------
+                {   // temperature slot: D_old[igas+1][row] + dkdT_new[col]*amount
+                    stage_slice(A, Dold + (size_t)(igas + 1) * GW, G, lane);
+                    stage_slice(NV, DTB, G, lane);
+                    const double tail = grad_replay<true, W32>(nloop, lane, perm, A, NV, B, DG);
+                    grad_resolve<true>(G, lane, ig, rec, A, NV, B, tail, Dnew + (size_t)(igas + 2) * GW);
+                }
+                for (int pp = 0; pp <= igas + 1; ++pp) {
+                    // pp <= igas: D_old[pp][row];  pp == igas+1: k_new[col] (col gather = DUAL with a zero row part)
+                    const bool colsrc = (pp == igas + 1);
+                    const double *src = colsrc ? KRB : Dold + (size_t)pp * GW;
+                    stage_slice(colsrc ? NV : A, src, G, lane);
+                    if (colsrc) {
+                        for (int g = 0; g < G; ++g) A[g * kWave + lane] = 0.0;
+                        const double tail = grad_replay<true, W32>(nloop, lane, perm, A, NV, B, DG);
+                        grad_resolve<true>(G, lane, ig, rec, A, NV, B, tail, Dnew + (size_t)pp * GW);
+                    } else {
+                        const double tail = grad_replay<false, W32>(nloop, lane, perm, A, A, B, DG);
+                        grad_resolve<false>(G, lane, ig, rec, A, A, B, tail, Dnew + (size_t)pp * GW);
+                    }
+                }
+                for (int pp = n; pp < NP1; ++pp)
                     for (int g = 0; g < G; ++g) Dnew[(size_t)pp * GW + g * kWave + lane] = 0.0;
-                double ckey = pack_key(A[lane] + b0, 0, 0);
-                double gd = 0.0, kacc = 0.0, sum1 = 0.0, gnext = GORD[1];
-                double acc[MAXP];
-#pragma unroll
-                for (int pp = 0; pp < MAXP; ++pp) acc[pp] = 0.0;
-                int ig = 0;
-                const int nloop = G * G;
-                for (int it = 0; it < nloop; ++it) {
-                    const unsigned kb = (unsigned)__double_as_longlong(ckey);
-                    const int ci = kb & 31, cp = (kb >> 5) & 31;
-                    const int np = cp + 1;
-                    const int npc = np < G ? np : G - 1;
-                    const double ai = A[ci * kWave + lane];
-                    const double bc = B[cp * kWave + lane];
-                    const double bn = B[npc * kWave + lane];
-                    double w = DG[ci] * DG[cp];
-                    if (w32) w = (double)(float)w;
-                    const int x0 = (G + ci) >> 1;
-                    double tv[DEPTH];
-#pragma unroll
-                    for (int d = 0; d < DEPTH; ++d) tv[d] = NV[(x0 >> d) * kWave + lane];
-                    // gradient row of this element (:5946-5949)
-                    const double kbv = KRB[cp * kWave + lane];
-                    const double dtb = DTB[cp * kWave + lane];
-                    const double doldT = Dold[(size_t)(igas + 1) * GW + ci * kWave + lane];
-                    double gw[MAXP];
-#pragma unroll
-                    for (int pp = 0; pp < MAXP; ++pp) {
-                        if (pp < n) {
-                            double gp;
-                            if (pp <= igas) gp = Dold[(size_t)pp * GW + ci * kWave + lane];
-                            else if (pp == igas + 1) gp = kbv;
-                            else gp = doldT + dtb;
-                            gw[pp] = gp * w;
-                        }
-                    }
-                    double car = (np < G) ? pack_key(ai + bn, ci, np) : sentinel_key(ci);
-#pragma unroll
-                    for (int d = 0; d < DEPTH; ++d) {
-                        double lo, hi;
-                        minmax_f64(tv[d], car, lo, hi);
-                        NV[(x0 >> d) * kWave + lane] = hi;
-                        car = lo;
-                    }
-                    ckey = car;
-                    const double cv = ai + bc;
-                    const double gdn = gd + w;
-                    const double cw = cv * w;
-                    if (ig < G) {
-                        if (gdn < gnext) {
-                            kacc += cw;
-                            sum1 += w;
-#pragma unroll
-                            for (int pp = 0; pp < MAXP; ++pp)
-                                if (pp < n) acc[pp] += gw[pp];
-                        } else {
-                            const double gprev = (it == 0) ? wtot : gd;
-                            const double frac = fast_div(gnext - gprev, gdn - gprev);
-                            scrK[ig * kWave + lane] = kacc + frac * cw;
-                            scrS[ig * kWave + lane] = sum1 + frac * w;
-#pragma unroll
-                            for (int pp = 0; pp < MAXP; ++pp)
-                                if (pp < n) {
-                                    Dnew[(size_t)pp * GW + ig * kWave + lane] = acc[pp] + frac * gw[pp];
-                                    acc[pp] = (1.0 - frac) * gw[pp];
-                                }
-                            ig += 1;
-                            sum1 = (1.0 - frac) * w;
-                            kacc = (1.0 - frac) * cw;
-                            gnext = GORD[ig + 1];
-                        }
-                    }
-                    gd = gdn;
-                }
-                if (ig < G) {
-                    scrK[ig * kWave + lane] = kacc;
-                    scrS[ig * kWave + lane] = (ig == G - 1) ? sum1 : 1.0;
-#pragma unroll
-                    for (int pp = 0; pp < MAXP; ++pp)
-                        if (pp < n) Dnew[(size_t)pp * GW + ig * kWave + lane] = acc[pp];
-                }
-                for (int g = 0; g < G; ++g) {
-                    const double ss = scrS[g * kWave + lane];
-                    A[g * kWave + lane] = scrK[g * kWave + lane] / ss;
-                    for (int pp = 0; pp < n; ++pp) {
-                        const size_t o = (size_t)pp * GW + g * kWave + lane;
-                        Dnew[o] = Dnew[o] / ss;
-                    }
-                }
+                stage_slice(A, ASAVE, G, lane);
             }
             cur ^= 1;
         }
@@ -750,9 +948,6 @@ __global__ __launch_bounds__(kWave) void k_ck_overlapg(OverlapGParams pg)
         for (int g = 0; g < G; ++g) out[(size_t)g * p.Wpad] = A[g * kWave + lane];
         double *dout = pg.dk + (((size_t)m * p.L + l) * NP1) * G * p.Wpad + nu;
         const double *Dc = Dbuf[cur];
-        if (p.S == 1) {
-            // NGAS == 1 shortcut (:5871-5876): tau = k*amount, dk[...,0] = k, dk[...,1] = dkdT*amount
-        }
         for (int pp = 0; pp < NP1; ++pp)
             for (int g = 0; g < G; ++g)
                 dout[((size_t)pp * G + g) * p.Wpad] = Dc[(size_t)pp * GW + g * kWave + lane];
