@@ -4,6 +4,7 @@
 #include "ansfm_ms_kernels.hip.h"
 #include "ansfm_lbl_kernels.hip.h"
 #include "ansfm_layer_kernels.hip.h"
+#include "ansfm_map_kernels.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -57,6 +58,9 @@ struct ansfm_ctx {
 
     // workspaces
     DevBuf li, tau, scratch, cont_t, tmp_in, tmp_out, misc;
+    DevBuf dspec_ref, map_out, map_b, map_batch;
+    int dspec_dims[4] = {0, 0, 0, 0};   // W, NPAR, LIMAX, P of dspec_ref (single-model cirsradg result)
+    int map_dims[4] = {0, 0, 0, 0};     // W, NPAR, NPRO, P of map_out
     DevBuf gscratch, perm, dkbuf, trold_ws, dspec_i, dcont_t, tmp_in2, tmp_out2, lbl_li;
     DevBuf hb[24];  // staging buffers of the host-pointer entry points
     int last_n = 0, last_L = 0;
@@ -839,18 +843,20 @@ int ansfm_cirsradg_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L, c
 #undef UP
     const size_t nsp = (size_t)n_models * W * P, ndsp = (size_t)n_models * W * NPAR * LIMAX * P;
     HIPCHK(ctx->tmp_out.reserve((2 * nsp) * D));
-    HIPCHK(ctx->tmp_out2.reserve(ndsp * D));
+    HIPCHK(ctx->dspec_ref.reserve(ndsp * D));     // kept on the device for ansfm_map2pro(dSPECIN = NULL)
+    ctx->dspec_dims[0] = 0;
     double *o_spec = ctx->tmp_out.as<double>(), *o_dts = o_spec + nsp;
     rc = ansfm_cirsradg_ck_thermal_dev(ctx, ISPACE, n_models, L, (const double *)d[0], (const double *)d[1],
                                        (const double *)d[2], (const double *)d[3], (const double *)d[4], NVMR, NPAR,
                                        igas_map, P, LIMAX, (const int32_t *)d[5], (const int32_t *)d[6],
                                        (const double *)d[7], (const double *)d[8], (const double *)d[9],
-                                       (const double *)d[10], (const double *)d[11], o_spec, ctx->tmp_out2.as<double>(),
+                                       (const double *)d[10], (const double *)d[11], o_spec, ctx->dspec_ref.as<double>(),
                                        o_dts);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(SPECOUT, o_spec, nsp * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(dTSURF, o_dts, nsp * D, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dSPECOUT, ctx->tmp_out2.p, ndsp * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dSPECOUT, ctx->dspec_ref.p, ndsp * D, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_models == 1) { ctx->dspec_dims[0] = ctx->W; ctx->dspec_dims[1] = NPAR; ctx->dspec_dims[2] = LIMAX; ctx->dspec_dims[3] = P; }
     return check_unsorted(ctx);
 }
 
@@ -897,6 +903,140 @@ int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *d
     return check_unsorted(ctx);
 }
 
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* gradient maps (ForwardModel_0.map2pro / map2xvec)                                           */
+/* ------------------------------------------------------------------------------------------ */
+static int launch_gemm(ansfm_ctx *ctx, GemmParams g, const std::vector<GemmBatch> &batch)
+{
+    if (batch.empty() || g.M <= 0 || g.N <= 0) return ANSFM_OK;
+    HIPCHK(ctx->map_batch.reserve(batch.size() * sizeof(GemmBatch)));
+    HIPCHK(hipMemcpyAsync(ctx->map_batch.p, batch.data(), batch.size() * sizeof(GemmBatch), hipMemcpyHostToDevice,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // batch is a host temporary
+    g.batch = ctx->map_batch.as<GemmBatch>();
+    hipLaunchKernelGGL(k_gemm_f64, dim3((unsigned)((g.M + 63) / 64), (unsigned)((g.N + 63) / 64), (unsigned)batch.size()),
+                       dim3(256), 0, ctx->stream, g);
+    HIPCHK(hipGetLastError());
+    return ANSFM_OK;
+}
+
+int ansfm_map2pro(ansfm_ctx *ctx, int W, int NPAR, int LIMAX, int P, int NPRO, int NLAY, int NVMR, int NDUST,
+                  const double *dSPECIN, const int32_t *LAYINC, const double *DTE, const double *DAM,
+                  const double *DCO, int n_incpar, const int32_t *INCPAR, double *dSPECOUT)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || NPAR <= 0 || LIMAX <= 0 || P <= 0 || NPRO <= 0 || NLAY <= 0 || NVMR < 0 || NDUST < 0 ||
+        NPAR != NVMR + 2 + NDUST || !LAYINC || !DTE || !DAM || !DCO || n_incpar < 0 || (n_incpar > 0 && !INCPAR))
+        FAIL(ANSFM_ERR_INVALID, "map2pro: bad argument (NPAR must be NVMR+2+NDUST)");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t D = sizeof(double);
+    const size_t nin = (size_t)W * NPAR * LIMAX * P, nout = (size_t)W * NPAR * NPRO * P;
+    const double *dA;
+    if (dSPECIN) {
+        HIPCHK(ctx->tmp_in.reserve(nin * D));
+        HIPCHK(hipMemcpyAsync(ctx->tmp_in.p, dSPECIN, nin * D, hipMemcpyHostToDevice, ctx->stream));
+        dA = ctx->tmp_in.as<double>();
+    } else {
+        if (ctx->dspec_dims[0] != W || ctx->dspec_dims[1] != NPAR || ctx->dspec_dims[2] != LIMAX || ctx->dspec_dims[3] != P)
+            FAIL(ANSFM_ERR_INVALID, "map2pro: no device-resident cirsradg result of these dimensions");
+        dA = ctx->dspec_ref.as<double>();
+    }
+    // M_cls[LAYINC[j][p]][pro] gathered on the host: Bx[cls][p][j][pro], cls 0 = DAM, 1 = DTE, 2 = DCO
+    std::vector<double> bx((size_t)3 * P * LIMAX * NPRO);
+    const double *Mc[3] = {DAM, DTE, DCO};
+    for (int cls = 0; cls < 3; ++cls)
+        for (int p = 0; p < P; ++p)
+            for (int j = 0; j < LIMAX; ++j) {
+                int lay = LAYINC[(size_t)j * P + p];
+                if (lay < 0) lay += NLAY;                     // python negative index
+                if (lay < 0 || lay >= NLAY) FAIL(ANSFM_ERR_INVALID, "map2pro: LAYINC entry outside the layer range");
+                memcpy(&bx[(((size_t)cls * P + p) * LIMAX + j) * NPRO], Mc[cls] + (size_t)lay * NPRO, NPRO * D);
+            }
+    HIPCHK(ctx->map_b.reserve(bx.size() * D));
+    HIPCHK(hipMemcpyAsync(ctx->map_b.p, bx.data(), bx.size() * D, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx->map_out.reserve(nout * D));
+    ctx->map_dims[0] = 0;
+    HIPCHK(hipMemsetAsync(ctx->map_out.p, 0, nout * D, ctx->stream));
+    std::vector<GemmBatch> batch;
+    long long last_a = -1, last_b = -1;                       // the reference's stale dSPECOUT1
+    const int npm = n_incpar > 0 ? n_incpar : NPAR;
+    for (int p = 0; p < P; ++p)
+        for (int ip = 0; ip < npm; ++ip) {
+            const int par = n_incpar > 0 ? INCPAR[ip] : ip;
+            if (par < 0 || par >= NPAR) FAIL(ANSFM_ERR_INVALID, "map2pro: INCPAR entry outside 0..NPAR-1");
+            int cls = -1;
+            if (par <= NVMR - 1) cls = 0;
+            else if (par <= NVMR) cls = 1;
+            else if (par <= NVMR + NDUST) cls = 2;
+            GemmBatch b;
+            if (cls >= 0) {
+                b.a_off = ((long long)par * LIMAX) * P + p;
+                b.b_off = (((long long)cls * P + p) * LIMAX) * NPRO;
+                last_a = b.a_off; last_b = b.b_off;
+            } else {
+                if (last_a < 0) FAIL(ANSFM_ERR_INVALID, "map2pro: para-H2 parameter listed first (the reference raises UnboundLocalError)");
+                b.a_off = last_a; b.b_off = last_b;
+            }
+            b.c_off = ((long long)par * NPRO) * P + p;
+            batch.push_back(b);
+        }
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = dA; g.B = ctx->map_b.as<double>(); g.C = ctx->map_out.as<double>();
+    g.M = W; g.N = NPRO; g.K = LIMAX;
+    g.a_sm = (long long)NPAR * LIMAX * P; g.a_sk = P;
+    g.b_sk = NPRO; g.b_sn = 1;
+    g.c_sm = (long long)NPAR * NPRO * P; g.c_sn = P;
+    int rc = launch_gemm(ctx, g, batch);
+    if (rc) return rc;
+    ctx->map_dims[0] = W; ctx->map_dims[1] = NPAR; ctx->map_dims[2] = NPRO; ctx->map_dims[3] = P;
+    if (dSPECOUT) {
+        HIPCHK(hipMemcpyAsync(dSPECOUT, ctx->map_out.p, nout * D, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return ANSFM_OK;
+}
+
+int ansfm_map2xvec(ansfm_ctx *ctx, int W, int NPAR, int NPRO, int P, int NX, const double *dSPECIN,
+                   const double *xmap, double *dSPECOUT)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || NPAR <= 0 || NPRO <= 0 || P <= 0 || NX <= 0 || !xmap || !dSPECOUT)
+        FAIL(ANSFM_ERR_INVALID, "map2xvec: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t D = sizeof(double);
+    const size_t nin = (size_t)W * NPAR * NPRO * P, nout = (size_t)W * P * NX, nxm = (size_t)NX * NPAR * NPRO;
+    const double *dA;
+    if (dSPECIN) {
+        HIPCHK(ctx->tmp_in.reserve(nin * D));
+        HIPCHK(hipMemcpyAsync(ctx->tmp_in.p, dSPECIN, nin * D, hipMemcpyHostToDevice, ctx->stream));
+        dA = ctx->tmp_in.as<double>();
+    } else {
+        if (ctx->map_dims[0] != W || ctx->map_dims[1] != NPAR || ctx->map_dims[2] != NPRO || ctx->map_dims[3] != P)
+            FAIL(ANSFM_ERR_INVALID, "map2xvec: no device-resident map2pro result of these dimensions");
+        dA = ctx->map_out.as<double>();
+    }
+    HIPCHK(ctx->map_b.reserve(nxm * D));
+    HIPCHK(hipMemcpyAsync(ctx->map_b.p, xmap, nxm * D, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx->tmp_out.reserve(nout * D));
+    std::vector<GemmBatch> batch;
+    for (int p = 0; p < P; ++p) batch.push_back(GemmBatch{(long long)p, 0, (long long)p * NX});
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = dA; g.B = ctx->map_b.as<double>(); g.C = ctx->tmp_out.as<double>();
+    g.M = W; g.N = NX; g.K = NPAR * NPRO;
+    g.a_sm = (long long)NPAR * NPRO * P; g.a_sk = P;
+    g.b_sk = 1; g.b_sn = (long long)NPAR * NPRO;
+    g.c_sm = (long long)P * NX; g.c_sn = 1;
+    int rc = launch_gemm(ctx, g, batch);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(dSPECOUT, ctx->tmp_out.p, nout * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* multiple scattering                                                                         */

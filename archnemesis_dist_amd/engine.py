@@ -28,6 +28,14 @@ def _ptr(a):
     return C.c_void_p(a.data_ptr())  # torch tensor
 
 
+def _fingerprint(a):
+    """Identity of a result array handed back to the caller: address, shape and a few sampled values -- enough to
+    recognise "the array I returned, unmodified" when it comes back as the next step's input."""
+    flat = a.reshape(-1)
+    idx = np.linspace(0, flat.size - 1, num=min(flat.size, 32)).astype(np.int64)
+    return (a.ctypes.data, a.shape, a.strides, flat[idx].tobytes())
+
+
 class AnsfmEngine:
     def __init__(self, device=0):
         self._lib = _lib.load()
@@ -214,6 +222,7 @@ class AnsfmEngine:
             _ptr(ig), P, LIMAX, _ptr(NLAYIN), _ptr(LAYINC), _ptr(SC), _ptr(ET), _ptr(TS), _ptr(_np(EMISSIVITY)),
             _ptr(_np(xfac)), _ptr(spec), _ptr(dspec), _ptr(dts))
         self._check(rc, "cirsradg_ck_thermal")
+        self._chain_dspec = _fingerprint(dspec[0]) if n == 1 else None   # device copy usable by map2pro
         return (spec[0], dspec[0], dts[0]) if single else (spec, dspec, dts)
 
     def cirsrad_ck_thermal_dev(self, ISPACE, n_models, L, lay_press_pa, lay_temp, amount, taucont, P, LIMAX,
@@ -291,6 +300,48 @@ class AnsfmEngine:
         self._check(rc, "layer_average")
         out = (HEIGHT, PRESS, TEMP, TOTAM, AMOUNT, PPo, CONT, FRAC, DELH, BASET, LAYSF)
         return tuple(a[0] for a in out) if single else out
+
+    def map2pro(self, dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NLAYIN, LAYINC, DTE, DAM, DCO, INCPAR=(-1,)):
+        """ForwardModel_0.map2pro (:5319), same arguments -> dSPECOUT (NWAVE, NVMR+2+NDUST, NPRO, NPATH).
+        When dSPECIN is the very array the last cirsradg_ck_thermal call returned, its device copy is used
+        (no host->device transfer); the result stays on the device for a following map2xvec."""
+        dSPECIN = _np(dSPECIN)
+        W, NPAR, LIMAX, P = dSPECIN.shape
+        if W != NWAVE or NPAR != NVMR + 2 + NDUST or P != NPATH:
+            raise ValueError("map2pro: dSPECIN must be (NWAVE, NVMR+2+NDUST, NLAYIN, NPATH)")
+        LAYINC = _np(LAYINC, np.int32)
+        if LAYINC.ndim == 1:
+            LAYINC = LAYINC[:, None]
+        if LAYINC.shape != (LIMAX, P):
+            raise ValueError("shapes (%d,%d) and %s not aligned: LAYINC rows must equal dSPECIN's layer axis"
+                             % (W, LIMAX, LAYINC.shape))
+        DTE = _np(DTE); DAM = _np(DAM); DCO = _np(DCO)
+        NLAY = DTE.shape[0]
+        inc = None if INCPAR[0] == -1 else _np(list(INCPAR), np.int32)
+        if inc is not None and inc[0] > NVMR + NDUST:
+            raise UnboundLocalError("local variable 'dSPECOUT1' referenced before assignment")   # as the reference
+        out = np.empty((W, NPAR, NPRO, P))
+        chained = getattr(self, "_chain_dspec", None) is not None and self._chain_dspec == _fingerprint(dSPECIN)
+        rc = self._lib.ansfm_map2pro(self._ctx, W, NPAR, LIMAX, P, int(NPRO), NLAY, int(NVMR), int(NDUST),
+                                     None if chained else _ptr(dSPECIN), _ptr(LAYINC), _ptr(DTE), _ptr(DAM), _ptr(DCO),
+                                     0 if inc is None else len(inc), _ptr(inc), _ptr(out))
+        self._check(rc, "map2pro")
+        self._chain_map = _fingerprint(out)
+        return out
+
+    def map2xvec(self, dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NX, xmap):
+        """ForwardModel_0.map2xvec (:5387), same arguments -> dSPECOUT (NWAVE, NPATH, NX)."""
+        dSPECIN = _np(dSPECIN)
+        W, NPAR, NPROi, P = dSPECIN.shape
+        xmap = _np(xmap)
+        if xmap.shape != (NX, NPAR, NPROi):
+            raise ValueError("shape-mismatch for sum")     # np.tensordot's message
+        out = np.empty((W, P, NX))
+        chained = getattr(self, "_chain_map", None) is not None and self._chain_map == _fingerprint(dSPECIN)
+        rc = self._lib.ansfm_map2xvec(self._ctx, W, NPAR, NPROi, P, int(NX), None if chained else _ptr(dSPECIN),
+                                      _ptr(xmap), _ptr(out))
+        self._check(rc, "map2xvec")
+        return out
 
     def get_taugas(self, L, model=0):
         W, G = self.dims[0], self.dims[1]

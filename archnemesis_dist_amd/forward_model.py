@@ -259,3 +259,24 @@ def install_gpu_line_kernel(device=0):
     ld._ansfm_reference_line_kernel = ref_fn
     ld.add_line_set_monochromatic_absorption = add_line_set_monochromatic_absorption
     return add_line_set_monochromatic_absorption
+
+
+def install_gpu_gradient_maps(device=0):
+    """Route ForwardModel_0.map2pro / map2xvec (ForwardModel_0.py:5319, :5387) -- the layer -> profile -> state-vector
+    gradient maps nemesisfmg applies right after CIRSrad(return_grad=True) (:704-711) -- through the GPU.  The arrays
+    stay on the device between the three steps when they are passed on unmodified, as nemesisfmg does."""
+    import importlib
+    fm = importlib.import_module("archnemesis.ForwardModel_0")
+    eng = get_engine(device)
+    if not hasattr(fm, "_ansfm_reference_maps"):
+        fm._ansfm_reference_maps = (fm.map2pro, fm.map2xvec)
+
+    def map2pro(dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NLAYIN, LAYINC, DTE, DAM, DCO, INCPAR=[-1]):
+        return eng.map2pro(dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NLAYIN, LAYINC, DTE, DAM, DCO, INCPAR=INCPAR)
+
+    def map2xvec(dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NX, xmap):
+        return eng.map2xvec(dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NX, xmap)
+
+    fm.map2pro = map2pro
+    fm.map2xvec = map2xvec
+    return map2pro, map2xvec

@@ -223,6 +223,25 @@ int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, c
                         double *AMOUNT, double *PP, double *CONT, double *FRAC, double *DELH,
                         double *BASET, double *LAYSF);
 
+/* ---- gradient maps ------------------------------------------------------------------------------------
+ * ForwardModel_0.map2pro (ForwardModel_0.py:5319-5383): layer gradients -> profile-level gradients,
+ *   dSPECOUT[W][NPAR][NPRO][P] = sum_j dSPECIN[W][NPAR][LIMAX][P] * M[LAYINC[j][p]][NPRO], M = DAM for gas
+ *   parameters (index < NVMR), DTE for temperature (== NVMR), DCO for dust (NVMR < index <= NVMR+NDUST);
+ *   NPAR = NVMR+2+NDUST.  INCPAR[n_incpar] = the parameters to map (n_incpar = 0: all); unlisted slots stay 0.
+ *   The para-H2 slot (NVMR+NDUST+1) receives the PREVIOUS listed parameter's result, as in the reference
+ *   (:5373-5377 assign the stale dSPECOUT1); listing it first is the reference's UnboundLocalError ->
+ *   ANSFM_ERR_INVALID.   LAYINC[LIMAX][P] int32, DTE/DAM/DCO[NLAY][NPRO].
+ * ForwardModel_0.map2xvec (:5387-5424): dSPECOUT[W][P][NX] = sum_{par,pro} dSPECIN[W][NPAR][NPRO][P] * xmap[NX][NPAR][NPRO].
+ * Device chaining: dSPECIN == NULL takes the device-resident result of the previous step of this ctx
+ * (map2pro: the dSPECOUT of the last single-model ansfm_cirsradg_ck_thermal; map2xvec: the last map2pro) and
+ * fails with ANSFM_ERR_INVALID if its dimensions differ.  dSPECOUT == NULL (map2pro only) keeps the result
+ * on the device for the following map2xvec. */
+int ansfm_map2pro(ansfm_ctx *ctx, int W, int NPAR, int LIMAX, int P, int NPRO, int NLAY, int NVMR, int NDUST,
+                  const double *dSPECIN, const int32_t *LAYINC, const double *DTE, const double *DAM,
+                  const double *DCO, int n_incpar, const int32_t *INCPAR, double *dSPECOUT);
+int ansfm_map2xvec(ansfm_ctx *ctx, int W, int NPAR, int NPRO, int P, int NX, const double *dSPECIN,
+                   const double *xmap, double *dSPECOUT);
+
 /* Vertical gas opacity of the last cirsrad call's first model, TAUGAS[W][G][L]
  * (what CIRSrad leaves in LayerX.TAUGAS, ForwardModel_0.py:3925) -- host pointer out. */
 int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS);

@@ -268,3 +268,39 @@ def layer_average(RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP, LAYANG=0
     if rc:
         raise NotImplementedError("layer_average: even NINT not restated")
     return o[0], o[1], o[2], o[3], AM, PPo, CO, FR, DELH, BASET, LAYSF
+
+
+# ---- gradient maps (ForwardModel_0.map2pro :5319-5383, map2xvec :5387-5424) ----------------------------------
+def map2pro(dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NLAYIN, LAYINC, DTE, DAM, DCO, INCPAR=(-1,)):
+    """NumPy restatement: per (path, listed parameter) a (NWAVE x NLAYIN)·(NLAYIN x NPRO) product with the rows
+    DAM/DTE/DCO[LAYINC[:,path]] (:5362-5377).  The para-H2 slot is assigned the previous iteration's product (the
+    reference sets it to zero and then overwrites it with the stale dSPECOUT1, :5375-5377)."""
+    dSPECIN = np.asarray(dSPECIN, float)
+    LAYINC = np.asarray(LAYINC).reshape(dSPECIN.shape[2], -1)
+    out = np.zeros((NWAVE, NVMR + 2 + NDUST, NPRO, NPATH))
+    inc = list(range(NVMR + 2 + NDUST)) if INCPAR[0] == -1 else list(INCPAR)
+    last = None
+    for ipath in range(NPATH):
+        for par in inc:
+            if par <= NVMR - 1:
+                M = DAM
+            elif par <= NVMR:
+                M = DTE
+            elif NVMR < par <= NVMR + NDUST:
+                M = DCO
+            else:
+                M = None
+            if M is not None:
+                last = dSPECIN[:, par, :, ipath] @ np.asarray(M, float)[LAYINC[:, ipath], :]
+            if last is None:
+                raise UnboundLocalError("local variable 'dSPECOUT1' referenced before assignment")
+            out[:, par, :, ipath] = last
+    return out
+
+
+def map2xvec(dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NX, xmap):
+    """dSPECOUT[w,p,x] = sum_{par,pro} dSPECIN[w,par,pro,p] * xmap[x,par,pro]   (:5421)."""
+    a = np.asarray(dSPECIN, float)
+    x = np.asarray(xmap, float)
+    W, NPAR, NP_, P = a.shape
+    return np.einsum("wkp,xk->wpx", a.reshape(W, NPAR * NP_, P), x.reshape(NX, NPAR * NP_), optimize=True)

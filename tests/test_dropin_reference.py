@@ -44,6 +44,14 @@ class OracleEngineDouble:
                                               return_taugas=True)[1]
         return r
 
+    def map2pro(self, *a, **k):
+        self.map_calls = getattr(self, "map_calls", 0) + 1
+        return self.orc.map2pro(*a, **k)
+
+    def map2xvec(self, *a, **k):
+        self.map_calls = getattr(self, "map_calls", 0) + 1
+        return self.orc.map2xvec(*a, **k)
+
     def get_taugas(self, L, model=0):
         return self.tg
 
@@ -121,4 +129,32 @@ def test_nemesisfmg_through_the_adapter_matches_the_reference(c1_run, oracle, go
     # (trold - tr) with tr = trold*exp(-tau) cancels for the thin top layers (tau ~ 1e-9), so a 1-ulp
     # difference between libm's and NumPy's exp shows up as ~1e-7 relative in those (tiny) gradient entries:
     # measured 9e-7 of the column maximum; the Jacobian contract is 1e-4
+    assert np.max(np.abs(dSPECONV - ref) / scale) < 1e-5
+
+
+def test_nemesisfmg_with_gradient_maps_routed_through_the_engine(c1_run, oracle, golden_dir, monkeypatch):
+    """install_gpu_gradient_maps: nemesisfmg's map2pro / map2xvec calls (:705-711) land on the engine's entry points
+    with the reference's arguments, and the result is still the reference's dSPECONV."""
+    ans = c1_run
+    import importlib
+    import archnemesis_dist_amd.forward_model as fmod
+    fm0 = importlib.import_module("archnemesis.ForwardModel_0")
+    double = OracleEngineDouble(oracle)
+    monkeypatch.setattr(fmod, "get_engine", lambda device=0: double)
+    orig = (fm0.map2pro, fm0.map2xvec)
+    try:
+        fmod.install_gpu_gradient_maps()
+        FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+        Atm, Meas, Spec, Scat, Stel, Surf, CIA, Lay, Var, Ret = ans.Files.read_input_files("cirstest")
+        fm = FMGPU(runname="cirstest", Atmosphere=Atm, Surface=Surf, Measurement=Meas, Spectroscopy=Spec, Stellar=Stel,
+                   Scatter=Scat, CIA=CIA, Layer=Lay, Variables=Var)
+        SPECONV, dSPECONV = fm.nemesisfmg()
+    finally:
+        fm0.map2pro, fm0.map2xvec = orig
+        if hasattr(fm0, "_ansfm_reference_maps"):
+            del fm0._ansfm_reference_maps
+    assert double.map_calls >= 2
+    z = np.load(os.path.join(golden_dir, "c1_cirsrad_grad.npz"))
+    ref = z["dSPECONV"]
+    scale = np.abs(ref).max(axis=(0, 1), keepdims=True) + 1e-300
     assert np.max(np.abs(dSPECONV - ref) / scale) < 1e-5

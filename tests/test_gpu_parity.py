@@ -345,3 +345,58 @@ def test_layer_average_golden(eng, golden_dir, case):
         np.testing.assert_allclose(v[0], z[f"{case}_{n}"], rtol=1e-10, err_msg=n)
         np.testing.assert_allclose(v[2], z[f"{case}_{n}"], rtol=1e-10, err_msg=n)
     assert np.all(rb[2][1] > rb[2][0])          # TEMP of the warmed state
+
+
+def test_gradient_maps_golden(eng, golden_dir):
+    """ForwardModel_0.map2pro / map2xvec (matrix-core GEMM) vs the reference (golden): default and explicit INCPAR
+    (para-H2 slot = previous parameter's product), host-pointer and device-chained inputs."""
+    z = _load(golden_dir, "gradient_maps")
+    W, NVMR, NDUST, NPRO, NPATH, NX = (int(v) for v in z["dims"])
+    close = lambda a, b: np.testing.assert_allclose(a, b, rtol=0, atol=1e-13 * np.max(np.abs(b)))
+    a = eng.map2pro(z["dSPECIN"], W, NVMR, NDUST, NPRO, NPATH, z["NLAYIN"], z["LAYINC"], z["DTE"], z["DAM"], z["DCO"])
+    for par in range(NVMR + 2 + NDUST):
+        close(a[:, par], z["pro_all"][:, par])
+    x = eng.map2xvec(a, W, NVMR, NDUST, NPRO, NPATH, NX, z["xmap"])          # chained: a's device copy
+    close(x, z["xvec_all"])
+    x2 = eng.map2xvec(z["pro_all"].copy(), W, NVMR, NDUST, NPRO, NPATH, NX, z["xmap"])   # uploaded
+    close(x2, z["xvec_all"])
+    b = eng.map2pro(z["dSPECIN"], W, NVMR, NDUST, NPRO, NPATH, z["NLAYIN"], z["LAYINC"], z["DTE"], z["DAM"], z["DCO"],
+                    INCPAR=list(z["incpar"]))
+    for par in range(NVMR + 2 + NDUST):
+        close(b[:, par], z["pro_inc"][:, par])
+    assert np.array_equal(b[:, 6], b[:, 5]) and not np.any(b[:, 1])
+    with pytest.raises(UnboundLocalError):
+        eng.map2pro(z["dSPECIN"], W, NVMR, NDUST, NPRO, NPATH, z["NLAYIN"], z["LAYINC"], z["DTE"], z["DAM"], z["DCO"], INCPAR=[6, 0])
+
+
+def test_gradient_maps_vs_oracle_chained_from_cirsradg(eng, oracle):
+    """nemesisfmg's tail on the device: CIRSrad(return_grad=True) -> map2pro -> map2xvec with the intermediate arrays
+    taken from HBM (the arrays handed back are recognised), against the oracle fed the same host arrays."""
+    from archnemesis_dist_amd import synthetic as syn
+    W, G, S, L, NP, NT = 300, 8, 3, 24, 6, 5
+    _, delg = syn.gauss_legendre_01(G, True)
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S, seed=11)
+    eng.upload_ktable(K, PRESS, TEMP, 100.0 + np.arange(W), delg)
+    atm = syn.synth_atmosphere(L, S)
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L)
+    EMTEMP = atm["lay_temp"][0][LAYINC[:, 0]][:, None]
+    NVMR, NDUST = S, 1
+    NPAR = NVMR + 2 + NDUST
+    spec, dspec, dts = eng.cirsradg_ck_thermal(0, atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0], None, None,
+                                               NVMR, NPAR, np.arange(S, dtype=np.int32), NLAYIN, LAYINC, SCALE, EMTEMP, -1.0)
+    rng = np.random.default_rng(3)
+    NPRO, NX = 40, 17
+    DTE, DAM, DCO = (rng.uniform(0, 1, (L, NPRO)) for _ in range(3))
+    xmap = rng.normal(size=(NX, NPAR, NPRO))
+    pro = eng.map2pro(dspec, W, NVMR, NDUST, NPRO, 1, NLAYIN, LAYINC, DTE, DAM, DCO)
+    xv = eng.map2xvec(pro, W, NVMR, NDUST, NPRO, 1, NX, xmap)
+    pro_o = oracle.map2pro(dspec, W, NVMR, NDUST, NPRO, 1, NLAYIN, LAYINC, DTE, DAM, DCO)
+    xv_o = oracle.map2xvec(pro_o, W, NVMR, NDUST, NPRO, 1, NX, xmap)
+    for par in range(NPAR):
+        if np.any(pro_o[:, par]):
+            np.testing.assert_allclose(pro[:, par], pro_o[:, par], rtol=0, atol=1e-12 * np.max(np.abs(pro_o[:, par])))
+    np.testing.assert_allclose(xv, xv_o, rtol=0, atol=1e-12 * np.max(np.abs(xv_o)))
+    # a modified copy is NOT mistaken for the device-resident array
+    d2 = dspec.copy(); d2[:, 0] *= 2.0
+    pro2 = eng.map2pro(d2, W, NVMR, NDUST, NPRO, 1, NLAYIN, LAYINC, DTE, DAM, DCO)
+    np.testing.assert_allclose(pro2[:, 0], 2.0 * pro[:, 0], rtol=1e-12)

@@ -30,7 +30,39 @@ def main():
         bench_lbl(eng, out, rng)
     if only in (None, "layer"):
         bench_layer(eng, out)
+    if only in (None, "maps"):
+        bench_maps(eng, out, rng)
     print(json.dumps(out, indent=1))
+
+
+def bench_maps(eng, out, rng):
+    # ---- nemesisfmg tail at C2: map2pro + map2xvec, host arrays in / out vs NumPy on the host ---------------
+    W, NVMR, NDUST, Li, NPRO, NX = 10000, 8, 0, 100, 100, 200
+    NPAR = NVMR + 2 + NDUST
+    dS = rng.normal(size=(W, NPAR, Li, 1))
+    LAYINC = np.arange(Li, dtype=np.int32)[::-1].copy()[:, None]
+    DTE, DAM, DCO = (rng.uniform(0, 1, (Li, NPRO)) for _ in range(3))
+    xmap = rng.normal(size=(NX, NPAR, NPRO))
+    NLAYIN = np.array([Li], dtype=np.int32)
+
+    def gpu():
+        p = eng.map2pro(dS, W, NVMR, NDUST, NPRO, 1, NLAYIN, LAYINC, DTE, DAM, DCO)
+        return eng.map2xvec(p, W, NVMR, NDUST, NPRO, 1, NX, xmap)
+
+    def host():
+        p = np.zeros((W, NPAR, NPRO, 1))
+        last = None
+        for par in range(NPAR):
+            M = DAM if par < NVMR else (DTE if par == NVMR else (DCO if par <= NVMR + NDUST else None))
+            if M is not None:
+                last = np.tensordot(dS[:, par, :, 0], M[LAYINC[:, 0], :], axes=(1, 0))
+            p[:, par, :, 0] = last          # para-H2 slot: the reference's stale dSPECOUT1
+        return np.tensordot(p, xmap, axes=([1, 2], [1, 2]))
+    tg = timeit(gpu)
+    th = timeit(host, n=2)
+    err = float(np.max(np.abs(gpu() - host())) / np.max(np.abs(host())))
+    out["gradient_maps_C2"] = {"gpu_wall_s_host_ptr": tg, "numpy_host_wall_s": th, "max_rel_diff": err,
+                               "note": "W=1e4, NPAR=10, Li=100, NPRO=100, NX=200; GPU time includes 80 MB H2D + 96 MB D2H"}
 
 
 def bench_grad(eng, out):
