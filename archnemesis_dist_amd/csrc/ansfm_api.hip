@@ -1287,14 +1287,23 @@ int ansfm_add_line_set_monochromatic_absorption(
 /* ------------------------------------------------------------------------------------------ */
 /* layering                                                                                    */
 /* ------------------------------------------------------------------------------------------ */
-int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, const double *H, const double *P,
-                        const double *T, int NVMR, const double *VMR, int NDUST, const double *DUST, const double *PARAH2,
-                        int NLAY, const double *BASEH, double LAYANG, int LAYINT, double LAYHT, int NINT,
-                        const int32_t *DUST_UNITS, const double *XMOLWT, double *HEIGHT, double *PRESS, double *TEMP,
-                        double *TOTAM, double *AMOUNT, double *PP, double *CONT, double *FRAC, double *DELH, double *BASET,
-                        double *LAYSF)
+static int layer_average_impl(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, const double *H, const double *P,
+                              const double *T, int NVMR, const double *VMR, int NDUST, const double *DUST,
+                              const double *PARAH2, int NLAY, const double *BASEH, double LAYANG, int LAYINT, double LAYHT,
+                              int NINT, const int32_t *DUST_UNITS, const double *XMOLWT, double *HEIGHT, double *PRESS,
+                              double *TEMP, double *TOTAM, double *AMOUNT, double *PP, double *CONT, double *FRAC,
+                              double *DELH, double *BASET, double *LAYSF, bool with_grad, double *DTE, double *DAM,
+                              double *DCO, double *DPH)
 {
     CHECK_CTX(ctx);
+    int any_units = 0;
+    if (DUST_UNITS) for (int j = 0; j < NDUST; ++j) if (DUST_UNITS[j] == -1) any_units = 1;
+    if (with_grad) {
+        if (!DTE || !DAM || !DCO || !DPH) FAIL(ANSFM_ERR_INVALID, "layer_averageg: bad argument");
+        if ((NINT % 2) == 0) FAIL(ANSFM_ERR_INVALID, "NINT must be odd for Simpson's rule.");            // Layer_0.py:1188
+        if (LAYINT == 0 && any_units && NDUST > 0)
+            FAIL(ANSFM_ERR_INVALID, "setting an array element with a sequence.");   // the reference's failure at :1255-1257
+    }
     if (n_models <= 0 || NPRO < 2 || NVMR <= 0 || NDUST < 0 || NLAY <= 0 || !H || !P || !T || !VMR || !BASEH || !HEIGHT ||
         !PRESS || !TEMP || !TOTAM || !AMOUNT || !PP || !FRAC || !DELH || !BASET || !LAYSF || (NDUST > 0 && (!DUST || !CONT)) ||
         (LAYINT != 0 && LAYINT != 1))
@@ -1319,7 +1328,7 @@ int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, c
     UP(DUST_UNITS, (size_t)NDUST * sizeof(int32_t));                            // 8
 #undef UP
     const size_t nl = n * NLAY;
-    const size_t tot = nl * (8 + 2 * (size_t)NVMR + NDUST);
+    const size_t tot = nl * (8 + 2 * (size_t)NVMR + NDUST) + (with_grad ? 4 * nl * NPRO : 0);
     HIPCHK(ctx->tmp_out.reserve(tot * D));
     double *o = ctx->tmp_out.as<double>();
     LayerAvgParams p;
@@ -1331,6 +1340,11 @@ int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, c
     p.BASET = o + 6 * nl; p.LAYSF = o + 7 * nl; p.AMOUNT = o + 8 * nl; p.PP = p.AMOUNT + nl * NVMR; p.CONT = p.PP + nl * NVMR;
     p.RADIUS = RADIUS; p.LAYANG = LAYANG; p.LAYHT = LAYHT;
     p.n_models = n_models; p.NPRO = NPRO; p.NVMR = NVMR; p.NDUST = NDUST; p.NLAY = NLAY; p.LAYINT = LAYINT; p.NINT = NINT;
+    if (with_grad) {
+        p.with_grad = 1; p.any_dust_units = any_units;
+        p.DTE = p.CONT + nl * NDUST; p.DAM = p.DTE + nl * NPRO; p.DCO = p.DAM + nl * NPRO; p.DPH = p.DCO + nl * NPRO;
+        HIPCHK(hipMemsetAsync(p.DTE, 0, 4 * nl * NPRO * D, ctx->stream));
+    }
     hipLaunchKernelGGL(k_layer_average, dim3((unsigned)NLAY, (unsigned)n_models), dim3(128), 0, ctx->stream, p);
     HIPCHK(hipGetLastError());
     double *outs[8] = {HEIGHT, PRESS, TEMP, TOTAM, FRAC, DELH, BASET, LAYSF};
@@ -1338,8 +1352,38 @@ int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, c
     HIPCHK(hipMemcpyAsync(AMOUNT, p.AMOUNT, nl * NVMR * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(PP, p.PP, nl * NVMR * D, hipMemcpyDeviceToHost, ctx->stream));
     if (NDUST > 0) HIPCHK(hipMemcpyAsync(CONT, p.CONT, nl * NDUST * D, hipMemcpyDeviceToHost, ctx->stream));
+    if (with_grad) {
+        double *mo[4] = {DTE, DAM, DCO, DPH};
+        const double *ms[4] = {p.DTE, p.DAM, p.DCO, p.DPH};
+        for (int k = 0; k < 4; ++k) HIPCHK(hipMemcpyAsync(mo[k], ms[k], nl * NPRO * D, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ANSFM_OK;
+}
+
+
+int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, const double *H, const double *P,
+                        const double *T, int NVMR, const double *VMR, int NDUST, const double *DUST, const double *PARAH2,
+                        int NLAY, const double *BASEH, double LAYANG, int LAYINT, double LAYHT, int NINT,
+                        const int32_t *DUST_UNITS, const double *XMOLWT, double *HEIGHT, double *PRESS, double *TEMP,
+                        double *TOTAM, double *AMOUNT, double *PP, double *CONT, double *FRAC, double *DELH, double *BASET,
+                        double *LAYSF)
+{
+    return layer_average_impl(ctx, n_models, RADIUS, NPRO, H, P, T, NVMR, VMR, NDUST, DUST, PARAH2, NLAY, BASEH, LAYANG, LAYINT,
+                              LAYHT, NINT, DUST_UNITS, XMOLWT, HEIGHT, PRESS, TEMP, TOTAM, AMOUNT, PP, CONT, FRAC, DELH, BASET,
+                              LAYSF, false, nullptr, nullptr, nullptr, nullptr);
+}
+
+int ansfm_layer_averageg(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, const double *H, const double *P,
+                         const double *T, int NVMR, const double *VMR, int NDUST, const double *DUST, const double *PARAH2,
+                         int NLAY, const double *BASEH, double LAYANG, int LAYINT, double LAYHT, int NINT,
+                         const int32_t *DUST_UNITS, const double *XMOLWT, double *HEIGHT, double *PRESS, double *TEMP,
+                         double *TOTAM, double *AMOUNT, double *PP, double *CONT, double *FRAC, double *DELH, double *BASET,
+                         double *LAYSF, double *DTE, double *DAM, double *DCO, double *DPH)
+{
+    return layer_average_impl(ctx, n_models, RADIUS, NPRO, H, P, T, NVMR, VMR, NDUST, DUST, PARAH2, NLAY, BASEH, LAYANG, LAYINT,
+                              LAYHT, NINT, DUST_UNITS, XMOLWT, HEIGHT, PRESS, TEMP, TOTAM, AMOUNT, PP, CONT, FRAC, DELH, BASET,
+                              LAYSF, true, DTE, DAM, DCO, DPH);
 }
 
 }  // extern "C"

@@ -29,7 +29,23 @@ struct LayerAvgParams {
     double *CONT;                   // [n][NLAY][NDUST]
     double RADIUS, LAYANG, LAYHT;
     int n_models, NPRO, NVMR, NDUST, NLAY, LAYINT, NINT;
+    // layer_averageg (Layer_0.py:1032-1398): T / PARAH2 / VMR / DUST through the reference's `interpg` and the
+    // matrices DTE, DAM, DCO, DPH [n][NLAY][NPRO] (zeroed by the caller)
+    int with_grad, any_dust_units;
+    double *DTE, *DAM, *DCO, *DPH;
 };
+
+// Layer_0.interpg (:716-751): j = clip(#{x <= X}, 1, n-1)
+__device__ __forceinline__ int lay_bracket_g(const double *x, int n, double xn)
+{
+    int lo = 0, hi = n;                       // first index with x > xn
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (x[mid] <= xn) lo = mid + 1; else hi = mid; }
+    return lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+}
+__device__ __forceinline__ double lay_interp_g(const double *y, int stride, int j, double F)
+{
+    return (1.0 - F) * y[(size_t)(j - 1) * stride] + F * y[(size_t)j * stride];
+}
 
 __device__ __forceinline__ int lay_bracket(const double *x, int n, double xn)
 {   // scipy interp1d linear: idx = clip(searchsorted(x, xn, 'left'), 1, n-1)
@@ -47,8 +63,10 @@ __device__ __forceinline__ double lay_interp(const double *x, const double *y, i
 __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
 {
     __shared__ double S[kLayMaxNint], hh[kLayMaxNint], pp[kLayMaxNint], duds[kLayMaxNint], mw[kLayMaxNint];
-    __shared__ int idx[kLayMaxNint];
+    __shared__ int idx[kLayMaxNint], jg[kLayMaxNint];
+    __shared__ double FF[kLayMaxNint];
     __shared__ double res[160];
+    const bool GR = p.with_grad != 0;
     const double k_B = 1.38065e-23, AVOGAD = 6.02214076e23, PI = 3.141592653589793;
     const int I = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
     const int NPRO = p.NPRO, V = p.NVMR, D = p.NDUST, NL = p.NLAY;
@@ -74,7 +92,14 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
         else { const double step = (S1 - S0) / (p.NINT - 1); s = (k == p.NINT - 1) ? S1 : k * step + S0; }   // np.linspace
         const double h = sqrt(s * s + z0 * z0 + 2 * s * z0 * cs) - p.RADIUS;
         const int ix = lay_bracket(H, NPRO, h);
-        const double pk = lay_interp(H, P, 1, ix, h), tk = lay_interp(H, T, 1, ix, h);
+        const double pk = lay_interp(H, P, 1, ix, h);
+        double tk = lay_interp(H, T, 1, ix, h);
+        if (GR) {
+            const int j = lay_bracket_g(H, NPRO, h);
+            const double F = (h - H[j - 1]) / (H[j] - H[j - 1]);
+            jg[k] = j; FF[k] = F;
+            tk = lay_interp_g(T, 1, j, F);
+        }
         S[k] = s; hh[k] = h; idx[k] = ix; pp[k] = pk;
         duds[k] = pk / (k_B * tk);
         mw[k] = XM ? lay_interp(H, XM, 1, ix, h) * 1000. : 0.0;       // XMOLWT *= 1000 :877
@@ -89,6 +114,18 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
             if (q == 0) return duds[k];
             if (q == 1) return h * duds[k];
             if (q == 2) return pp[k] * duds[k];
+            if (GR) {
+                const int j = jg[k];
+                const double F = FF[k];
+                if (q == 3) return lay_interp_g(T, 1, j, F) * duds[k];
+                if (q == 4) return (PH2 ? lay_interp_g(PH2, 1, j, F) : 0.0) * duds[k];
+                if (q < 5 + V) return lay_interp_g(VMR + (q - 5), V, j, F) * duds[k];
+                if (q < 5 + 2 * V) return (lay_interp_g(VMR + (q - 5 - V), V, j, F) * pp[k]) * duds[k];
+                const int J = q - 5 - 2 * V;
+                const double dd = (p.LAYINT == 0) ? lay_interp(H, DUST + J, D, ix, h)      // MID_PATH: interp1d (:1231)
+                                                  : lay_interp_g(DUST + J, D, j, F);
+                return (p.dust_units && p.dust_units[J] == -1) ? dd * duds[k] * mw[k] / AVOGAD : dd;
+            }
             if (q == 3) return lay_interp(H, T, 1, ix, h) * duds[k];
             if (q == 4) return (PH2 ? lay_interp(H, PH2, 1, ix, h) : 0.0) * duds[k];
             if (q < 5 + V) return lay_interp(H, VMR + (q - 5), V, ix, h) * duds[k];
@@ -120,13 +157,23 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
         const double hmid = hh[0], PR = pp[0];
         const int ix = idx[0];
         if (tid == 0) {
-            p.HEIGHT[o] = hmid; p.PRESS[o] = PR; p.TEMP[o] = lay_interp(H, T, 1, ix, hmid);
-            p.FRAC[o] = PH2 ? lay_interp(H, PH2, 1, ix, hmid) : 0.0;
+            p.HEIGHT[o] = hmid; p.PRESS[o] = PR;
+            p.TEMP[o] = GR ? lay_interp_g(T, 1, jg[0], FF[0]) : lay_interp(H, T, 1, ix, hmid);
+            p.FRAC[o] = PH2 ? (GR ? lay_interp_g(PH2, 1, jg[0], FF[0]) : lay_interp(H, PH2, 1, ix, hmid)) : 0.0;
             p.TOTAM[o] = TOT / LAYSF;
+            if (GR) {   // :1209-1221, :1252-1254, then / LAYSF (:1388-1390)
+                const int j = jg[0];
+                const double F = FF[0];
+                double *dte = p.DTE + o * NPRO, *dam = p.DAM + o * NPRO, *dco = p.DCO + o * NPRO, *dph = p.DPH + o * NPRO;
+                dte[j - 1] += (1.0 - F); dte[j] += F;
+                dph[j - 1] += (1.0 - F); dph[j] += F;
+                dam[j - 1] = ((1.0 - F) * TOT) / LAYSF; dam[j] = (F * TOT) / LAYSF;
+                if (D > 0) { dco[j - 1] = (1.0 - F) / LAYSF; dco[j] = F / LAYSF; }
+            }
             p.DELH[o] = DELH; p.LAYSF[o] = LAYSF; p.BASET[o] = lay_interp(H, T, 1, lay_bracket(H, NPRO, BASEH[I]), BASEH[I]);
         }
         for (int J = tid; J < V; J += blockDim.x) {
-            const double a = lay_interp(H, VMR + J, V, ix, hmid);
+            const double a = GR ? lay_interp_g(VMR + J, V, jg[0], FF[0]) : lay_interp(H, VMR + J, V, ix, hmid);
             p.PP[o * V + J] = a * PR;
             p.AMOUNT[o * V + J] = (a * TOT) * pow(LAYSF, -1.0);
         }
@@ -147,6 +194,28 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
             p.PP[o * V + J] = res[5 + V + J] / TOT;
         }
         for (int J = tid; J < D; J += blockDim.x) p.CONT[o * D + J] = res[5 + 2 * V + J] * pow(LAYSF, -1.0);
+        if (GR && tid < 4) {
+            // :1280-1284, :1303-1305, :1336-1343 -- sequential over the sub-points like the reference, one thread per
+            // matrix (0 DTE, 1 DPH, 2 DAM, 3 DCO), then the scaling of :1346-1350 and the / LAYSF of :1388-1390
+            if (tid == 3 && D == 0) return;
+            double *row = (tid == 0 ? p.DTE : tid == 1 ? p.DPH : tid == 2 ? p.DAM : p.DCO) + o * NPRO;
+            for (int k = 0; k < npts; ++k) {
+                const double w = (k == 0 || k == npts - 1) ? 1.0 : ((k & 1) ? 4.0 : 2.0);
+                const int j = jg[k];
+                const double F = FF[k];
+                double lo, hi;
+                if (tid <= 1) { lo = (1. - F) * w * duds[k]; hi = F * w * duds[k]; }
+                else if (tid == 2) { lo = (1. - F) * duds[k] * w; hi = F * duds[k] * w; }
+                else if (!p.any_dust_units) { lo = (1. - F) * w; hi = F * w; }
+                else { lo = (1. - F) * w * duds[k] * mw[k] / AVOGAD; hi = F * w * duds[k] * mw[k] / AVOGAD; }
+                row[j - 1] += lo; row[j] += hi;
+            }
+            for (int k = 0; k < NPRO; ++k) {
+                double v = row[k] * DELS / (p.NINT - 1.) / 3.;
+                if (tid <= 1) v = v / TOT; else v = v / LAYSF;
+                row[k] = v;
+            }
+        }
     }
 }
 

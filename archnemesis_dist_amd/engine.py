@@ -280,6 +280,16 @@ class AnsfmEngine:
         """Layer_0.layer_average (:755), same argument order (ID and BASEP are unused there too).  A leading
         state axis on H/P/T/VMR/DUST/PARAH2/BASEH batches the call.  Returns
         HEIGHT,PRESS,TEMP,TOTAM,AMOUNT,PP,CONT,FRAC,DELH,BASET,LAYSF."""
+        return self._layer_average(False, RADIUS, H, P, T, VMR, DUST, PARAH2, BASEH, LAYANG, LAYINT, LAYHT, NINT,
+                                   DUST_UNITS, XMOLWT)
+
+    def layer_averageg(self, RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP=None, LAYANG=0.0, LAYINT=0, LAYHT=0.0,
+                       NINT=101, DUST_UNITS=None, XMOLWT=None):
+        """Layer_0.layer_averageg (:1032): layer_average's outputs followed by DTE, DAM, DCO, DPH (NLAY, NPRO)."""
+        return self._layer_average(True, RADIUS, H, P, T, VMR, DUST, PARAH2, BASEH, LAYANG, LAYINT, LAYHT, NINT,
+                                   DUST_UNITS, XMOLWT)
+
+    def _layer_average(self, grad, RADIUS, H, P, T, VMR, DUST, PARAH2, BASEH, LAYANG, LAYINT, LAYHT, NINT, DUST_UNITS, XMOLWT):
         H = _np(H); single = H.ndim == 1
         H2 = np.atleast_2d(H); n, NPRO = H2.shape
         P2 = _np(P).reshape(n, NPRO); T2 = _np(T).reshape(n, NPRO)
@@ -292,13 +302,17 @@ class AnsfmEngine:
         mk = lambda *shape: np.empty(shape)
         HEIGHT, PRESS, TEMP, TOTAM, FRAC, DELH, BASET, LAYSF = (mk(n, NL) for _ in range(8))
         AMOUNT, PPo, CONT = mk(n, NL, NV), mk(n, NL, NV), mk(n, NL, ND)
-        rc = self._lib.ansfm_layer_average(
-            self._ctx, n, float(RADIUS), NPRO, _ptr(H2), _ptr(P2), _ptr(T2), NV, _ptr(V2), ND, _ptr(D2), _ptr(PH), NL, _ptr(BH),
-            float(LAYANG), int(LAYINT), float(LAYHT), int(NINT), _ptr(_np(DUST_UNITS, np.int32)), _ptr(XM), _ptr(HEIGHT),
-            _ptr(PRESS), _ptr(TEMP), _ptr(TOTAM), _ptr(AMOUNT), _ptr(PPo), _ptr(CONT), _ptr(FRAC), _ptr(DELH), _ptr(BASET),
-            _ptr(LAYSF))
-        self._check(rc, "layer_average")
+        args = [self._ctx, n, float(RADIUS), NPRO, _ptr(H2), _ptr(P2), _ptr(T2), NV, _ptr(V2), ND, _ptr(D2), _ptr(PH), NL, _ptr(BH),
+                float(LAYANG), int(LAYINT), float(LAYHT), int(NINT), _ptr(_np(DUST_UNITS, np.int32)), _ptr(XM), _ptr(HEIGHT),
+                _ptr(PRESS), _ptr(TEMP), _ptr(TOTAM), _ptr(AMOUNT), _ptr(PPo), _ptr(CONT), _ptr(FRAC), _ptr(DELH), _ptr(BASET),
+                _ptr(LAYSF)]
         out = (HEIGHT, PRESS, TEMP, TOTAM, AMOUNT, PPo, CONT, FRAC, DELH, BASET, LAYSF)
+        if grad:
+            M = tuple(mk(n, NL, NPRO) for _ in range(4))
+            self._check(self._lib.ansfm_layer_averageg(*args, *(_ptr(m) for m in M)), "layer_averageg")
+            out = out + M
+        else:
+            self._check(self._lib.ansfm_layer_average(*args), "layer_average")
         return tuple(a[0] for a in out) if single else out
 
     def map2pro(self, dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NLAYIN, LAYINC, DTE, DAM, DCO, INCPAR=(-1,)):

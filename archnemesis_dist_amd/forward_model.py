@@ -280,3 +280,29 @@ def install_gpu_gradient_maps(device=0):
     fm.map2pro = map2pro
     fm.map2xvec = map2xvec
     return map2pro, map2xvec
+
+
+def install_gpu_layering(device=0):
+    """Route Layer_0.layer_average / layer_averageg (Layer_0.py:755, :1032; called by the Layer_0 methods of the same
+    names, :509 / :552, from calc_path / calc_pathg) through the GPU."""
+    import importlib
+    l0 = importlib.import_module("archnemesis.Layer_0")
+    eng = get_engine(device)
+    if not hasattr(l0, "_ansfm_reference_layering"):
+        l0._ansfm_reference_layering = (l0.layer_average, l0.layer_averageg)
+
+    def _wrap(fn):
+        def f(RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP, LAYANG=0.0, LAYINT=0, LAYHT=0.0, NINT=101,
+              DUST_UNITS=None, XMOLWT=None):
+            r = list(fn(RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP, LAYANG=LAYANG, LAYINT=int(LAYINT), LAYHT=LAYHT,
+                        NINT=NINT, DUST_UNITS=DUST_UNITS, XMOLWT=XMOLWT))
+            if np.ndim(VMR) == 1:                      # single-gas profiles come back 1-D in the reference
+                r[4] = r[4][:, 0]; r[5] = r[5][:, 0]
+            if DUST is not None and np.ndim(DUST) == 1:
+                r[6] = r[6][:, 0]
+            return tuple(r)
+        return f
+
+    l0.layer_average = _wrap(eng.layer_average)
+    l0.layer_averageg = _wrap(eng.layer_averageg)
+    return l0.layer_average, l0.layer_averageg

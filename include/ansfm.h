@@ -223,6 +223,20 @@ int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, c
                         double *AMOUNT, double *PP, double *CONT, double *FRAC, double *DELH,
                         double *BASET, double *LAYSF);
 
+/* Layer_0.layer_averageg (Layer_0.py:1032-1398): the same plus DTE, DAM, DCO, DPH [n][NLAY][NPRO], the matrices
+ * relating layer temperature / gas amounts / dust amounts / para-H2 fraction to the profile levels (consumed by
+ * map2pro).  T, PARAH2, VMR and DUST go through the reference's own `interpg` bracket (:716-751) here, so the layer
+ * values differ from ansfm_layer_average's in the last bits exactly as the reference's two functions do.
+ * ANSFM_ERR_INVALID for an even NINT (ValueError :1188) and for MID_PATH with DUST_UNITS == -1 (the reference
+ * fails there, :1255-1257). */
+int ansfm_layer_averageg(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, const double *H,
+                         const double *P, const double *T, int NVMR, const double *VMR, int NDUST,
+                         const double *DUST, const double *PARAH2, int NLAY, const double *BASEH,
+                         double LAYANG, int LAYINT, double LAYHT, int NINT, const int32_t *DUST_UNITS,
+                         const double *XMOLWT, double *HEIGHT, double *PRESS, double *TEMP, double *TOTAM,
+                         double *AMOUNT, double *PP, double *CONT, double *FRAC, double *DELH,
+                         double *BASET, double *LAYSF, double *DTE, double *DAM, double *DCO, double *DPH);
+
 /* ---- gradient maps ------------------------------------------------------------------------------------
  * ForwardModel_0.map2pro (ForwardModel_0.py:5319-5383): layer gradients -> profile-level gradients,
  *   dSPECOUT[W][NPAR][NPRO][P] = sum_j dSPECIN[W][NPAR][LIMAX][P] * M[LAYINC[j][p]][NPRO], M = DAM for gas

@@ -41,6 +41,18 @@ def main():
             out[f"{cn}_{n}"] = np.asarray(v)
         print(cn, r[3][:3])
     np.savez_compressed(os.path.join(OUT, "layer_average.npz"), **out)
+    # ---- layer_averageg (:1032): same inputs, plus the DTE/DAM/DCO/DPH matrices -------------------------------
+    gnames = names + ["DTE", "DAM", "DCO", "DPH"]
+    gout = {k: out[k] for k in ("RADIUS", "H", "P", "T", "VMR", "DUST", "PARAH2", "XMOLWT", "split1_BASEH", "split1_BASEP")}
+    for cn, kw in cases.items():
+        kw = dict(kw)
+        if "XMOLWT" in kw:
+            kw["XMOLWT"] = XMOLWT.copy()            # the reference scales it in place (:1144, :1394)
+        r = L0.layer_averageg(RADIUS, H, P, T, np.arange(NV), VMR, DUST, PARAH2, BASEH, BASEP, LAYHT=-6.0e4, NINT=101, **kw)
+        for n, v in zip(gnames, r):
+            gout[f"{cn}_{n}"] = np.asarray(v)
+        print("g", cn, np.abs(r[11]).sum(), np.abs(r[12]).sum(), np.abs(r[13]).sum())
+    np.savez_compressed(os.path.join(OUT, "layer_averageg.npz"), **gout)
 
 
 if __name__ == "__main__":

@@ -270,6 +270,29 @@ def layer_average(RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP, LAYANG=0
     return o[0], o[1], o[2], o[3], AM, PPo, CO, FR, DELH, BASET, LAYSF
 
 
+def layer_averageg(RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP, LAYANG=0.0, LAYINT=0, LAYHT=0.0, NINT=101,
+                   DUST_UNITS=None, XMOLWT=None):
+    """Layer_0.layer_averageg (:1032) -> HEIGHT,PRESS,TEMP,TOTAM,AMOUNT,PP,CONT,FRAC,DELH,BASET,LAYSF,DTE,DAM,DCO,DPH."""
+    H = _c(H); P = _c(P); T = _c(T); BASEH = _c(BASEH)
+    VMR = _c(VMR).reshape(H.size, -1); NV = VMR.shape[1]
+    ND = 0 if DUST is None else _c(DUST).reshape(H.size, -1).shape[1]
+    D = None if DUST is None else _c(DUST).reshape(H.size, -1)
+    NL = BASEH.size
+    o = [np.zeros(NL) for _ in range(4)]
+    AM = np.zeros((NL, NV)); PPo = np.zeros((NL, NV)); CO = np.zeros((NL, ND)); FR = np.zeros(NL)
+    DELH = np.zeros(NL); BASET = np.zeros(NL); LAYSF = np.zeros(NL)
+    M = [np.zeros((NL, H.size)) for _ in range(4)]
+    rc = lib().orc_layer_averageg(C.c_double(RADIUS), H.size, _p(H), _p(P), _p(T), NV, _p(VMR), ND, _p(D), _p(_c(PARAH2)), NL,
+                                  _p(BASEH), C.c_double(LAYANG), int(LAYINT), C.c_double(LAYHT), int(NINT),
+                                  _p(_c(DUST_UNITS, np.int32)), _p(_c(XMOLWT)), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(AM),
+                                  _p(PPo), _p(CO), _p(FR), _p(DELH), _p(BASET), _p(LAYSF), _p(M[0]), _p(M[1]), _p(M[2]), _p(M[3]))
+    if rc == 5:
+        raise ValueError("NINT must be odd for Simpson's rule.")
+    if rc:
+        raise ValueError("setting an array element with a sequence.")   # the reference's MID_PATH + DUST_UNITS=-1 failure
+    return (o[0], o[1], o[2], o[3], AM, PPo, CO, FR, DELH, BASET, LAYSF) + tuple(M)
+
+
 # ---- gradient maps (ForwardModel_0.map2pro :5319-5383, map2xvec :5387-5424) ----------------------------------
 def map2pro(dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NLAYIN, LAYINC, DTE, DAM, DCO, INCPAR=(-1,)):
     """NumPy restatement: per (path, listed parameter) a (NWAVE x NLAYIN)·(NLAYIN x NPRO) product with the rows

@@ -44,6 +44,14 @@ class OracleEngineDouble:
                                               return_taugas=True)[1]
         return r
 
+    def layer_average(self, *a, **k):
+        self.lay_calls = getattr(self, "lay_calls", 0) + 1
+        return self.orc.layer_average(*a, **k)
+
+    def layer_averageg(self, *a, **k):
+        self.lay_calls = getattr(self, "lay_calls", 0) + 1
+        return self.orc.layer_averageg(*a, **k)
+
     def map2pro(self, *a, **k):
         self.map_calls = getattr(self, "map_calls", 0) + 1
         return self.orc.map2pro(*a, **k)
@@ -134,16 +142,20 @@ def test_nemesisfmg_through_the_adapter_matches_the_reference(c1_run, oracle, go
 
 def test_nemesisfmg_with_gradient_maps_routed_through_the_engine(c1_run, oracle, golden_dir, monkeypatch):
     """install_gpu_gradient_maps: nemesisfmg's map2pro / map2xvec calls (:705-711) land on the engine's entry points
-    with the reference's arguments, and the result is still the reference's dSPECONV."""
+    with the reference's arguments -- likewise Layer_0.layer_averageg via install_gpu_layering (calc_pathg) -- and the
+    result is still the reference's dSPECONV."""
     ans = c1_run
     import importlib
     import archnemesis_dist_amd.forward_model as fmod
     fm0 = importlib.import_module("archnemesis.ForwardModel_0")
     double = OracleEngineDouble(oracle)
     monkeypatch.setattr(fmod, "get_engine", lambda device=0: double)
+    l0 = importlib.import_module("archnemesis.Layer_0")
     orig = (fm0.map2pro, fm0.map2xvec)
+    orig_l = (l0.layer_average, l0.layer_averageg)
     try:
         fmod.install_gpu_gradient_maps()
+        fmod.install_gpu_layering()
         FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
         Atm, Meas, Spec, Scat, Stel, Surf, CIA, Lay, Var, Ret = ans.Files.read_input_files("cirstest")
         fm = FMGPU(runname="cirstest", Atmosphere=Atm, Surface=Surf, Measurement=Meas, Spectroscopy=Spec, Stellar=Stel,
@@ -151,9 +163,11 @@ def test_nemesisfmg_with_gradient_maps_routed_through_the_engine(c1_run, oracle,
         SPECONV, dSPECONV = fm.nemesisfmg()
     finally:
         fm0.map2pro, fm0.map2xvec = orig
-        if hasattr(fm0, "_ansfm_reference_maps"):
-            del fm0._ansfm_reference_maps
-    assert double.map_calls >= 2
+        l0.layer_average, l0.layer_averageg = orig_l
+        for mod, name in ((fm0, "_ansfm_reference_maps"), (l0, "_ansfm_reference_layering")):
+            if hasattr(mod, name):
+                delattr(mod, name)
+    assert double.map_calls >= 2 and double.lay_calls >= 1
     z = np.load(os.path.join(golden_dir, "c1_cirsrad_grad.npz"))
     ref = z["dSPECONV"]
     scale = np.abs(ref).max(axis=(0, 1), keepdims=True) + 1e-300

@@ -400,3 +400,29 @@ def test_gradient_maps_vs_oracle_chained_from_cirsradg(eng, oracle):
     d2 = dspec.copy(); d2[:, 0] *= 2.0
     pro2 = eng.map2pro(d2, W, NVMR, NDUST, NPRO, 1, NLAYIN, LAYINC, DTE, DAM, DCO)
     np.testing.assert_allclose(pro2[:, 0], 2.0 * pro[:, 0], rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["cg_nadir", "cg_slant", "mid_slant", "cg_dustunits"])
+def test_layer_averageg_golden(eng, golden_dir, case):
+    """Layer_0.layer_averageg (:1032) vs the reference (golden): layer values through `interpg` and the DTE/DAM/DCO/DPH
+    matrices; a batch of states; the reference's two ValueErrors."""
+    from test_layer_oracle import GNAMES, CASES
+    z = _load(golden_dir, "layer_averageg")
+    kw = dict(CASES[case]); du = kw.pop("dust_units", False)
+    args = dict(LAYHT=-6.0e4, NINT=101, DUST_UNITS=np.array([-1, 0]) if du else None, XMOLWT=z["XMOLWT"] if du else None, **kw)
+    a = (float(z["RADIUS"]), z["H"], z["P"], z["T"], None, z["VMR"], z["DUST"], z["PARAH2"], z["split1_BASEH"], z["split1_BASEP"])
+    r = eng.layer_averageg(*a, **args)
+    for n, v in zip(GNAMES, r):
+        ref = z[f"{case}_{n}"]
+        np.testing.assert_allclose(v, ref, rtol=1e-10, atol=1e-13 * np.max(np.abs(ref)), err_msg=n)
+    rep = lambda x: np.repeat(np.asarray(x)[None], 2, 0)
+    rb = eng.layer_averageg(float(z["RADIUS"]), rep(z["H"]), rep(z["P"]), np.stack([z["T"] * 1.02, z["T"]]), None, rep(z["VMR"]),
+                            rep(z["DUST"]), rep(z["PARAH2"]), z["split1_BASEH"], None, **args)
+    for n, v in zip(GNAMES, rb):
+        ref = z[f"{case}_{n}"]
+        np.testing.assert_allclose(v[1], ref, rtol=1e-10, atol=1e-13 * np.max(np.abs(ref)), err_msg=n)
+    if case == "cg_nadir":
+        with pytest.raises(ValueError):
+            eng.layer_averageg(*a, LAYHT=-6.0e4, NINT=100, LAYINT=1)
+        with pytest.raises(ValueError):
+            eng.layer_averageg(*a, LAYHT=-6.0e4, NINT=101, LAYINT=0, DUST_UNITS=np.array([-1, 0]), XMOLWT=z["XMOLWT"])
