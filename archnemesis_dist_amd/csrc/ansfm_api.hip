@@ -1059,7 +1059,6 @@ int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const
     for (int i = 0; i < ngeom; ++i) { if (emiss_angs[i] < 90) ++nless; if (emiss_angs[i] > 90) ++nmore; }
     if (nless != ngeom && nmore != ngeom)
         FAIL(ANSFM_ERR_INVALID, "Emission angles are a mix of values above and below 90 degrees.");   // :776
-    if (nmore == ngeom) FAIL(ANSFM_ERR_UNSUPPORTED, "scloud11wave_core: look-up geometry (emission angle > 90) not built");
     HIPCHK(hipSetDevice(ctx->device));
     MsParams p;
     memset(&p, 0, sizeof p);
@@ -1082,6 +1081,7 @@ int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const
     p.tauray = (const double *)d[6]; p.omegas = (const double *)d[7]; p.lfrac = (const double *)d[8];
     p.ncont = ncont; p.ncomp = ncont + 1; p.nwave = nwave; p.nth = nth; p.ngeom = ngeom; p.lowbc = lowbc; p.nmu = nmu;
     p.nf = nf; p.ng = ng; p.nlay = nlay; p.nphi = nphi; p.iray = iray; p.imie = imie;
+    p.lookup = (nmore == ngeom) ? 1 : 0;
     double xs = 0.0;
     for (int k = 0; k < nmu; ++k) { xs += mu1[k] * wt1[k]; p.mu[k] = mu1[nmu - 1 - k]; p.wtmu[k] = wt1[nmu - 1 - k]; }
     p.xfac = 0.5 / xs;                                          // :720-722

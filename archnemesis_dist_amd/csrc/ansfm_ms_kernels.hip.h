@@ -1,8 +1,9 @@
 // ansfm_ms_kernels.hip.h -- doubling/adding multiple-scattering core on gfx950.
 //
 // Restates Multiple_Scattering_Core.scloud11wave_core (Multiple_Scattering_Core.py:651-960) and its
-// callees phasint2 :141, hansen :200, add :275, double1 :321, addp :481, angle_quadrature :535,
-// calc_rtj_matrix :566, for the look-down geometry.
+// callees phasint2 :141, hansen :200, add :275, double1 :321, idown :366, addp :481, angle_quadrature :535,
+// calc_rtj_matrix :566, for both viewing geometries (look-down: surface first, layers bottom to top; look-up: layers
+// top to bottom, the surface kept apart and combined through idown when lowbc > 0).
 //
 // Decomposition (every (wavenumber, g, Fourier order) chain is independent):
 //   k_ms_phase   one block per (wave, scatterer): azimuth-integrated phase matrices P++ / P+- for
@@ -47,6 +48,7 @@ struct MsParams {
     double sol_ang[kMsMaxPath], emiss_ang[kMsMaxPath], aphi[kMsMaxPath];
     double xfac;
     int hansen_comp0, phase_comp0;
+    int lookup;              // all emission angles > 90: layers top to bottom, surface brought in with idown (:366-420)
 };
 
 __device__ __forceinline__ double ms_interp(double x, const double *xp, const double *fp, int n)
@@ -290,7 +292,8 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
     if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // radg[:, ::-1] :765
     __syncthreads();
     bool defined = false;
-    if (p.lowbc > 0) {  // surface operator first :824-836
+    const bool lookup = p.lookup != 0;
+    if (p.lowbc > 0 && !lookup) {  // surface operator first :824-836
         MS_FOR_IJ {
             MS_AT(rc, i, j) = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
             MS_AT(tc, i, j) = 0.0;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
     const double *FC = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp) * nn;   // ppl *= fc (:232)
 
     for (int l = 0; l < p.nlay; ++l) {
-        const int k = l;  // look-down: bottom layer first (:842-845)
+        const int k = lookup ? p.nlay - 1 - l : l;  // look-down: bottom layer first (:842-845)
         const double taut = p.taus[((size_t)widx * p.ng + ig) * p.nlay + k];
         const double bc = p.bnu[(size_t)widx * p.nlay + k];
         double omega = p.omegas[((size_t)widx * p.ng + ig) * p.nlay + k];
@@ -429,10 +432,24 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
     }
     if (ic != 0 && lane < n) jc[lane] = 0.0;   // :881-882
     __syncthreads();
+    if (lookup && p.lowbc > 0) {
+        // idown (:366-420) with rb = rs, tb = 0, jb = radg (js is set for every ic, :822):
+        //   upl = (E - rc rs)^-1 (tc u0+ + (rc radg + jc));   m3 = the inverse, v0 = rc radg + jc
+        MS_FOR_IJ MS_AT(m0, i, j) = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
+        __syncthreads();
+        ms_mm(n, ld, rc, m0, m1, lane);
+        MS_FOR_IJ MS_AT(m2, i, j) = ((i == j) ? 1.0 : 0.0) - MS_AT(m1, i, j);
+        __syncthreads();
+        ms_inv(n, ld, m2, m3, col, lane);
+        ms_mv(n, ld, rc, radg, v0, lane);
+        if (lane < n) v0[lane] = v0[lane] + jc[lane];
+        __syncthreads();
+    }
     // ---- per path: the four (mu0, mu) samples and the bilinear interpolation :886-945 ---------------------------
     if (lane < p.ngeom) {
         const int ipath = lane;
-        const double sol_ang = p.sol_ang[ipath], emiss_ang = p.emiss_ang[ipath];
+        const double sol_ang = p.sol_ang[ipath];
+        const double emiss_ang = lookup ? 180. - p.emiss_ang[ipath] : p.emiss_ang[ipath];   // new_emi :900-903
         double zmu0, solar1;
         if (sol_ang > 90.0) { zmu0 = cos((180 - sol_ang) * pi / 180.0); solar1 = p.solar[widx] * 0.0; }
         else { zmu0 = cos(sol_ang * pi / 180.0); solar1 = p.solar[widx]; }
@@ -449,9 +466,19 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
         for (int imu0 = isol; imu0 < isol + 2; ++imu0) {
             const double s0 = solar1 / (2.0 * pi * p.wtmu[imu0]);
             for (int imu = iemm; imu < iemm + 2; ++imu) {
-                double bcom = 0.0;   // (T utmi)[imu], utmi = radg for ic == 0 else 0
-                if (ic == 0) for (int kk = 0; kk < n; ++kk) bcom += MS_AT(tc, imu, kk) * radg[kk];
-                yx[ico++] = (MS_AT(rc, imu, imu0) * s0 + bcom) + jc[imu];
+                if (!lookup) {
+                    double bcom = 0.0;   // (T utmi)[imu], utmi = radg for ic == 0 else 0
+                    if (ic == 0) for (int kk = 0; kk < n; ++kk) bcom += MS_AT(tc, imu, kk) * radg[kk];
+                    yx[ico++] = (MS_AT(rc, imu, imu0) * s0 + bcom) + jc[imu];
+                } else if (p.lowbc == 0) {   // bottom of the atmosphere: T u0+ + R u- + J  (:929-933)
+                    double bcom = 0.0;
+                    if (ic == 0) for (int kk = 0; kk < n; ++kk) bcom += MS_AT(rc, imu, kk) * radg[kk];
+                    yx[ico++] = (MS_AT(tc, imu, imu0) * s0 + bcom) + jc[imu];
+                } else {
+                    double upl = 0.0;
+                    for (int kk = 0; kk < n; ++kk) upl += MS_AT(m3, imu, kk) * (MS_AT(tc, kk, imu0) * s0 + v0[kk]);
+                    yx[ico++] = upl;
+                }
             }
         }
         double drad = ((1 - t) * (1 - u) * yx[0] + t * (1 - u) * yx[1] + t * u * yx[3] + (1 - t) * u * yx[2]) *
@@ -585,7 +612,8 @@ __global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
 
     if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // radg[:, ::-1] :765
     bool defined = false;
-    if (p.lowbc > 0) {  // surface operator first :824-836
+    const bool lookup = p.lookup != 0;
+    if (p.lowbc > 0 && !lookup) {  // surface operator first :824-836
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = q + 4 * r, j = c;
@@ -602,7 +630,7 @@ __global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
     const double rmu_c = 1. / p.mu[c];
 
     for (int l = 0; l < p.nlay; ++l) {
-        const int k = l;  // look-down: bottom layer first (:842-845)
+        const int k = lookup ? p.nlay - 1 - l : l;  // look-down: bottom layer first (:842-845)
         const double taut = p.taus[((size_t)widx * p.ng + ig) * p.nlay + k];
         const double bc = p.bnu[(size_t)widx * p.nlay + k];
         double omega = p.omegas[((size_t)widx * p.ng + ig) * p.nlay + k];
@@ -757,10 +785,29 @@ __global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
     }
     if (ic != 0 && lane < n) jc[lane] = 0.0;   // :881-882
     __syncthreads();
+    if (lookup && p.lowbc > 0) {
+        // idown (:366-420) with rb = rs, tb = 0, jb = radg (js is set for every ic, :822):
+        //   upl = (E - rc rs)^-1 (tc u0+ + (rc radg + jc));   mB = the inverse, v0 = rc radg + jc
+        ms_v4f64 rs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = q + 4 * r, j = c;
+            rs[r] = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
+        }
+        double aRc[4];
+        L.load_a(rc, aRc);
+        L.store_d(mA, L.eye_plus(Ms16::mm(aRc, rs), -1.0));
+        MS16_FENCE();
+        ms_inv16(mA, mB, lane);
+        const double wv = L.mv(aRc, radg) + jc[c];
+        if (q == 0) v0[c] = wv;
+        __syncthreads();
+    }
     // ---- per path: the four (mu0, mu) samples and the bilinear interpolation :886-945 ---------------------------
     if (lane < p.ngeom) {
         const int ipath = lane;
-        const double sol_ang = p.sol_ang[ipath], emiss_ang = p.emiss_ang[ipath];
+        const double sol_ang = p.sol_ang[ipath];
+        const double emiss_ang = lookup ? 180. - p.emiss_ang[ipath] : p.emiss_ang[ipath];   // new_emi :900-903
         double zmu0, solar1;
         if (sol_ang > 90.0) { zmu0 = cos((180 - sol_ang) * pi / 180.0); solar1 = p.solar[widx] * 0.0; }
         else { zmu0 = cos(sol_ang * pi / 180.0); solar1 = p.solar[widx]; }
@@ -777,9 +824,19 @@ __global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
         for (int imu0 = isol; imu0 < isol + 2; ++imu0) {
             const double s0 = solar1 / (2.0 * pi * p.wtmu[imu0]);
             for (int imu = iemm; imu < iemm + 2; ++imu) {
-                double bcom = 0.0;   // (T utmi)[imu], utmi = radg for ic == 0 else 0
-                if (ic == 0) for (int kk = 0; kk < n; ++kk) bcom += MS_AT(tc, imu, kk) * radg[kk];
-                yx[ico++] = (MS_AT(rc, imu, imu0) * s0 + bcom) + jc[imu];
+                if (!lookup) {
+                    double bcom = 0.0;   // (T utmi)[imu], utmi = radg for ic == 0 else 0
+                    if (ic == 0) for (int kk = 0; kk < n; ++kk) bcom += MS_AT(tc, imu, kk) * radg[kk];
+                    yx[ico++] = (MS_AT(rc, imu, imu0) * s0 + bcom) + jc[imu];
+                } else if (p.lowbc == 0) {   // bottom of the atmosphere: T u0+ + R u- + J  (:929-933)
+                    double bcom = 0.0;
+                    if (ic == 0) for (int kk = 0; kk < n; ++kk) bcom += MS_AT(rc, imu, kk) * radg[kk];
+                    yx[ico++] = (MS_AT(tc, imu, imu0) * s0 + bcom) + jc[imu];
+                } else {
+                    double upl = 0.0;
+                    for (int kk = 0; kk < n; ++kk) upl += MS_AT(mB, imu, kk) * (MS_AT(tc, kk, imu0) * s0 + v0[kk]);
+                    yx[ico++] = upl;
+                }
             }
         }
         double drad = ((1 - t) * (1 - u) * yx[0] + t * (1 - u) * yx[1] + t * u * yx[3] + (1 - t) * u * yx[2]) *

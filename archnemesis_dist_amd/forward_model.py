@@ -208,8 +208,8 @@ def install_gpu_scattering_core(device=0):
 
     ForwardModel_0.scloud11wave (ForwardModel_0.py:5018) prepares RADGROUND/BB/FRAC/OMEGA/PHASE_ARRAY on the host
     and imports `scloud11wave_core` from archnemesis.Multiple_Scattering_Core at call time (:5050); replacing that
-    module attribute keeps all of the reference's host preparation and swaps only the core (K7).  Geometries the GPU
-    core does not cover yet (look-up) go to the reference's own function."""
+    module attribute keeps all of the reference's host preparation and swaps only the core (K7).  Sizes outside the
+    GPU core's limits (nmu > 20, more than 16 paths per call) go to the reference's own function."""
     import importlib
     msc = importlib.import_module("archnemesis.Multiple_Scattering_Core")
     eng = get_engine(device)

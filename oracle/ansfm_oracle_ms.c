@@ -283,8 +283,10 @@ static void addp(int n, const double *r1, const double *t1, const double *j1, in
     memcpy(jsub, jans, sizeof(double) * n);
 }
 
-/* scloud11wave_core :651-960.  Array layouts are the reference's.  Returns 0, or 5 (unsupported:
- * look-up geometry) / 1 (mixed emission angles, the reference raises ValueError :776). */
+/* scloud11wave_core :651-960.  Array layouts are the reference's.  Returns 0, or 1 (mixed emission angles,
+ * the reference raises ValueError :776).  Both geometries: look-down (all emission angles < 90: layers bottom
+ * to top, surface first) and look-up (all > 90: layers top to bottom, surface kept apart and brought in with
+ * idown :366-420 when lowbc > 0). */
 ORC_API int orc_scloud11wave_core(
     int ncont, int nwave, int nth, const double *phasarr /*[ncont][nwave][2][nth]*/, const double *radg_in /*[nwave][nmu]*/,
     int ngeom, const double *sol_angs, const double *emiss_angs, const double *solar /*[nwave]*/, const double *aphis,
@@ -297,7 +299,7 @@ ORC_API int orc_scloud11wave_core(
     int nless = 0, nmore = 0;
     for (int i = 0; i < ngeom; ++i) { if (emiss_angs[i] < 90) ++nless; if (emiss_angs[i] > 90) ++nmore; }
     if (nless != ngeom && nmore != ngeom) return 1;
-    if (nmore == ngeom) return 5;
+    const int lookdown = (nless == ngeom);
     const int n = nmu, NF1 = nf + 1;
     double xfac = 0.0;
     for (int i = 0; i < n; ++i) xfac += mu1[i] * wt1[i];
@@ -314,6 +316,7 @@ ORC_API int orc_scloud11wave_core(
     double *rcomb = (double *)malloc(sizeof(double) * NF1 * n * n);
     double *tcomb = (double *)malloc(sizeof(double) * NF1 * n * n);
     double *jcomb = (double *)malloc(sizeof(double) * NF1 * n);
+    double *rsurf = (double *)calloc((size_t)NF1 * n * n, sizeof(double));      /* rs[:,:,ic]; ts = 0; js = radg (every ic) */
     memset(rad, 0, sizeof(double) * ngeom * ng * nwave);
     for (int ig = 0; ig < ng; ++ig)
         for (int widx = 0; widx < nwave; ++widx) {
@@ -338,17 +341,20 @@ ORC_API int orc_scloud11wave_core(
                 }
                 double *rc = rcomb + (size_t)ic * n * n, *tc = tcomb + (size_t)ic * n * n, *jc = jcomb + (size_t)ic * n;
                 int surface_defined = 0;
-                if (lowbc > 0) {   /* look-down: surface is the first element of the stack :824-836 */
-                    for (int i = 0; i < n; ++i) {
-                        jc[i] = radg[i];
+                if (lowbc > 0) {   /* :822-836: look-down puts the surface first in the stack */
+                    double *rs = rsurf + (size_t)ic * n * n;
+                    for (int i = 0; i < n; ++i)
                         for (int j = 0; j < n; ++j)
-                            rc[i * n + j] = (2. * (brdf[(((size_t)widx * n + i) * n + j) * NF1 + ic] * M_PI) * mu[j] * wtmu[j]) * xfac;
+                            rs[i * n + j] = (2. * (brdf[(((size_t)widx * n + i) * n + j) * NF1 + ic] * M_PI) * mu[j] * wtmu[j]) * xfac;
+                    if (lookdown) {
+                        for (int i = 0; i < n; ++i) jc[i] = radg[i];
+                        memcpy(rc, rs, sizeof(double) * n * n);
+                        memset(tc, 0, sizeof(double) * n * n);
+                        surface_defined = 1;
                     }
-                    memset(tc, 0, sizeof(double) * n * n);
-                    surface_defined = 1;
                 }
                 for (int l = 0; l < nlay; ++l) {
-                    int k = l;
+                    int k = lookdown ? l : nlay - 1 - l;                       /* :841-844 */
                     double taut = taus[((size_t)widx * ng + ig) * nlay + k];
                     double bc = bnu[(size_t)widx * nlay + k];
                     double omega = omegas_s[((size_t)widx * ng + ig) * nlay + k];
@@ -378,6 +384,7 @@ ORC_API int orc_scloud11wave_core(
                 double zmu0, solar1;
                 if (sol_ang > 90.0) { zmu0 = cos((180 - sol_ang) * M_PI / 180.0); solar1 = solar[widx] * 0.0; }
                 else { zmu0 = cos(sol_ang * M_PI / 180.0); solar1 = solar[widx]; }
+                if (!lookdown) emiss_ang = 180. - emiss_ang;                   /* new_emi :900-903 */
                 double zmu = cos(emiss_ang * M_PI / 180.0);
                 int isol = 0, iemm = 0;
                 for (int j = 0; j < n - 1; ++j) if (zmu0 <= mu[j] && zmu0 > mu[j + 1]) isol = j;
@@ -394,11 +401,33 @@ ORC_API int orc_scloud11wave_core(
                     int ico = 0;
                     for (int imu0 = isol; imu0 < isol + 2; ++imu0) {
                         u0pl[imu0] = solar1 / (2.0 * M_PI * wtmu[imu0]);
-                        double acom[MAXMU], bcom[MAXMU];
-                        mv_mul(n, rc, u0pl, acom);
-                        mv_mul(n, tc, utmi, bcom);
+                        double acom[MAXMU], bcom[MAXMU], upl[MAXMU];
+                        if (lookdown) {
+                            mv_mul(n, rc, u0pl, acom);
+                            mv_mul(n, tc, utmi, bcom);
+                            for (int i = 0; i < n; ++i) upl[i] = (acom[i] + bcom[i]) + jc[i];
+                        } else if (lowbc == 0) {                               /* :929-933 */
+                            mv_mul(n, tc, u0pl, acom);
+                            mv_mul(n, rc, utmi, bcom);
+                            for (int i = 0; i < n; ++i) upl[i] = (acom[i] + bcom[i]) + jc[i];
+                        } else {                                               /* idown :366-420, rb = rs, tb = 0, jb = radg */
+                            const double *rs = rsurf + (size_t)ic * n * n;
+                            mat ac, em, bc2, zero;
+                            double xcom[MAXMU], ycom[MAXMU];
+                            mm_mul(n, rc, rs, ac);
+                            for (int i = 0; i < n * n; ++i) em[i] = e[i] - ac[i];
+                            mat_inv(n, em, bc2);
+                            mv_mul(n, tc, u0pl, xcom);
+                            memset(zero, 0, sizeof zero);
+                            mm_mul(n, rc, zero, ac);                            /* R10*T21 with T21 = 0 */
+                            mv_mul(n, ac, utmi, ycom);
+                            for (int i = 0; i < n; ++i) xcom[i] += ycom[i];
+                            mv_mul(n, rc, radg, ycom);                          /* R10*J21-, js = radg for every ic (:822) */
+                            for (int i = 0; i < n; ++i) xcom[i] += ycom[i] + jc[i];
+                            mv_mul(n, bc2, xcom, upl);
+                        }
                         for (int imu = iemm; imu < iemm + 2; ++imu) {
-                            yx[ico++] = (acom[imu] + bcom[imu]) + jc[imu];
+                            yx[ico++] = upl[imu];
                             u0pl[imu0] = 0.0;
                         }
                     }
@@ -412,6 +441,6 @@ ORC_API int orc_scloud11wave_core(
                 }
             }
         }
-    free(fc); free(ppln); free(pmin); free(rcomb); free(tcomb); free(jcomb);
+    free(fc); free(ppln); free(pmin); free(rcomb); free(tcomb); free(jcomb); free(rsurf);
     return 0;
 }

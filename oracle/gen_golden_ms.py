@@ -74,6 +74,16 @@ def make_case(ans, name, seed, NMU, NWAVE, NG, NLAY, NCONT, NF, NPHI, imie, iray
 
 def main():
     ans = import_reference()
+    # upward-looking geometry (emission angle > 90, :900-903, :927-942): without a surface in the stack (lowbc = 0) and
+    # with the internal-field formula `idown` (lowbc > 0)
+    gu = [(30.0, 160.0, 45.0), (120.0, 130.0, 0.0)]
+    make_case(ans, "ms_nmu5_lookup", 4, NMU=5, NWAVE=3, NG=2, NLAY=6, NCONT=2, NF=2, NPHI=101, imie=0, iray=1, lowbc=0, geoms=gu)
+    make_case(ans, "ms_nmu5_lookup_lambert", 5, NMU=5, NWAVE=3, NG=2, NLAY=5, NCONT=1, NF=3, NPHI=101, imie=1, iray=0, lowbc=1,
+              geoms=[(10.0, 120.0, 130.0), (75.0, 175.0, 10.0), (40.0, 140.0, 180.0)])
+    make_case(ans, "ms_nmu16_lookup_lambert", 6, NMU=16, NWAVE=2, NG=2, NLAY=5, NCONT=1, NF=3, NPHI=101, imie=1, iray=1, lowbc=1,
+              geoms=[(30.0, 155.0, 45.0)])
+    if "--lookup-only" in sys.argv:
+        return
     g2 = [(30.0, 20.0, 45.0), (120.0, 50.0, 0.0)]
     make_case(ans, "ms_nmu5_hg_ray", 1, NMU=5, NWAVE=4, NG=2, NLAY=6, NCONT=2, NF=2, NPHI=101, imie=0, iray=1, lowbc=0, geoms=g2)
     make_case(ans, "ms_nmu5_tab_lambert", 2, NMU=5, NWAVE=3, NG=2, NLAY=5, NCONT=1, NF=3, NPHI=101, imie=1, iray=0, lowbc=1,

@@ -197,8 +197,6 @@ def scloud11wave_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, lowbc, 
         _p(taus), _p(_c(tauray)), _p(_c(omegas_s)), int(nphi), int(iray), int(imie), _p(_c(lfrac)), _p(rad))
     if rc == 1:
         raise ValueError("Emission angles are a mix of values above and below 90 degrees (or NMU too large).")
-    if rc == 5:
-        raise NotImplementedError("look-up geometry (emission angle > 90) not restated")
     return rad
 
 

@@ -200,9 +200,11 @@ def test_cirsradg_vs_oracle(eng, oracle, W, G, S, L, f32):
         assert np.max(np.abs(dspec[m] - rd) / scale) < 1e-9, m
 
 
-@pytest.mark.parametrize("name", ["ms_nmu5_hg_ray", "ms_nmu5_tab_lambert", "ms_nmu16_tab_ray"])
+@pytest.mark.parametrize("name", ["ms_nmu5_hg_ray", "ms_nmu5_tab_lambert", "ms_nmu16_tab_ray", "ms_nmu5_lookup",
+                                  "ms_nmu5_lookup_lambert", "ms_nmu16_lookup_lambert"])
 def test_scloud11wave_core_golden(eng, golden_dir, name):
-    """Doubling/adding core vs the reference's scloud11wave_core (golden) -- contract 1e-6."""
+    """Doubling/adding core vs the reference's scloud11wave_core (golden) -- contract 1e-6.  Look-down and look-up
+    geometry (the latter without and with a reflecting lower boundary, i.e. through idown)."""
     from test_ms_oracle import ms_args
     z = _load(golden_dir, name)
     rad = eng.scloud11wave_core(*ms_args(z))
@@ -233,6 +235,16 @@ def test_scloud11wave_core_vs_oracle_random(eng, oracle, golden_dir):
     rad = eng.scloud11wave_core(*ms_args(z))
     ref = oracle.scloud11wave_core(*ms_args(z))
     np.testing.assert_allclose(rad, ref, rtol=1e-8)
+    # the same stack seen from below, with a reflecting surface under it (idown)
+    z["emiss_angs"] = 180.0 - np.asarray(z["emiss_angs"])
+    z["lowbc"] = 1
+    z["brdf_matrix"] = rng.uniform(0.02, 0.2, size=z["brdf_matrix"].shape) / np.pi
+    rad = eng.scloud11wave_core(*ms_args(z))
+    ref = oracle.scloud11wave_core(*ms_args(z))
+    np.testing.assert_allclose(rad, ref, rtol=1e-8)
+    with pytest.raises(ValueError):      # mixed geometries: the reference's ValueError (:776)
+        z["emiss_angs"] = np.array([20.0, 160.0])
+        eng.scloud11wave_core(*ms_args(z))
 
 
 @pytest.mark.parametrize("name", ["lbl_tab", "lbl_tab_t2d_f32"])

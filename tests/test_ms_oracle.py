@@ -4,7 +4,8 @@ import os
 import numpy as np
 import pytest
 
-MS_CASES = ["ms_nmu5_hg_ray", "ms_nmu5_tab_lambert", "ms_nmu16_tab_ray"]
+MS_CASES = ["ms_nmu5_hg_ray", "ms_nmu5_tab_lambert", "ms_nmu16_tab_ray", "ms_nmu5_lookup", "ms_nmu5_lookup_lambert",
+            "ms_nmu16_lookup_lambert"]
 
 
 def ms_args(z):
