@@ -50,6 +50,7 @@ struct ansfm_ctx {
     // k-table
     int W = 0, Wpad = 0, G = 0, NP = 0, NT = 0, S = 0;
     int monotone = 0;
+    int force_generic = 0;   // rerun of a call whose k-distributions turned out not to be sorted in g
     bool have_table = false;
     int grid_f32 = 0, delg_f32 = 0;
     int is_lbl = 0, temp2d = 0;   // LBL-table mode (ILBL=2): G = 1, TEMP may be [NP][NT]
@@ -242,6 +243,9 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
                           int L, int n_models, const LayerInterp *li, const double *amount,
                           const double *del_g_dev, const double *del_g_host, double *tau)
 {
+    // fast path: every k(g) non-decreasing (checked at upload for tables, in the kernel otherwise); generic path:
+    // per-lane sort of each gas first (k_ck_overlap<..., SORTED = false>)
+    const bool sorted = !ctx->force_generic && (from_k || ctx->monotone);
     OverlapParams p;
     memset(&p, 0, sizeof p);
     p.lnK = ctx->lnK.as<double>();
@@ -267,7 +271,8 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
         p.g_ord[G] = 1.0;
         p.g_ord[G + 1] = __builtin_inf();
     }
-    const size_t lds = (size_t)(3 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double);
+    const size_t lds = (size_t)(3 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) +
+                       (sorted ? 0 : (size_t)2 * G * kWave);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
@@ -278,12 +283,16 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     if (grid < 1) grid = 1;
     HIPCHK(ctx->scratch.reserve((size_t)grid * 6 * G * kWave * sizeof(double)));
     p.scratch = ctx->scratch.as<double>();
+#define LAUNCH_OV2(D, FK, W32)                                                                                      \
+    do {                                                                                                            \
+        if (sorted)                                                                                                 \
+            hipLaunchKernelGGL((k_ck_overlap<D, FK, W32, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p);  \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_ck_overlap<D, FK, W32, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p); \
+    } while (0)
 #define LAUNCH_OV(D, FK)                                                                              \
     do {                                                                                              \
-        if (ctx->delg_f32)                                                                            \
-            hipLaunchKernelGGL((k_ck_overlap<D, FK, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p);  \
-        else                                                                                          \
-            hipLaunchKernelGGL((k_ck_overlap<D, FK, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p); \
+        if (ctx->delg_f32) LAUNCH_OV2(D, FK, true); else LAUNCH_OV2(D, FK, false);                    \
     } while (0)
     if (from_k) {
         switch (p.depth) {
@@ -303,6 +312,7 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
         }
     }
 #undef LAUNCH_OV
+#undef LAUNCH_OV2
     HIPCHK(hipGetLastError());
     return ANSFM_OK;
 }
@@ -318,13 +328,22 @@ static int launch_rt(ansfm_ctx *ctx, const RtParams &p, int n_models)
     return ANSFM_OK;
 }
 
+// Synchronises; *flag = 1 when the fast merge kernel met a k-distribution that is not non-decreasing in g (its
+// output is then not to be used: the caller reruns on the generic path, or fails where none exists).
+static int read_unsorted(ansfm_ctx *ctx, int *flag)
+{
+    *flag = 0;
+    HIPCHK(hipMemcpyAsync(flag, ctx->d_flag.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *flag &= 1;
+    return ANSFM_OK;
+}
 static int check_unsorted(ansfm_ctx *ctx)
 {
-    int flag = 0;
-    HIPCHK(hipMemcpyAsync(&flag, ctx->d_flag.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (flag & 1)
-        FAIL(ANSFM_ERR_UNSORTED, "k-distribution not non-decreasing in g: generic (unsorted) merge path not built");
+    int flag = 0, rc = read_unsorted(ctx, &flag);
+    if (rc) return rc;
+    if (flag)
+        FAIL(ANSFM_ERR_UNSORTED, "k-distribution not non-decreasing in g: the gradient merge has no generic (unsorted) path");
     return ANSFM_OK;
 }
 
@@ -344,8 +363,6 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
     if (n_models <= 0 || L <= 0 || P <= 0 || LIMAX <= 0 || !lay_press_pa || !lay_temp || !amount || !NLAYIN ||
         !LAYINC || !SCALE || !EMTEMP || !TSURF || !SPECOUT || (ISPACE != 0 && ISPACE != 1))
         FAIL(ANSFM_ERR_INVALID, "cirsrad: bad argument");
-    if (!ctx->monotone)
-        FAIL(ANSFM_ERR_UNSORTED, "k-table is not non-negative and non-decreasing in g: generic merge path not built");
     HIPCHK(hipSetDevice(ctx->device));
     const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, S = ctx->S;
     HIPCHK(ctx->li.reserve((size_t)n_models * L * sizeof(LayerInterp)));
@@ -469,15 +486,23 @@ int ansfm_cirsrad_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L, co
     UP(xfac, (size_t)W * D);                               // 14
 #undef UP
     HIPCHK(ctx->tmp_out.reserve((size_t)n_models * W * P * D));
-    rc = ansfm_cirsrad_ck_thermal_dev(
-        ctx, ISPACE, n_models, L, (const double *)d[0], (const double *)d[1], (const double *)d[2],
-        (const double *)d[3], P, LIMAX, (const int32_t *)d[4], (const int32_t *)d[5], (const double *)d[6],
-        (const double *)d[7], (const double *)d[8], (const double *)d[9], (const double *)d[10],
-        (const double *)d[11], (const double *)d[12], (const double *)d[13], (const double *)d[14],
-        ctx->tmp_out.as<double>());
-    if (rc) return rc;
+    for (int pass = 0; pass < 2; ++pass) {
+        ctx->force_generic = pass;       // pass 1 only if the fast merge met an unsorted k-distribution
+        rc = ansfm_cirsrad_ck_thermal_dev(
+            ctx, ISPACE, n_models, L, (const double *)d[0], (const double *)d[1], (const double *)d[2],
+            (const double *)d[3], P, LIMAX, (const int32_t *)d[4], (const int32_t *)d[5], (const double *)d[6],
+            (const double *)d[7], (const double *)d[8], (const double *)d[9], (const double *)d[10],
+            (const double *)d[11], (const double *)d[12], (const double *)d[13], (const double *)d[14],
+            ctx->tmp_out.as<double>());
+        ctx->force_generic = 0;
+        if (rc) return rc;
+        int flag = 0;
+        if ((rc = read_unsorted(ctx, &flag))) return rc;
+        if (!flag) break;
+    }
     HIPCHK(hipMemcpyAsync(SPECOUT, ctx->tmp_out.p, (size_t)n_models * W * P * D, hipMemcpyDeviceToHost, ctx->stream));
-    return check_unsorted(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
 }
 
 int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS)
@@ -549,16 +574,25 @@ int ansfm_k_overlap(ansfm_ctx *ctx, int W, int G, int L, int S, const double *de
     HIPCHK(hipGetLastError());
     const size_t ntau = (size_t)L * G * Wpad;
     HIPCHK(ctx->misc.reserve(ntau * sizeof(double)));
-    rc = launch_overlap(ctx, true, ctx->tmp_in.as<double>(), W, Wpad, G, S, L, 1, nullptr, (const double *)dam,
-                        (const double *)ddg, del_g, ctx->misc.as<double>());
-    if (rc) return rc;
+    for (int pass = 0; pass < 2; ++pass) {
+        ctx->force_generic = pass;       // pass 1 only if the fast merge met an unsorted k-distribution
+        if (pass) HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+        rc = launch_overlap(ctx, true, ctx->tmp_in.as<double>(), W, Wpad, G, S, L, 1, nullptr, (const double *)dam,
+                            (const double *)ddg, del_g, ctx->misc.as<double>());
+        ctx->force_generic = 0;
+        if (rc) return rc;
+        int flag = 0;
+        if ((rc = read_unsorted(ctx, &flag))) return rc;
+        if (!flag) break;
+    }
     const size_t nout = (size_t)W * G * L;
     HIPCHK(ctx->tmp_out.reserve(nout * sizeof(double)));
     hipLaunchKernelGGL(k_w_to_first, dim3(nblk(nout, 256)), dim3(256), 0, ctx->stream, ctx->misc.as<double>(),
                        ctx->tmp_out.as<double>(), W, Wpad, L, G, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(tau, ctx->tmp_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    return check_unsorted(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
 }
 
 int ansfm_thermal_emission(ansfm_ctx *ctx, int ISPACE, int W, int G, int NLAYIN, const double *WAVE,

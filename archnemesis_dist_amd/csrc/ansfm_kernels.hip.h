@@ -338,9 +338,12 @@ struct MergeElem {
     int ci, np;
 };
 
-template <int DEPTH, bool W32>
+// SORTED = false (generic path): the rows / columns were sorted per lane beforehand; PA / PB give the original
+// g-ordinate of each sorted position, which is the one whose weight applies.
+template <int DEPTH, bool W32, bool SORTED = true>
 __device__ __forceinline__ void merge_fetch(double key, int G, int lane, const double *A, const double *B,
-                                            const double *NV, const double *DG, MergeElem<DEPTH> &e)
+                                            const double *NV, const double *DG, MergeElem<DEPTH> &e,
+                                            const unsigned char *PA = nullptr, const unsigned char *PB = nullptr)
 {
     const unsigned kb = (unsigned)__double_as_longlong(key);
     const int ci = kb & 31, cp = (kb >> 5) & 63;
@@ -349,7 +352,9 @@ __device__ __forceinline__ void merge_fetch(double key, int G, int lane, const d
     e.ai = A[ci * kWave + lane];
     e.bc = B[cp * kWave + lane];
     e.bn = B[(cp + 1) * kWave + lane];          // B[G] = sentinel column: an exhausted row re-enters as "huge"
-    double w = DG[ci] * DG[cp];                  // exact in double when both are float32 values
+    double w;
+    if constexpr (SORTED) w = DG[ci] * DG[cp];   // exact in double when both are float32 values
+    else w = DG[PA[ci * kWave + lane]] * DG[PB[cp * kWave + lane]];
     if constexpr (W32) w = (double)(float)w;     // -> the float32 product NumPy forms (DELG float32)
     e.w = w;
     const unsigned t = (unsigned)(G + ci);
@@ -403,10 +408,11 @@ __device__ __forceinline__ bool merge_walk(const MergeElem<DEPTH> &e, WalkState 
 
 // Returns the consumed element's (row, column) and whether it closed a bin, as 16 bits: the gradient kernel
 // records them and replays the sorted order for the gradient rows.
-template <int DEPTH, bool W32, bool REC_CODE = false>
+template <int DEPTH, bool W32, bool REC_CODE = false, bool SORTED = true>
 __device__ __forceinline__ unsigned merge_step(MergeElem<DEPTH> &e, MergeElem<DEPTH> &en, WalkState &ws, int G,
                                                int lane, const double *A, const double *B, double *NV,
-                                               const double *DG, const double *GORD, double *rec)
+                                               const double *DG, const double *GORD, double *rec,
+                                               const unsigned char *PA = nullptr, const unsigned char *PB = nullptr)
 {
     // 1. replay the tree path of the popped leaf with the row's next element
     double car = pack_key11(e.ai + e.bn, e.ci, e.np);
@@ -418,7 +424,7 @@ __device__ __forceinline__ unsigned merge_step(MergeElem<DEPTH> &e, MergeElem<DE
         car = lo;
     }
     // 2. fetch the operands of the new winner (LDS reads in flight during the walk)
-    merge_fetch<DEPTH, W32>(car, G, lane, A, B, NV, DG, en);
+    merge_fetch<DEPTH, W32, SORTED>(car, G, lane, A, B, NV, DG, en, PA, PB);
     // 3. rank walk on the element just consumed
     const bool cross = merge_walk<DEPTH, REC_CODE>(e, ws, rec, GORD, lane);
     return (unsigned)(e.ci | ((e.np - 1) << 5) | (cross ? 0x8000 : 0));
@@ -461,7 +467,31 @@ struct TileQueue {
     }
 };
 
-template <int DEPTH, bool FROM_K, bool W32>
+// Per-lane insertion sort of one LDS column (values ascending, stable) carrying the original index of every
+// position in P.  Only the generic path (k not sorted in g) uses it.
+__device__ __forceinline__ void sort_column(double *X, unsigned char *P, int G, int lane)
+{
+    for (int g = 0; g < G; ++g) P[g * kWave + lane] = (unsigned char)g;
+    for (int i = 1; i < G; ++i) {
+        const double key = X[i * kWave + lane];
+        const unsigned char pk = P[i * kWave + lane];
+        int j = i - 1;
+        while (j >= 0 && X[j * kWave + lane] > key) {
+            X[(j + 1) * kWave + lane] = X[j * kWave + lane];
+            P[(j + 1) * kWave + lane] = P[j * kWave + lane];
+            --j;
+        }
+        X[(j + 1) * kWave + lane] = key;
+        P[(j + 1) * kWave + lane] = pk;
+    }
+}
+
+// SORTED = false: generic path for k-distributions that are not non-decreasing in g (the reference sorts the G*G
+// products itself, :6150).  Each gas's (k, weight) pairs are sorted per lane first -- the multiset of
+// (product, weight) is unchanged, so rank()'s walk sees the same sequence up to the order of exact ties -- and the
+// skip rules keep looking at the LAST g-ordinate in the original order (:6075-6102).  A spectrum that passes through
+// unmerged comes out in its original order.
+template <int DEPTH, bool FROM_K, bool W32, bool SORTED = true>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_ck_overlap(OverlapParams p)
 {
     extern __shared__ double smem[];
@@ -472,6 +502,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     double *NV = B + (G + 1) * kWave;
     double *DG = NV + G * kWave;
     double *GORD = DG + kMaxG;
+    unsigned char *PA = reinterpret_cast<unsigned char *>(GORD + kMaxG + 2);     // SORTED = false only
+    unsigned char *PB = PA + G * kWave;
     if (lane < G) DG[lane] = p.del_g[lane];
     if (lane < G + 2) GORD[lane] = p.g_ord[lane];
     const double HUGE_KEY = __longlong_as_double(0x7FE0000000000000LL);   // finite, above any optical depth
@@ -494,17 +526,25 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         bool unsorted = false;
 
         load_gas<FROM_K>(p, q, m, l, 0, nu, A, lane, unsorted);
+        double alast = A[(G - 1) * kWave + lane];       // last g-ordinate in the ORIGINAL order
+        if constexpr (!SORTED) sort_column(A, PA, G, lane);
         for (int s = 1; s < p.S; ++s) {
             load_gas<FROM_K>(p, q, m, l, s, nu, B, lane, unsorted);
-            const double alast = A[(G - 1) * kWave + lane];
             const double blast = B[(G - 1) * kWave + lane];
+            if constexpr (!SORTED) sort_column(B, PB, G, lane);
+            if constexpr (SORTED) alast = A[(G - 1) * kWave + lane];
             // skip rules, cutoff = 0  (ForwardModel_0.py:6073-6102)
             bool takeB, keepA;
             if (s == 1) { takeB = (alast <= 0.0); keepA = !takeB && (blast <= 0.0); }
             else { keepA = (blast <= 0.0); takeB = !keepA && (alast <= 0.0); }
             const bool do_merge = !(takeB | keepA);
-            if (takeB)
+            if (takeB) {
                 for (int g = 0; g < G; ++g) A[g * kWave + lane] = B[g * kWave + lane];
+                if constexpr (!SORTED) {
+                    for (int g = 0; g < G; ++g) PA[g * kWave + lane] = PB[g * kWave + lane];
+                    alast = blast;
+                }
+            }
             if (do_merge) {
                 // ---- loser tree over the G rows (row i = a_i + b_j, j ascending) ----------------
                 const double b0 = B[lane];
@@ -514,15 +554,15 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 }
                 NV[lane] = HUGE_KEY;  // node 0: dummy level for the shallower leaves
                 MergeElem<DEPTH> e0, e1;
-                merge_fetch<DEPTH, W32>(pack_key11(A[lane] + b0, 0, 0), G, lane, A, B, NV, DG, e0);
+                merge_fetch<DEPTH, W32, SORTED>(pack_key11(A[lane] + b0, 0, 0), G, lane, A, B, NV, DG, e0, PA, PB);
                 WalkState ws{0.0, 0.0, 0.0, GORD[1], 0};
                 const int nloop = G * G;
                 int it = 0;
                 for (; it + 1 < nloop; it += 2) {   // ping-pong: no register rotation
-                    merge_step<DEPTH, W32>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec);
-                    merge_step<DEPTH, W32>(e1, e0, ws, G, lane, A, B, NV, DG, GORD, rec);
+                    merge_step<DEPTH, W32, false, SORTED>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec, PA, PB);
+                    merge_step<DEPTH, W32, false, SORTED>(e1, e0, ws, G, lane, A, B, NV, DG, GORD, rec, PA, PB);
                 }
-                if (it < nloop) merge_step<DEPTH, W32>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec);
+                if (it < nloop) merge_step<DEPTH, W32, false, SORTED>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec, PA, PB);
                 // ---- resolve the bins --------------------------------------------------------------------
                 double ck = 0.0, cs = 0.0;   // (1-frac) share carried into the next bin
                 const int ig = ws.ig;
@@ -562,11 +602,19 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                         }
                     }
                 }
+                if constexpr (!SORTED) {   // the merged spectrum is ascending with the plain del_g weights
+                    for (int g = 0; g < G; ++g) PA[g * kWave + lane] = (unsigned char)g;
+                    alast = A[(G - 1) * kWave + lane];
+                }
             }
         }
-        if (unsorted) atomicOr(p.err_flag, 1);
         double *out = p.tau + (((size_t)m * p.L + l) * G) * p.Wpad + nu;
-        for (int g = 0; g < G; ++g) out[(size_t)g * p.Wpad] = A[g * kWave + lane];
+        if constexpr (SORTED) {
+            if (unsorted) atomicOr(p.err_flag, 1);
+            for (int g = 0; g < G; ++g) out[(size_t)g * p.Wpad] = A[g * kWave + lane];
+        } else {
+            for (int g = 0; g < G; ++g) out[(size_t)PA[g * kWave + lane] * p.Wpad] = A[g * kWave + lane];
+        }
     }
 }
 

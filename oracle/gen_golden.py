@@ -119,6 +119,22 @@ def case_rank(ans, name, seed, G):
     print(name, outs.shape)
 
 
+def case_ko_unsorted(ans, name, seed, W, G, L, S):
+    """k_overlap (:6029) on k-distributions that are NOT sorted in g (the reference sorts the G*G products itself,
+    :6150) including the skip rules, which look at the LAST g-ordinate only (:6075-6102)."""
+    fm = sys.modules['archnemesis.ForwardModel_0']
+    rng = np.random.default_rng(seed)
+    _, del_g = gauss_legendre_01(G)
+    k = 10.0 ** rng.uniform(-24, -20, (W, G, L, S))
+    amount = 10.0 ** rng.uniform(19, 22, (S, L))
+    k[:, -1, 1, 2] = 0.0          # gas 2 skipped in layer 1 although its other ordinates are non-zero
+    k[:, -1, 2, 0] = 0.0          # first gas "empty" in layer 2: the second gas is taken as is (unsorted output)
+    k[:, -1, 3, 1:] = 0.0         # only gas 0 left in layer 3: output = its unsorted k * amount
+    tau = fm.k_overlap(del_g, k, amount)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), DELG=del_g, k=k, amount=amount, tau=tau)
+    print(name, tau.shape)
+
+
 def case_thermal(ans, name, seed, W, G, Li, NPAR, NVMR):
     fm = sys.modules['archnemesis.ForwardModel_0']
     rng = np.random.default_rng(seed)
@@ -195,6 +211,9 @@ def main():
     if "--f32-only" in sys.argv:
         case_ck(ans, "ck_g10_s3_f32dtype", 106, W=6, G=10, NP=6, NT=5, S=3, L=8, f32_dtype=True)
         return
+    if "--unsorted-only" in sys.argv:
+        case_ko_unsorted(ans, "ko_unsorted_g8_s4", 107, W=5, G=8, L=4, S=4)
+        return
     if "--lbl-only" in sys.argv:
         case_lbl(ans, "lbl_tab", 301, W=9, NP=6, NTa=5, S=3, L=9)
         case_lbl(ans, "lbl_tab_t2d_f32", 302, W=7, NP=5, NTa=4, S=2, L=8, temp2d=True, fp32=True)
@@ -207,6 +226,7 @@ def main():
     case_ck(ans, "ck_g8_s1", 104, W=6, G=8, NP=5, NT=4, S=1, L=6, special=False)
     case_ck(ans, "ck_g10_s3_nozero", 105, W=6, G=10, NP=5, NT=4, S=3, L=7, zero_low_g=False)
     case_thermal(ans, "thermal_g6", 201, W=7, G=6, Li=11, NPAR=5, NVMR=3)
+    case_ko_unsorted(ans, "ko_unsorted_g8_s4", 107, W=5, G=8, L=4, S=4)
 
 
 if __name__ == "__main__":

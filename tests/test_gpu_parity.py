@@ -49,12 +49,49 @@ def test_k_overlap_golden(eng, golden_dir, name):
     np.testing.assert_allclose(tau, z["tau"], rtol=1e-11, atol=0)
 
 
-def test_k_overlap_unsorted_fails_loudly(eng, golden_dir):
-    z = _load(golden_dir, "ck_g10_s4")
-    k = z["k"].copy()
-    k[:, ::-1, :, 1] = k[:, :, :, 1].copy()                 # gas 1 decreasing in g
-    with pytest.raises(ValueError):
-        eng.k_overlap(z["DELG"], k, z["amount"])
+def test_k_overlap_unsorted_golden(eng, golden_dir):
+    """k-distributions NOT sorted in g (generic path: per-lane sort of each gas, weights follow) vs the reference's
+    k_overlap (golden): skip rules on the last ordinate, unmerged spectra returned in their original order."""
+    z = _load(golden_dir, "ko_unsorted_g8_s4")
+    tau = eng.k_overlap(z["DELG"], z["k"], z["amount"])
+    np.testing.assert_allclose(tau, z["tau"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("G,S,f32", [(20, 8, True), (10, 3, False), (7, 1, False)])
+def test_k_overlap_unsorted_vs_oracle(eng, oracle, G, S, f32):
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(G * 100 + S)
+    W, L = 150, 7
+    _, delg = syn.gauss_legendre_01(G, f32)
+    k = 10.0 ** rng.uniform(-25, -20, (W, G, L, S))
+    k[rng.uniform(size=k.shape) < 0.05] = 0.0                   # zeros anywhere, also in the last ordinate
+    amount = 10.0 ** rng.uniform(19, 22, (S, L))
+    tau = eng.k_overlap(delg, k, amount)
+    ref = oracle.k_overlap(delg, k, amount)
+    np.testing.assert_allclose(tau, ref, rtol=1e-11, atol=0)
+
+
+def test_cirsrad_unsorted_table_vs_oracle(eng, oracle):
+    """A k-table that is not monotone in g goes down the generic path for the whole forward model."""
+    from archnemesis_dist_amd import synthetic as syn
+    W, G, S, L, NP, NT = 200, 10, 4, 15, 6, 5
+    _, delg = syn.gauss_legendre_01(G, True)
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S, seed=3)
+    K = K[:, np.random.default_rng(1).permutation(G)]           # scramble the g axis
+    WAVE = 300.0 + np.arange(W)
+    eng.upload_ktable(K, PRESS, TEMP, WAVE, delg)
+    assert eng.ktable_info()[1] is False
+    atm = syn.synth_atmosphere(L, S)
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L)
+    EMTEMP = atm["lay_temp"][0][LAYINC[:, 0]][:, None]
+    spec = eng.cirsrad_ck_thermal(0, atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0], None, NLAYIN, LAYINC, SCALE,
+                                  EMTEMP, -1.0)
+    ref = oracle.cirsrad_ck_thermal(0, K, PRESS, TEMP, WAVE, delg, atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0],
+                                    None, NLAYIN, LAYINC, SCALE, EMTEMP, -1.0)
+    np.testing.assert_allclose(np.squeeze(spec), np.squeeze(ref), rtol=1e-10)
+    with pytest.raises(ValueError):      # the gradient merge has no generic path
+        eng.cirsradg_ck_thermal(0, atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0], None, None, S, S + 2,
+                                np.arange(S, dtype=np.int32), NLAYIN, LAYINC, SCALE, EMTEMP, -1.0)
 
 
 def test_thermal_emission_golden(eng, golden_dir):
