@@ -1342,8 +1342,8 @@ static int layer_average_impl(ansfm_ctx *ctx, int n_models, double RADIUS, int N
         !PRESS || !TEMP || !TOTAM || !AMOUNT || !PP || !FRAC || !DELH || !BASET || !LAYSF || (NDUST > 0 && (!DUST || !CONT)) ||
         (LAYINT != 0 && LAYINT != 1))
         FAIL(ANSFM_ERR_INVALID, "layer_average: bad argument");
-    if (LAYINT == 1 && ((NINT % 2) == 0 || NINT < 3 || NINT > kLayMaxNint))
-        FAIL(ANSFM_ERR_UNSUPPORTED, "layer_average: NINT must be odd and in [3,256] (scipy's even-N Simpson correction not built)");
+    if (LAYINT == 1 && (NINT < 2 || NINT > kLayMaxNint))
+        FAIL(ANSFM_ERR_UNSUPPORTED, "layer_average: NINT must be in [2,256]");
     if (5 + 2 * NVMR + NDUST > 160) FAIL(ANSFM_ERR_UNSUPPORTED, "layer_average: 5 + 2*NVMR + NDUST <= 160");
     if (DUST_UNITS && !XMOLWT)
         for (int j = 0; j < NDUST; ++j)

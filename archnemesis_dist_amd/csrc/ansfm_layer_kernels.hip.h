@@ -3,7 +3,8 @@
 // Restates archnemesis/Layer_0.py:755-1030 (MID_PATH and the Curtis-Godson ABSORBER_WEIGHTED_AVERAGE branch
 // :949-1010): slant-path sub-division of every layer into NINT points, linear interpolation (with
 // extrapolation) of the profile in height, n = p/(k_B T), Simpson integrals of n, h n, p n, T n, f n, vmr n,
-// vmr p n and dust, then the scaling back to vertical columns (:1013-1023).
+// vmr p n and dust (scipy.integrate.simpson incl. its even-N end correction), then the scaling back to vertical
+// columns (:1013-1023).
 // One workgroup per (state, layer): phase 1 = one thread per sub-point (geometry, bracket, p, T, n), phase 2 =
 // one thread per integrated quantity (scipy's unequal-spacing Simpson sum, sequential like np.sum's order to
 // rounding).  A numerical Jacobian re-derives the layers for every perturbed state (jacobian_nemesis ->
@@ -137,14 +138,27 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
         double r = 0.0;
         if (p.LAYINT == 0) {
             r = yval(0);   // point value; combined below
+        } else if (npts == 2) {
+            r = 0.5 * (S[1] - S[0]) * (yval(1) + yval(0));     // scipy simpson with two points
         } else {
-            for (int i = 0; i + 2 < npts; i += 2) {   // scipy _basic_simpson, unequal-spacing form
+            const int nodd = (npts & 1) ? npts : npts - 1;
+            for (int i = 0; i + 2 < nodd; i += 2) {   // scipy _basic_simpson, unequal-spacing form
                 const double h0 = S[i + 1] - S[i], h1 = S[i + 2] - S[i + 1];
                 const double hsum = h0 + h1, hprod = h0 * h1;
                 const double h0divh1 = (h1 != 0) ? h0 / h1 : 0.0;
                 const double inv = (h0divh1 != 0) ? 1.0 / h0divh1 : 0.0;
                 const double hq = (hprod != 0) ? hsum / hprod : 0.0;
                 r += hsum / 6.0 * (yval(i) * (2.0 - inv) + yval(i + 1) * (hsum * hq) + yval(i + 2) * (2.0 - h0divh1));
+            }
+            if (!(npts & 1)) {   // even number of points: simpson()'s correction for the last interval
+                const double h0 = S[npts - 2] - S[npts - 3], h1 = S[npts - 1] - S[npts - 2];
+                double num = 2 * (h1 * h1) + 3 * h0 * h1, den = 6 * (h1 + h0);
+                const double alpha = (den != 0) ? num / den : 0.0;
+                num = h1 * h1 + 3.0 * h0 * h1; den = 6 * h0;
+                const double beta = (den != 0) ? num / den : 0.0;
+                num = 1 * pow(h1, 3.0); den = 6 * h0 * (h0 + h1);
+                const double eta = (den != 0) ? num / den : 0.0;
+                r += alpha * yval(npts - 1) + beta * yval(npts - 2) - eta * yval(npts - 3);
             }
         }
         res[q] = r;

@@ -214,7 +214,7 @@ int ansfm_add_line_set_monochromatic_absorption(
  *   H,P,T[n][NPRO]; VMR[n][NPRO][NVMR]; DUST[n][NPRO][NDUST] or NULL; PARAH2[n][NPRO] or NULL;
  *   BASEH[n][NLAY] (layer_split output); DUST_UNITS[NDUST] (int32) / XMOLWT[n][NPRO] (kg/mol) or NULL
  *   -> HEIGHT,PRESS,TEMP,TOTAM,FRAC,DELH,BASET,LAYSF [n][NLAY]; AMOUNT,PP [n][NLAY][NVMR]; CONT [n][NLAY][NDUST].
- * NINT must be odd (scipy.integrate.simpson's even-N end correction is not built). */
+ * 2 <= NINT <= 256 (even NINT: scipy.integrate.simpson's last-interval correction, as the reference gets). */
 int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, const double *H,
                         const double *P, const double *T, int NVMR, const double *VMR, int NDUST,
                         const double *DUST, const double *PARAH2, int NLAY, const double *BASEH,

@@ -6,8 +6,9 @@
  * Third-party arithmetic on the path (scipy un-pinned by the reference; 1.15.3 in the build container):
  *   scipy.interpolate.interp1d(kind='linear', fill_value='extrapolate')  (Layer_0.interp :645)
  *       -> idx = clip(searchsorted(x, xnew), 1, n-1); slope*(xnew - x_lo) + y_lo
- *   scipy.integrate.simpson(y, x=S) for an odd number of points (:969-1010)
- *       -> scipy/integrate/_quadrature.py::_basic_simpson with the unequal-spacing weights
+ *   scipy.integrate.simpson(y, x=S) (:969-1010)
+ *       -> scipy/integrate/_quadrature.py::_basic_simpson with the unequal-spacing weights; for an even number of
+ *          points the last-interval correction of simpson() (alpha, beta, eta)
  *   numpy.linspace (step*arange + start, last point forced to stop)
  */
 #include <math.h>
@@ -30,9 +31,12 @@ static double interp_lin(const double *x, const double *y, int n, double xn)
 }
 
 static double simpson_x(const double *y, const double *x, int n)
-{   /* n odd */
+{   /* scipy.integrate.simpson(y, x=x): n odd -> _basic_simpson; n even -> _basic_simpson on the first n-1 points plus the
+     * last-interval correction (alpha, beta, eta; scipy 1.15 _quadrature.py, "Cartwright"); n == 2 -> trapezoid */
+    if (n == 2) return 0.5 * (x[1] - x[0]) * (y[1] + y[0]);
+    const int nodd = (n % 2 == 0) ? n - 1 : n;
     double res = 0.0;
-    for (int i = 0; i + 2 < n; i += 2) {
+    for (int i = 0; i + 2 < nodd; i += 2) {
         double h0 = x[i + 1] - x[i], h1 = x[i + 2] - x[i + 1];
         double hsum = h0 + h1, hprod = h0 * h1;
         double h0divh1 = (h1 != 0) ? h0 / h1 : 0.0;
@@ -40,10 +44,20 @@ static double simpson_x(const double *y, const double *x, int n)
         double hq = (hprod != 0) ? hsum / hprod : 0.0;
         res += hsum / 6.0 * (y[i] * (2.0 - inv) + y[i + 1] * (hsum * hq) + y[i + 2] * (2.0 - h0divh1));
     }
+    if (n % 2 == 0) {
+        const double h0 = x[n - 2] - x[n - 3], h1 = x[n - 1] - x[n - 2];
+        double num = 2 * (h1 * h1) + 3 * h0 * h1, den = 6 * (h1 + h0);
+        const double alpha = (den != 0) ? num / den : 0.0;
+        num = h1 * h1 + 3.0 * h0 * h1; den = 6 * h0;
+        const double beta = (den != 0) ? num / den : 0.0;
+        num = 1 * pow(h1, 3); den = 6 * h0 * (h0 + h1);
+        const double eta = (den != 0) ? num / den : 0.0;
+        res += alpha * y[n - 1] + beta * y[n - 2] - eta * y[n - 3];
+    }
     return res;
 }
 
-/* Returns 0, or 5 when NINT is even (scipy then adds a Cartwright end correction, not restated). */
+/* Returns 0 (5: NINT < 2). */
 ORC_API int orc_layer_average(
     double RADIUS, int NPRO, const double *H, const double *P, const double *T, int NVMR, const double *VMR /*[NPRO][NVMR]*/,
     int NDUST, const double *DUST /*[NPRO][NDUST] or NULL*/, const double *PARAH2 /*[NPRO] or NULL*/, int NLAY,
@@ -53,7 +67,7 @@ ORC_API int orc_layer_average(
     double *BASET, double *LAYSF)
 {
     const double k_B = 1.38065e-23, AVOGAD = 6.02214076e23;      /* Layer_0.py:828, :36 */
-    if (LAYINT == 1 && (NINT % 2) == 0) return 5;
+    if (LAYINT == 1 && NINT < 2) return 5;
     const double sn = sin(LAYANG * M_PI / 180), cs = cos(LAYANG * M_PI / 180);
     const double z0 = RADIUS + LAYHT, zmax = RADIUS + H[NPRO - 1];
     const double SMAX = sqrt(zmax * zmax - (z0 * sn) * (z0 * sn)) - z0 * cs;

@@ -53,6 +53,14 @@ def main():
             gout[f"{cn}_{n}"] = np.asarray(v)
         print("g", cn, np.abs(r[11]).sum(), np.abs(r[12]).sum(), np.abs(r[13]).sum())
     np.savez_compressed(os.path.join(OUT, "layer_averageg.npz"), **gout)
+    # ---- layer_average with an even number of sub-points (scipy's simpson end correction) and NINT = 2 (trapezoid)
+    eout = {}
+    for nint in (100, 2, 4):
+        r = L0.layer_average(RADIUS, H, P, T, np.arange(NV), VMR, DUST, PARAH2, BASEH, BASEP, LAYANG=35.0, LAYINT=1,
+                             LAYHT=-6.0e4, NINT=nint)
+        for n, v in zip(names, r):
+            eout[f"nint{nint}_{n}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "layer_average_even_nint.npz"), **eout)
 
 
 if __name__ == "__main__":

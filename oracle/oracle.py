@@ -264,7 +264,7 @@ def layer_average(RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP, LAYANG=0
                                  _p(_c(DUST_UNITS, np.int32)), _p(_c(XMOLWT)), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(AM),
                                  _p(PPo), _p(CO), _p(FR), _p(DELH), _p(BASET), _p(LAYSF))
     if rc:
-        raise NotImplementedError("layer_average: even NINT not restated")
+        raise ValueError("layer_average: NINT < 2")
     return o[0], o[1], o[2], o[3], AM, PPo, CO, FR, DELH, BASET, LAYSF
 
 

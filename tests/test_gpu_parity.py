@@ -475,3 +475,13 @@ def test_layer_averageg_golden(eng, golden_dir, case):
             eng.layer_averageg(*a, LAYHT=-6.0e4, NINT=100, LAYINT=1)
         with pytest.raises(ValueError):
             eng.layer_averageg(*a, LAYHT=-6.0e4, NINT=101, LAYINT=0, DUST_UNITS=np.array([-1, 0]), XMOLWT=z["XMOLWT"])
+
+
+@pytest.mark.parametrize("nint", [100, 2, 4])
+def test_layer_average_even_nint_golden(eng, golden_dir, nint):
+    from test_layer_oracle import NAMES
+    z = _load(golden_dir, "layer_average"); e = _load(golden_dir, "layer_average_even_nint")
+    r = eng.layer_average(float(z["RADIUS"]), z["H"], z["P"], z["T"], None, z["VMR"], z["DUST"], z["PARAH2"], z["split1_BASEH"],
+                          z["split1_BASEP"], LAYANG=35.0, LAYINT=1, LAYHT=-6.0e4, NINT=nint)
+    for n, v in zip(NAMES, r):
+        np.testing.assert_allclose(v, e[f"nint{nint}_{n}"], rtol=1e-10, err_msg=n)

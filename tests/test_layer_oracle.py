@@ -44,3 +44,14 @@ def test_layer_averageg_reference_failures(oracle, golden_dir):
         oracle.layer_averageg(*a, LAYHT=-6.0e4, NINT=100, LAYINT=1)
     with pytest.raises(ValueError):      # mis-indented else of the MID_PATH branch (:1255-1257)
         oracle.layer_averageg(*a, LAYHT=-6.0e4, NINT=101, LAYINT=0, DUST_UNITS=np.array([-1, 0]), XMOLWT=z["XMOLWT"])
+
+
+@pytest.mark.parametrize("nint", [100, 2, 4])
+def test_layer_average_even_nint(oracle, golden_dir, nint):
+    """scipy.integrate.simpson with an even number of points (last-interval correction) / two points (trapezoid)."""
+    z = np.load(os.path.join(golden_dir, "layer_average.npz"))
+    e = np.load(os.path.join(golden_dir, "layer_average_even_nint.npz"))
+    r = oracle.layer_average(float(z["RADIUS"]), z["H"], z["P"], z["T"], None, z["VMR"], z["DUST"], z["PARAH2"],
+                             z["split1_BASEH"], z["split1_BASEP"], LAYANG=35.0, LAYINT=1, LAYHT=-6.0e4, NINT=nint)
+    for n, v in zip(NAMES, r):
+        np.testing.assert_allclose(v, e[f"nint{nint}_{n}"], rtol=1e-11, err_msg=n)
