@@ -5,6 +5,7 @@
 #include "ansfm_lbl_kernels.hip.h"
 #include "ansfm_layer_kernels.hip.h"
 #include "ansfm_map_kernels.hip.h"
+#include "ansfm_conv_kernels.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -1070,6 +1071,73 @@ int ansfm_map2xvec(ansfm_ctx *ctx, int W, int NPAR, int NPRO, int P, int NX, con
     HIPCHK(hipMemcpyAsync(dSPECOUT, ctx->tmp_out.p, nout * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ANSFM_OK;
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* ILS convolution (Measurement_0.lblconv / lblconvg / lblconv_fil / lblconvg_fil)             */
+/* ------------------------------------------------------------------------------------------ */
+static int ils_conv_impl(ansfm_ctx *ctx, int nwave, const double *vwave, const double *y, int nx, const double *dydx,
+                         int nconv, const double *vconv, int ishape, double fwhm, int grad_rules, int nfilmax,
+                         const int32_t *nfil, const double *vfil, const double *afil, double *yout, double *gradout)
+{
+    CHECK_CTX(ctx);
+    const bool filter = nfil != nullptr;
+    if (nwave <= 0 || nconv <= 0 || nx < 0 || !vwave || !y || !vconv || !yout || (nx > 0 && (!dydx || !gradout)) ||
+        (filter && (!vfil || !afil || nfilmax < 2)))
+        FAIL(ANSFM_ERR_INVALID, "lblconv: bad argument");
+    for (int i = 1; i < nwave; ++i)
+        if (!(vwave[i] >= vwave[i - 1])) FAIL(ANSFM_ERR_UNSORTED, "lblconv: the calculation wavenumbers must be ascending");
+    if (filter)
+        for (int j = 0; j < nconv; ++j) {
+            if (nfil[j] < 2 || nfil[j] > nfilmax) FAIL(ANSFM_ERR_INVALID, "lblconv_fil: 2 <= nfil[j] <= rows of vfil");
+            for (int k = 1; k < nfil[j]; ++k)
+                if (!(vfil[(size_t)k * nconv + j] > vfil[(size_t)(k - 1) * nconv + j]))
+                    FAIL(ANSFM_ERR_UNSORTED, "lblconv_fil: filter wavenumbers must be strictly ascending");
+        }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t D = sizeof(double);
+    const void *d[8] = {nullptr};
+    int rc;
+    if ((rc = h2d(ctx, ctx->hb[0], vwave, nwave * D, &d[0]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[1], y, nwave * D, &d[1]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[2], dydx, (size_t)nwave * nx * D, &d[2]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[3], vconv, nconv * D, &d[3]))) return rc;
+    if (filter) {
+        if ((rc = h2d(ctx, ctx->hb[4], nfil, nconv * sizeof(int32_t), &d[4]))) return rc;
+        if ((rc = h2d(ctx, ctx->hb[5], vfil, (size_t)nfilmax * nconv * D, &d[5]))) return rc;
+        if ((rc = h2d(ctx, ctx->hb[6], afil, (size_t)nfilmax * nconv * D, &d[6]))) return rc;
+    }
+    HIPCHK(ctx->tmp_out.reserve(((size_t)nconv * (nx + 1)) * D));
+    ConvParams p;
+    memset(&p, 0, sizeof p);
+    p.vwave = (const double *)d[0]; p.y = (const double *)d[1]; p.dydx = (const double *)d[2]; p.vconv = (const double *)d[3];
+    p.nfil = (const int32_t *)d[4]; p.vfil = (const double *)d[5]; p.afil = (const double *)d[6];
+    p.yout = ctx->tmp_out.as<double>(); p.gradout = p.yout + nconv;
+    p.nwave = nwave; p.nx = nx; p.nconv = nconv; p.ishape = ishape; p.grad_rules = grad_rules; p.filter = filter ? 1 : 0;
+    p.fwhm = fwhm;
+    hipLaunchKernelGGL(k_ils_conv, dim3((unsigned)nconv, (unsigned)((nx + 1 + 127) / 128)), dim3(128), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(yout, p.yout, nconv * D, hipMemcpyDeviceToHost, ctx->stream));
+    if (nx > 0) HIPCHK(hipMemcpyAsync(gradout, p.gradout, (size_t)nconv * nx * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+int ansfm_lblconv(ansfm_ctx *ctx, int nwave, const double *vwave, const double *y, int nx, const double *dydx, int nconv,
+                  const double *vconv, int ishape, double fwhm, double *yout, double *gradout)
+{
+    if (ctx && !(fwhm > 0.0)) FAIL(ANSFM_ERR_INVALID, "lblconv: only valid if FWHM > 0");
+    return ils_conv_impl(ctx, nwave, vwave, y, nx, dydx, nconv, vconv, ishape, fwhm, nx > 0 ? 1 : 0, 0, nullptr, nullptr, nullptr,
+                         yout, gradout);
+}
+
+int ansfm_lblconv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const double *y, int nx, const double *dydx, int nconv,
+                      const double *vconv, int nfilmax, const int32_t *nfil, const double *vfil, const double *afil,
+                      double *yout, double *gradout)
+{
+    if (ctx && !nfil) FAIL(ANSFM_ERR_INVALID, "lblconv_fil: bad argument");
+    return ils_conv_impl(ctx, nwave, vwave, y, nx, dydx, nconv, vconv, 0, 0.0, 0, nfilmax, nfil, vfil, afil, yout, gradout);
 }
 
 /* ------------------------------------------------------------------------------------------ */

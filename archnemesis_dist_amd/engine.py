@@ -357,6 +357,41 @@ class AnsfmEngine:
         self._check(rc, "map2xvec")
         return out
 
+    # ---- instrument line shape ---------------------------------------------------------------------------------
+    def lblconv(self, nwave, vwave, y, nconv, vconv, ishape, fwhm):
+        """Measurement_0.lblconv (:3335), one geometry: y (nwave) -> yout (nconv)."""
+        return self._lblconv(vwave, y, None, nconv, vconv, ishape, fwhm)[0]
+
+    def lblconvg(self, nwave, vwave, y, dydx, nconv, vconv, ishape, fwhm):
+        """Measurement_0.lblconvg (:3799), one geometry: -> yout (nconv), gradout (nconv, nx)."""
+        return self._lblconv(vwave, y, dydx, nconv, vconv, ishape, fwhm)
+
+    def lblconv_fil(self, nwave, vwave, y, nconv, vconv, nfil, vfil, afil):
+        """Measurement_0.lblconv_fil (:3549)."""
+        return self._lblconv(vwave, y, None, nconv, vconv, None, None, (nfil, vfil, afil))[0]
+
+    def lblconvg_fil(self, nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil):
+        """Measurement_0.lblconvg_fil (:3992)."""
+        return self._lblconv(vwave, y, dydx, nconv, vconv, None, None, (nfil, vfil, afil))
+
+    def _lblconv(self, vwave, y, dydx, nconv, vconv, ishape, fwhm, fil=None):
+        vwave = _np(vwave); y = _np(y); vconv = _np(np.asarray(vconv)[:nconv])
+        if y.ndim != 1 or (dydx is not None and np.ndim(dydx) != 2):
+            raise ValueError("one geometry per call: y (nwave), dydx (nwave, nx)")
+        dydx = None if dydx is None else _np(dydx)
+        nx = 0 if dydx is None else dydx.shape[1]
+        yout = np.empty(nconv); gout = np.empty((nconv, nx))
+        if fil is None:
+            rc = self._lib.ansfm_lblconv(self._ctx, vwave.size, _ptr(vwave), _ptr(y), nx, _ptr(dydx), int(nconv), _ptr(vconv),
+                                         int(ishape), float(fwhm), _ptr(yout), _ptr(gout))
+        else:
+            nfil = _np(np.asarray(fil[0])[:nconv], np.int32)
+            vfil = _np(np.asarray(fil[1])[:, :nconv]); afil = _np(np.asarray(fil[2])[:, :nconv])
+            rc = self._lib.ansfm_lblconv_fil(self._ctx, vwave.size, _ptr(vwave), _ptr(y), nx, _ptr(dydx), int(nconv), _ptr(vconv),
+                                             vfil.shape[0], _ptr(nfil), _ptr(vfil), _ptr(afil), _ptr(yout), _ptr(gout))
+        self._check(rc, "lblconv")
+        return yout, gout
+
     def get_taugas(self, L, model=0):
         W, G = self.dims[0], self.dims[1]
         out = np.empty((W, G, L))

@@ -306,3 +306,42 @@ def install_gpu_layering(device=0):
     l0.layer_average = _wrap(eng.layer_average)
     l0.layer_averageg = _wrap(eng.layer_averageg)
     return l0.layer_average, l0.layer_averageg
+
+
+def install_gpu_convolution(device=0):
+    """Route the single-geometry ILS convolution kernels of Measurement_0 -- lblconv (:3335), lblconvg (:3799), lblconv_fil
+    (:3549), lblconvg_fil (:3992), which the Measurement_0.lblconv / lblconvg methods call by module-global name with
+    IGEOM = int (the way nemesisfm / nemesisfmg use them) -- through the GPU.  The *_ngeom variants stay the reference's."""
+    import importlib
+    m0 = importlib.import_module("archnemesis.Measurement_0")
+    eng = get_engine(device)
+    if not hasattr(m0, "_ansfm_reference_conv"):
+        m0._ansfm_reference_conv = (m0.lblconv, m0.lblconvg, m0.lblconv_fil, m0.lblconvg_fil)
+    ref = m0._ansfm_reference_conv
+
+    def _ascending(v):
+        v = np.asarray(v)
+        return v.ndim == 1 and np.all(v[1:] >= v[:-1])
+
+    def lblconv(nwave, vwave, y, nconv, vconv, ishape, fwhm):
+        if np.ndim(y) != 1 or not _ascending(vwave):
+            return ref[0](nwave, vwave, y, nconv, vconv, ishape, fwhm)
+        return eng.lblconv(nwave, vwave, y, nconv, vconv, int(ishape), fwhm)
+
+    def lblconvg(nwave, vwave, y, dydx, nconv, vconv, ishape, fwhm):
+        if np.ndim(y) != 1 or np.ndim(dydx) != 2 or not _ascending(vwave):
+            return ref[1](nwave, vwave, y, dydx, nconv, vconv, ishape, fwhm)
+        return eng.lblconvg(nwave, vwave, y, dydx, nconv, vconv, int(ishape), fwhm)
+
+    def lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil):
+        if np.ndim(y) != 1 or not _ascending(vwave):
+            return ref[2](nwave, vwave, y, nconv, vconv, nfil, vfil, afil)
+        return eng.lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil)
+
+    def lblconvg_fil(nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil):
+        if np.ndim(y) != 1 or np.ndim(dydx) != 2 or not _ascending(vwave):
+            return ref[3](nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil)
+        return eng.lblconvg_fil(nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil)
+
+    m0.lblconv, m0.lblconvg, m0.lblconv_fil, m0.lblconvg_fil = lblconv, lblconvg, lblconv_fil, lblconvg_fil
+    return lblconv, lblconvg, lblconv_fil, lblconvg_fil

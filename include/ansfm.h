@@ -256,6 +256,21 @@ int ansfm_map2pro(ansfm_ctx *ctx, int W, int NPAR, int LIMAX, int P, int NPRO, i
 int ansfm_map2xvec(ansfm_ctx *ctx, int W, int NPAR, int NPRO, int P, int NX, const double *dSPECIN,
                    const double *xmap, double *dSPECOUT);
 
+/* ---- instrument line shape (the step after the path) ---------------------------------------
+ * Measurement_0.lblconv (Measurement_0.py:3335; nx = 0) / lblconvg (:3799; nx > 0): convolution of the monochromatic
+ * spectrum y[nwave] (and gradients dydx[nwave][nx]) with the ILS given by ISHAPE (0 square, 1 triangular, 2 gaussian,
+ * 3 Hamming, 4 Hanning) and FWHM > 0 at the convolution wavenumbers vconv[nconv] -> yout[nconv], gradout[nconv][nx].
+ * Reference behaviour kept: only weights > 0 count; the Hamming window of lblconv is the single point
+ * vcen - 1.1 FWHM (:3391-3393) while lblconvg uses vcen -+ FWHM (:3866-3868); Hanning assigns no weight, so the
+ * result is 0/0 = NaN like the reference's.  vwave must be ascending (ANSFM_ERR_UNSORTED otherwise).
+ * lblconv_fil (:3549) / lblconvg_fil (:3992): the ILS is tabulated per convolution point, nfil[nconv] points in
+ * column j of vfil / afil [nfilmax][nconv], weights by linear interpolation (np.interp). */
+int ansfm_lblconv(ansfm_ctx *ctx, int nwave, const double *vwave, const double *y, int nx, const double *dydx,
+                  int nconv, const double *vconv, int ishape, double fwhm, double *yout, double *gradout);
+int ansfm_lblconv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const double *y, int nx,
+                      const double *dydx, int nconv, const double *vconv, int nfilmax, const int32_t *nfil,
+                      const double *vfil, const double *afil, double *yout, double *gradout);
+
 /* Vertical gas opacity of the last cirsrad call's first model, TAUGAS[W][G][L]
  * (what CIRSrad leaves in LayerX.TAUGAS, ForwardModel_0.py:3925) -- host pointer out. */
 int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS);

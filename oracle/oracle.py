@@ -325,3 +325,81 @@ def map2xvec(dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NX, xmap):
     x = np.asarray(xmap, float)
     W, NPAR, NP_, P = a.shape
     return np.einsum("wkp,xk->wpx", a.reshape(W, NPAR * NP_, P), x.reshape(NX, NPAR * NP_), optimize=True)
+
+
+# ---- ILS convolution (Measurement_0.lblconv :3335, lblconvg :3799, lblconv_fil :3549, lblconvg_fil :3992) ---------
+def _ils_window(ishape, vcen, fwhm, grad):
+    """Window [v1, v2] and the Gaussian sigma of one convolution point.  The two reference kernels differ for the
+    Hamming shape: lblconv sets v1 = v2 = vcen - 1.1*fwhm (:3391-3393), lblconvg vcen -+ fwhm (:3866-3868)."""
+    sig = 0.0
+    if ishape == 0:
+        v1 = vcen - 0.5 * fwhm; v2 = v1 + fwhm
+    elif ishape == 1:
+        v1 = vcen - fwhm; v2 = vcen + fwhm
+    elif ishape == 2:
+        sig = 0.5 * fwhm / np.sqrt(np.log(2.0)); v1 = vcen - 3. * sig; v2 = vcen + 3. * sig
+    elif ishape == 3:
+        if grad:
+            v1 = vcen - fwhm; v2 = vcen + fwhm
+        else:
+            v1 = vcen - 1.1 * fwhm; v2 = vcen - 1.1 * fwhm
+    else:
+        v1 = vcen - 3. * fwhm; v2 = vcen + 3. * fwhm
+    return v1, v2, sig
+
+
+def _ils_weight(ishape, dv_plus_vcen, vcen, fwhm, sig):
+    v = dv_plus_vcen
+    if ishape == 0:
+        return np.ones_like(v)
+    if ishape == 1:
+        return 1.0 - np.abs(v - vcen) / fwhm
+    if ishape == 2:
+        return np.exp(-((v - vcen) / sig) ** 2.0)
+    if ishape == 3:
+        a = 0.907 / fwhm
+        k = v - vcen
+        with np.errstate(all="ignore"):
+            num = a * (1.08 - (0.64 * a ** 2 * k ** 2)) * np.sin(2 * np.pi * a * k)
+            den = (1 - 4 * a ** 2 * k ** 2) * (2 * np.pi * a * k)
+            f = num / den
+        return np.where(k != 0.0, f, a * 1.08)
+    return np.zeros_like(v)             # Hanning: no weight is ever assigned (`else: pass`) -> 0/0
+
+
+def _ils_sum(f1, cols):
+    """sum_i f1_i * col_i over the window in index order, only where f1 > 0 (:3433-3435)."""
+    keep = f1 > 0.0
+    out = np.zeros(cols.shape[1]); nor = 0.0
+    for fi, row in zip(f1[keep], cols[keep]):
+        out = out + fi * row
+        nor = nor + fi
+    with np.errstate(all="ignore"):
+        return out / nor
+
+
+def lblconv(nwave, vwave, y, nconv, vconv, ishape, fwhm, dydx=None):
+    """Measurement_0.lblconv (dydx None) / lblconvg: yout (nconv) [, gradout (nconv, nx)]."""
+    vwave = np.asarray(vwave, float); y = np.asarray(y, float)
+    grad = dydx is not None
+    cols = np.column_stack([np.asarray(dydx, float), y]) if grad else y[:, None]
+    out = np.zeros((nconv, cols.shape[1]))
+    for j in range(nconv):
+        v1, v2, sig = _ils_window(int(ishape), vconv[j], fwhm, grad)
+        idx = np.where((vwave >= v1) & (vwave <= v2))[0]
+        out[j] = _ils_sum(_ils_weight(int(ishape), vwave[idx], vconv[j], fwhm, sig), cols[idx])
+    return (out[:, -1], out[:, :-1]) if grad else out[:, 0]
+
+
+def lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil, dydx=None):
+    """Measurement_0.lblconv_fil / lblconvg_fil: tabulated filter per convolution point, np.interp weights."""
+    vwave = np.asarray(vwave, float); y = np.asarray(y, float)
+    grad = dydx is not None
+    cols = np.column_stack([np.asarray(dydx, float), y]) if grad else y[:, None]
+    out = np.zeros((nconv, cols.shape[1]))
+    for j in range(nconv):
+        n = int(nfil[j])
+        xp = np.asarray(vfil[:n, j], float); yp = np.asarray(afil[:n, j], float)
+        idx = np.where((vwave >= xp[0]) & (vwave <= xp[-1]))[0]
+        out[j] = _ils_sum(np.interp(vwave[idx], xp, yp), cols[idx])
+    return (out[:, -1], out[:, :-1]) if grad else out[:, 0]

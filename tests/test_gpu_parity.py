@@ -485,3 +485,38 @@ def test_layer_average_even_nint_golden(eng, golden_dir, nint):
                           z["split1_BASEP"], LAYANG=35.0, LAYINT=1, LAYHT=-6.0e4, NINT=nint)
     for n, v in zip(NAMES, r):
         np.testing.assert_allclose(v, e[f"nint{nint}_{n}"], rtol=1e-10, err_msg=n)
+
+
+@pytest.mark.parametrize("ishape", range(5))
+def test_lblconv_golden(eng, golden_dir, ishape):
+    """ILS convolution vs the reference (golden), every ISHAPE incl. the ones whose result is 0/0 in the reference."""
+    from test_conv_oracle import close_nan
+    z = _load(golden_dir, "ils_conv")
+    nw, nc, fw = z["vwave"].size, z["vconv"].size, float(z["fwhm"])
+    close_nan(eng.lblconv(nw, z["vwave"], z["y"], nc, z["vconv"], ishape, fw), z[f"conv_{ishape}"], 1e-12)
+    yo, go = eng.lblconvg(nw, z["vwave"], z["y"], z["dydx"], nc, z["vconv"], ishape, fw)
+    close_nan(yo, z[f"convg_{ishape}_y"], 1e-12)
+    close_nan(go, z[f"convg_{ishape}_g"], 1e-11)
+
+
+def test_lblconv_fil_golden_and_large_vs_oracle(eng, oracle, golden_dir):
+    from test_conv_oracle import close_nan
+    z = _load(golden_dir, "ils_conv")
+    nw, nc = z["vwave"].size, z["vconv"].size
+    close_nan(eng.lblconv_fil(nw, z["vwave"], z["y"], nc, z["vconv"], z["nfil"], z["vfil"], z["afil"]), z["fil"], 1e-12)
+    yo, go = eng.lblconvg_fil(nw, z["vwave"], z["y"], z["dydx"], nc, z["vconv"], z["nfil"], z["vfil"], z["afil"])
+    close_nan(yo, z["filg_y"], 1e-12)
+    close_nan(go, z["filg_g"], 1e-11)
+    # a larger case (windows of several hundred points, 200 gradient columns) against the oracle
+    rng = np.random.default_rng(8)
+    nw, nx, nc = 20000, 200, 40
+    vw = 1000.0 + 1e-3 * np.arange(nw)
+    y = rng.uniform(1, 2, nw); dy = rng.normal(size=(nw, nx))
+    vc = np.linspace(1001.0, 1019.0, nc)
+    for ishape in (1, 2, 3):
+        yo, go = eng.lblconvg(nw, vw, y, dy, nc, vc, ishape, 0.4)
+        yr, gr = oracle.lblconv(nw, vw, y, nc, vc, ishape, 0.4, dydx=dy)
+        np.testing.assert_allclose(yo, yr, rtol=1e-12)
+        np.testing.assert_allclose(go, gr, rtol=0, atol=1e-12 * np.max(np.abs(gr)))
+    with pytest.raises(ValueError):
+        eng.lblconv(nw, vw[::-1].copy(), y, nc, vc, 1, 0.4)
