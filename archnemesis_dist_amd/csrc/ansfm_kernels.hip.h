@@ -330,11 +330,18 @@ __device__ __forceinline__ double fast_div(double n, double d)
 // One popped element of the merge with everything the replay and the rank walk need, fetched from LDS
 // as soon as the winner key is known (software pipelining: the walk of element t runs while the
 // operands of element t+1 are in flight).
+// LDS accessed through 32-bit byte addresses (address space 3): a tree-path node costs two integer instructions
+// (bit-field extract, shift-add onto the lane's base) and the same register serves the write-back.
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __forceinline__ unsigned lds_addr(const double *p) { return (unsigned)(size_t)(const lds_double *)p; }
+__device__ __forceinline__ double lds_ld(unsigned a) { return *(const lds_double *)(size_t)a; }
+__device__ __forceinline__ void lds_st(unsigned a, double v) { *(lds_double *)(size_t)a = v; }
+
 template <int DEPTH>
 struct MergeElem {
     double ai, bc, bn, w;
     double tv[DEPTH];
-    int off[DEPTH];   // LDS element offsets of the tree path (re-used for the write-back)
+    unsigned off[DEPTH];   // LDS byte addresses of the tree path (re-used for the write-back)
     int ci, np;
 };
 
@@ -358,10 +365,13 @@ __device__ __forceinline__ void merge_fetch(double key, int G, int lane, const d
     if constexpr (W32) w = (double)(float)w;     // -> the float32 product NumPy forms (DELG float32)
     e.w = w;
     const unsigned t = (unsigned)(G + ci);
+    const unsigned nvl = lds_addr(NV + lane);
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-        e.off[d] = (int)__builtin_amdgcn_ubfe(t, d + 1, 6) * kWave + lane;   // node (G+ci) >> (d+1)
-        e.tv[d] = NV[e.off[d]];
+        unsigned node;                                                        // (G+ci) >> (d+1); asm keeps it one v_bfe
+        asm("v_bfe_u32 %0, %1, %2, 6" : "=v"(node) : "v"(t), "n"(d + 1));      // (the compiler expands it to shl+and)
+        e.off[d] = (node << 9) + nvl;                                         // rows of 512 bytes: one v_lshl_add
+        e.tv[d] = lds_ld(e.off[d]);
     }
 }
 
@@ -420,7 +430,7 @@ __device__ __forceinline__ unsigned merge_step(MergeElem<DEPTH> &e, MergeElem<DE
     for (int d = 0; d < DEPTH; ++d) {
         double lo, hi;
         minmax_f64(e.tv[d], car, lo, hi);
-        NV[e.off[d]] = hi;
+        lds_st(e.off[d], hi);
         car = lo;
     }
     // 2. fetch the operands of the new winner (LDS reads in flight during the walk)
