@@ -28,6 +28,8 @@ def main():
         bench_ms(eng, out, rng)
     if only in (None, "lbl"):
         bench_lbl(eng, out, rng)
+    if only == "lbl_c5":
+        bench_lbl(eng, out, rng, full=True)
     if only in (None, "layer"):
         bench_layer(eng, out)
     if only in (None, "maps"):
@@ -109,11 +111,12 @@ def bench_ms(eng, out, rng):
                                   "scaled_to_W1e4_s": t * 1e4 / Wm}
 
 
-def bench_lbl(eng, out, rng):
-    # ---- runtime LBL, reduced C5 ---------------------------------------------------------------------------
-    nw, N, Ll = 200000, 20000, 5
+def bench_lbl(eng, out, rng, full=False):
+    # ---- runtime LBL: reduced C5 (default) or the full C5 grid (1e6 wavenumbers x 50 layers, 1e5 lines) ---------
+    nw, N, Ll = (1000000, 100000, 50) if full else (200000, 20000, 5)
     wn = 2000.0 + 1e-3 * np.arange(nw)
-    nu = np.sort(rng.uniform(1925.0, 2275.0, N)); sw = 10.0 ** rng.uniform(-28, -19, N); el = rng.uniform(0, 3000, N)
+    span = nw * 1e-3
+    nu = np.sort(rng.uniform(2000.0 - 75.0, 2000.0 + span + 75.0, N)); sw = 10.0 ** rng.uniform(-28, -19, N); el = rng.uniform(0, 3000, N)
     bp = np.zeros((3, N)); bp[0] = rng.uniform(0.02, 0.1, N); bp[1] = rng.uniform(0.5, 0.8, N); bp[2] = rng.uniform(-0.01, 0.01, N)
     c2 = 2.99792458E10 * 6.62607015E-27 / 1.380649E-16
     sr = 1 - np.exp(-c2 * nu / 296.0)
@@ -121,8 +124,8 @@ def bench_lbl(eng, out, rng):
     o = np.zeros((Ll, nw))
     t = timeit(lambda: eng.add_line_set_monochromatic_absorption(wn, 0, tt, 296.0, pp, 1.0, qq, 1.0, 28.0, np.array([1.0]), bp, nu,
                                                                  sw, el, sr, o), n=2)
-    evals = float(N) * (150.0 / 1e-3) * Ll * (200.0 / 350.0)     # lines whose window overlaps the grid, roughly
-    out["lbl_runtime_reducedC5"] = {"wall_s": t, "grid": nw, "lines": N, "layers": Ll, "approx_profile_evals": evals,
+    evals = float(N) * (150.0 / 1e-3) * Ll * (span / (span + 150.0))     # lines whose window overlaps the grid, roughly
+    out["lbl_runtime_C5" if full else "lbl_runtime_reducedC5"] = {"wall_s": t, "grid": nw, "lines": N, "layers": Ll, "approx_profile_evals": evals,
                                     "Gevals_per_s": evals / t / 1e9}
 
 
