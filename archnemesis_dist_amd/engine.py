@@ -29,8 +29,10 @@ def _ptr(a):
 
 
 def _fingerprint(a):
-    """Identity of a result array handed back to the caller: address, shape and a few sampled values -- enough to
-    recognise "the array I returned, unmodified" when it comes back as the next step's input."""
+    """Identity of a result array handed back to the caller: address, shape and a few sampled values, to recognise
+    "the array I returned" when it comes back as the next step's input.  Arrays that have a device twin are handed out
+    read-only (flags.writeable = False), so "unmodified" does not rest on the samples: an in-place edit raises, an
+    edited copy has another address."""
     flat = a.reshape(-1)
     idx = np.linspace(0, flat.size - 1, num=min(flat.size, 32)).astype(np.int64)
     return (a.ctypes.data, a.shape, a.strides, flat[idx].tobytes())
@@ -222,7 +224,10 @@ class AnsfmEngine:
             _ptr(ig), P, LIMAX, _ptr(NLAYIN), _ptr(LAYINC), _ptr(SC), _ptr(ET), _ptr(TS), _ptr(_np(EMISSIVITY)),
             _ptr(_np(xfac)), _ptr(spec), _ptr(dspec), _ptr(dts))
         self._check(rc, "cirsradg_ck_thermal")
-        self._chain_dspec = _fingerprint(dspec[0]) if n == 1 else None   # device copy usable by map2pro
+        self._chain_dspec = None
+        if n == 1:                       # device copy usable by map2pro: hand the host array out read-only
+            dspec.flags.writeable = False
+            self._chain_dspec = _fingerprint(dspec[0])
         return (spec[0], dspec[0], dts[0]) if single else (spec, dspec, dts)
 
     def cirsrad_ck_thermal_dev(self, ISPACE, n_models, L, lay_press_pa, lay_temp, amount, taucont, P, LIMAX,
@@ -340,6 +345,7 @@ class AnsfmEngine:
                                      None if chained else _ptr(dSPECIN), _ptr(LAYINC), _ptr(DTE), _ptr(DAM), _ptr(DCO),
                                      0 if inc is None else len(inc), _ptr(inc), _ptr(out))
         self._check(rc, "map2pro")
+        out.flags.writeable = False      # its device twin feeds map2xvec
         self._chain_map = _fingerprint(out)
         return out
 

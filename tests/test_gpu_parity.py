@@ -445,7 +445,9 @@ def test_gradient_maps_vs_oracle_chained_from_cirsradg(eng, oracle):
         if np.any(pro_o[:, par]):
             np.testing.assert_allclose(pro[:, par], pro_o[:, par], rtol=0, atol=1e-12 * np.max(np.abs(pro_o[:, par])))
     np.testing.assert_allclose(xv, xv_o, rtol=0, atol=1e-12 * np.max(np.abs(xv_o)))
-    # a modified copy is NOT mistaken for the device-resident array
+    # arrays with a device twin are read-only; a modified copy is NOT mistaken for the device-resident array
+    with pytest.raises(ValueError):
+        dspec[0, 0, 0, 0] = 1.0
     d2 = dspec.copy(); d2[:, 0] *= 2.0
     pro2 = eng.map2pro(d2, W, NVMR, NDUST, NPRO, 1, NLAYIN, LAYINC, DTE, DAM, DCO)
     np.testing.assert_allclose(pro2[:, 0], 2.0 * pro[:, 0], rtol=1e-12)
