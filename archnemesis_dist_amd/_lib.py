@@ -24,7 +24,7 @@ EXPORTS = [
     "ansfm_calc_k", "ansfm_k_overlap", "ansfm_thermal_emission", "ansfm_cirsrad_ck_thermal",
     "ansfm_cirsrad_ck_thermal_dev", "ansfm_get_taugas", "ansfm_last_kernel_ms",
     "ansfm_k_overlapg", "ansfm_cirsradg_ck_thermal", "ansfm_cirsradg_ck_thermal_dev", "ansfm_scloud11wave_core", "ansfm_upload_lbltable", "ansfm_calc_klbl", "ansfm_add_line_set_monochromatic_absorption", "ansfm_layer_average",
-    "ansfm_map2pro", "ansfm_map2xvec", "ansfm_layer_averageg", "ansfm_lblconv", "ansfm_lblconv_fil",
+    "ansfm_map2pro", "ansfm_map2xvec", "ansfm_layer_averageg", "ansfm_lblconv", "ansfm_lblconv_fil", "ansfm_set_layer_dedup", "ansfm_last_layer_rows",
 ]
 
 _lib = None
@@ -95,6 +95,8 @@ def load():
                                                                 vp, vp, vp, vp, vp, vp, cd, cd, cd]
     lib.ansfm_layer_average.argtypes = [vp, ci, cd, ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, vp, cd, ci, cd, ci, vp, vp] + [vp] * 11
     lib.ansfm_layer_averageg.argtypes = [vp, ci, cd, ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, vp, cd, ci, cd, ci, vp, vp] + [vp] * 15
+    lib.ansfm_set_layer_dedup.argtypes = [vp, ci]
+    lib.ansfm_last_layer_rows.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.ansfm_lblconv.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, ci, cd, vp, vp]
     lib.ansfm_lblconv_fil.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp]
     lib.ansfm_map2pro.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp]

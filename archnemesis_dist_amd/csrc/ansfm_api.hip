@@ -61,6 +61,9 @@ struct ansfm_ctx {
     // workspaces
     DevBuf li, tau, scratch, cont_t, tmp_in, tmp_out, misc;
     DevBuf dspec_ref, map_out, map_b, map_batch;
+    DevBuf dd_slot, dd_work, dd_in;      // layer de-duplication: row map [n][L], work list, packed inputs
+    int dedup = 1;                       // ansfm_set_layer_dedup
+    int last_rows = 0, last_dedup = 0;   // opacity rows computed by the last cirsrad call / whether tau_slot applies
     int dspec_dims[4] = {0, 0, 0, 0};   // W, NPAR, LIMAX, P of dspec_ref (single-model cirsradg result)
     int map_dims[4] = {0, 0, 0, 0};     // W, NPAR, NPRO, P of map_out
     DevBuf gscratch, perm, dkbuf, trold_ws, dspec_i, dcont_t, tmp_in2, tmp_out2, lbl_li;
@@ -366,11 +369,38 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
         FAIL(ANSFM_ERR_INVALID, "cirsrad: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
     const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, S = ctx->S;
-    HIPCHK(ctx->li.reserve((size_t)n_models * L * sizeof(LayerInterp)));
-    HIPCHK(ctx->tau.reserve((size_t)n_models * L * G * Wpad * sizeof(double)));
     HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_layer_prep, dim3(nblk((size_t)n_models * L, 128)), dim3(128), 0, ctx->stream,
-                       n_models * L, lay_press_pa, lay_temp, ctx->NP, ctx->d_press.as<double>(), ctx->NT,
+    // ---- which (model, layer) opacities have to be computed: all of them, or (batches) the distinct ones -------
+    int rows = n_models * L;                       // rows of the opacity buffer = layers handed to the merge kernel
+    const double *press_k = lay_press_pa, *temp_k = lay_temp, *amount_k = amount;
+    int n_k = n_models, L_k = L;                   // the merge kernel's view: n_k models of L_k layers
+    const int32_t *tau_slot = nullptr;
+    if (ctx->dedup && n_models > 1) {
+        const size_t nl = (size_t)n_models * L;
+        HIPCHK(ctx->dd_slot.reserve(nl * sizeof(int32_t)));
+        HIPCHK(ctx->dd_work.reserve(nl * sizeof(int32_t)));
+        int *counter = ctx->d_flag.as<int>() + 12;
+        HIPCHK(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_dedup_mark, dim3(nblk(nl, 128)), dim3(128), 0, ctx->stream, n_models, L, S, lay_press_pa,
+                           lay_temp, amount, ctx->dd_slot.as<int32_t>(), ctx->dd_work.as<int32_t>(), counter);
+        HIPCHK(hipGetLastError());
+        int extra = 0;
+        HIPCHK(hipMemcpyAsync(&extra, counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));         // the only synchronisation of this entry point (batches only)
+        rows = L + extra;
+        HIPCHK(ctx->dd_in.reserve((size_t)rows * (S + 2) * sizeof(double)));
+        double *pw = ctx->dd_in.as<double>(), *tw = pw + rows, *aw = tw + rows;
+        hipLaunchKernelGGL(k_dedup_gather, dim3(nblk((size_t)rows, 128)), dim3(128), 0, ctx->stream, rows, L, S,
+                           ctx->dd_work.as<int32_t>(), lay_press_pa, lay_temp, amount, pw, tw, aw);
+        HIPCHK(hipGetLastError());
+        press_k = pw; temp_k = tw; amount_k = aw; n_k = 1; L_k = rows;
+        tau_slot = ctx->dd_slot.as<int32_t>();
+    }
+    ctx->last_rows = rows; ctx->last_dedup = tau_slot != nullptr;
+    HIPCHK(ctx->li.reserve((size_t)rows * sizeof(LayerInterp)));
+    HIPCHK(ctx->tau.reserve((size_t)rows * G * Wpad * sizeof(double)));
+    hipLaunchKernelGGL(k_layer_prep, dim3(nblk((size_t)rows, 128)), dim3(128), 0, ctx->stream,
+                       rows, press_k, temp_k, ctx->NP, ctx->d_press.as<double>(), ctx->NT,
                        ctx->d_temp.as<double>(), 101325.0, ctx->grid_f32, ctx->li.as<LayerInterp>());
     HIPCHK(hipGetLastError());
     const double *cont_t = nullptr;
@@ -387,13 +417,13 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     int rc;
     if (ctx->is_lbl) {   // ILBL = LINE_BY_LINE_TABLES: tau = sum_gas k*amount (:3795-3817), NG = 1
-        if ((rc = lbl_prep_fwd(ctx, n_models * L, lay_press_pa, lay_temp, 101325.0, 0))) return rc;
-        hipLaunchKernelGGL(k_lbl_tau, dim3(nblk((size_t)n_models * L * Wpad, 256)), dim3(256), 0, ctx->stream,
-                           ctx->lnK.as<double>(), Wpad, ctx->NT, S, L, n_models, ctx->lbl_li.as<LblInterp>(), amount,
+        if ((rc = lbl_prep_fwd(ctx, rows, press_k, temp_k, 101325.0, 0))) return rc;
+        hipLaunchKernelGGL(k_lbl_tau, dim3(nblk((size_t)rows * Wpad, 256)), dim3(256), 0, ctx->stream,
+                           ctx->lnK.as<double>(), Wpad, ctx->NT, S, L_k, n_k, ctx->lbl_li.as<LblInterp>(), amount_k,
                            ctx->tau.as<double>(), (double *)nullptr);
         HIPCHK(hipGetLastError());
     } else {
-        rc = launch_overlap(ctx, false, nullptr, W, Wpad, G, S, L, n_models, ctx->li.as<LayerInterp>(), amount,
+        rc = launch_overlap(ctx, false, nullptr, W, Wpad, G, S, L_k, n_k, ctx->li.as<LayerInterp>(), amount_k,
                             ctx->d_delg.as<double>(), ctx->h_delg.data(), ctx->tau.as<double>());
         if (rc != ANSFM_OK) return rc;
     }
@@ -401,6 +431,7 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
     RtParams r;
     memset(&r, 0, sizeof r);
     r.tau = ctx->tau.as<double>();
+    r.tau_slot = tau_slot;
     r.cont = cont_t;
     r.emi = nullptr;
     r.wave = ctx->d_wave.as<double>();
@@ -419,6 +450,21 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
     ctx->rt_launches = 1;
     ctx->overlap_ms = -1.0;  // resolved lazily in ansfm_last_kernel_ms
     ctx->last_n = n_models; ctx->last_L = L;
+    return ANSFM_OK;
+}
+
+int ansfm_set_layer_dedup(ansfm_ctx *ctx, int enable)
+{
+    CHECK_CTX(ctx);
+    ctx->dedup = enable ? 1 : 0;
+    return ANSFM_OK;
+}
+
+int ansfm_last_layer_rows(const ansfm_ctx *ctx, int *rows_computed, int *rows_total)
+{
+    if (!ctx) return ANSFM_ERR_INVALID;
+    if (rows_computed) *rows_computed = ctx->last_rows;
+    if (rows_total) *rows_total = ctx->last_n * ctx->last_L;
     return ANSFM_OK;
 }
 
@@ -516,9 +562,13 @@ int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS)
     const size_t n = (size_t)W * G * L;
     HIPCHK(ctx->tmp_out.reserve(n * sizeof(double)));
     // internal [L][G][Wpad] -> reference [W][G][L]
-    hipLaunchKernelGGL(k_w_to_first, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream,
-                       ctx->tau.as<double>() + (size_t)model * L * G * Wpad, ctx->tmp_out.as<double>(), W, Wpad, L,
-                       G, 1);
+    if (ctx->last_dedup)
+        hipLaunchKernelGGL(k_taugas_from_slots, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, ctx->tau.as<double>(),
+                           ctx->dd_slot.as<int32_t>() + (size_t)model * L, ctx->tmp_out.as<double>(), W, Wpad, L, G);
+    else
+        hipLaunchKernelGGL(k_w_to_first, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream,
+                           ctx->tau.as<double>() + (size_t)model * L * G * Wpad, ctx->tmp_out.as<double>(), W, Wpad, L,
+                           G, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(TAUGAS, ctx->tmp_out.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -1028,6 +1028,55 @@ __global__ void k_dk_to_ref(const double *__restrict__ src, double *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Layer de-duplication inside a batch of atmospheric states.  The states of a numerical Jacobian differ from
+// the unperturbed one at a single profile level, i.e. in two or three layers; every other layer has bit-identical
+// (pressure, temperature, amounts) and therefore bit-identical gas opacities.  k_dedup_mark compares each layer
+// (m, l) of models m >= 1 with layer l of model 0 and hands out rows of the opacity buffer: row l for a copy,
+// a fresh row (atomic counter) otherwise.  k_dedup_gather packs the inputs of the rows that have to be computed
+// so that the merge kernel sees them as the layers of one pseudo-model; k_thermal_rt follows tau_slot.
+// Nothing is approximated: a layer is shared only when all of its S+2 inputs are equal to the last bit.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_dedup_mark(int n_models, int L, int S, const double *__restrict__ press,
+                             const double *__restrict__ temp, const double *__restrict__ amount,
+                             int32_t *__restrict__ slot, int32_t *__restrict__ work, int *__restrict__ counter)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_models * L) return;
+    const int m = i / L, l = i % L;
+    if (m == 0) { slot[i] = l; work[l] = i; return; }
+    auto bits = [](double x) { return __double_as_longlong(x); };
+    bool same = bits(press[i]) == bits(press[l]) && bits(temp[i]) == bits(temp[l]);
+    for (int s = 0; s < S && same; ++s)
+        same = bits(amount[((size_t)m * S + s) * L + l]) == bits(amount[(size_t)s * L + l]);
+    if (same) { slot[i] = l; return; }
+    const int w = L + atomicAdd(counter, 1);
+    slot[i] = w;
+    work[w] = i;                                  // (m, l) flattened
+}
+
+__global__ void k_dedup_gather(int nwork, int L, int S, const int32_t *__restrict__ work, const double *__restrict__ press,
+                               const double *__restrict__ temp, const double *__restrict__ amount,
+                               double *__restrict__ press_w, double *__restrict__ temp_w, double *__restrict__ amount_w)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwork) return;
+    const int i = work[w], m = i / L, l = i % L;
+    press_w[w] = press[i];
+    temp_w[w] = temp[i];
+    for (int s = 0; s < S; ++s) amount_w[(size_t)s * nwork + w] = amount[((size_t)m * S + s) * L + l];
+}
+
+// [rows][G][Wpad] addressed through slot[L] -> reference TAUGAS[W][G][L]
+__global__ void k_taugas_from_slots(const double *__restrict__ src, const int32_t *__restrict__ slot, double *__restrict__ dst,
+                                    int W, int Wpad, int L, int G)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)W * G * L) return;
+    const int l = (int)(idx % L), g = (int)((idx / L) % G), w = (int)(idx / ((size_t)L * G));
+    dst[idx] = src[((size_t)slot[l] * G + g) * Wpad + w];
+}
+
+// ------------------------------------------------------------------------------------------------
 // K11: LBL-table mode (ILBL = LINE_BY_LINE_TABLES): Spectroscopy_0.calc_klbl :1768-1919 /
 // calc_klblg :1601-1765 and the gas sum of calculate_gaseous_line_opacity (:3795-3817).
 // The table is stored like the k-table with G = 1: lnK[NP][NTa][S][1][Wpad].
@@ -1180,7 +1229,8 @@ constexpr int kGY = 4;
 constexpr int kGPer = kMaxG / kGY;  // 8
 
 struct RtParams {
-    const double *tau;      // [n][L][G][Wpad]
+    const double *tau;      // [n][L][G][Wpad], or [unique layers][G][Wpad] addressed through tau_slot
+    const int32_t *tau_slot;// [n][L] row of tau holding layer (m, l), or nullptr (identity)
     const double *cont;     // [n][L][Wpad] or nullptr
     const double *emi;      // [Li][Wpad] or nullptr  (array-level seam only)
     const double *wave;     // [W]
@@ -1230,7 +1280,8 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
         const double tc = p.cont ? p.cont[((size_t)m * p.L + lay) * p.Wpad + nu] : 0.0;
         const double bb = planck_bb(a, c2y, T);
         const double em = p.emi ? p.emi[(size_t)j * p.Wpad + nu] : 0.0;
-        const double *trow = p.tau + (((size_t)m * p.L + lay) * G) * p.Wpad + nu;
+        const size_t trow_i = p.tau_slot ? (size_t)p.tau_slot[(size_t)m * p.L + lay] : (size_t)m * p.L + lay;
+        const double *trow = p.tau + (trow_i * G) * p.Wpad + nu;
 #pragma unroll
         for (int k = 0; k < kGPer; ++k) {
             const int g = gy + k * kGY;

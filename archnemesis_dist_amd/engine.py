@@ -404,6 +404,16 @@ class AnsfmEngine:
         self._check(self._lib.ansfm_get_taugas(self._ctx, int(model), _ptr(out)), "get_taugas")
         return out
 
+    def set_layer_dedup(self, enable=True):
+        """Share the gas opacity of layers that are bit-identical to the first model's inside a batched call."""
+        self._check(self._lib.ansfm_set_layer_dedup(self._ctx, int(bool(enable))), "set_layer_dedup")
+
+    def last_layer_rows(self):
+        """(layer opacities computed, n_models * L) of the last cirsrad_ck_thermal call."""
+        a = C.c_int(); b = C.c_int()
+        self._check(self._lib.ansfm_last_layer_rows(self._ctx, C.byref(a), C.byref(b)), "last_layer_rows")
+        return a.value, b.value
+
     def last_kernel_ms(self):
         a = C.c_double(); b = C.c_double(); na = C.c_int(); nb = C.c_int()
         self._check(self._lib.ansfm_last_kernel_ms(self._ctx, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)),

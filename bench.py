@@ -156,31 +156,51 @@ def main():
     value = world * args.steps / elapsed
 
     # ---- numerical Jacobian (C3): nj forward models sharded over ranks + one gather ---------------
+    # Every perturbed state differs from the base state in one layer element (jacobian_nemesis perturbs one state-vector
+    # element per forward model, :2234-2242).  Measured twice on the same states: every layer of every model merged
+    # (`wall_s_all_layers`), and with the engine's layer de-duplication (`wall_s`: layers bit-identical to the first
+    # model of the batch share its opacity rows; same spectra to the last bit, checked below).
     jac = None
     if not args.no_jacobian:
         s, e = chunk_range(nj, world, rank)
         nloc = e - s
         sub = 16
-        d_cont_b = d_cont1.expand(sub, W, L).contiguous()   # continuum is per-model in the ABI
+        d_cont_b = d_cont1.expand(nloc, W, L).contiguous()  # continuum is per-model in the ABI
         out_b = torch.empty((nloc, W, P), dtype=f8, device=dev)
-        barrier()
-        t0 = time.perf_counter()
-        for b0 in range(s, e, sub):
-            b1 = min(e, b0 + sub)
-            nb = b1 - b0
-            eng.cirsrad_ck_thermal_dev(0, nb, L, d_lp[b0:b1], d_lt[b0:b1], d_am[b0:b1],
-                                       d_cont_b[:nb], P, L, d_nlayin, d_layinc,
-                                       d_scale[b0:b1], d_emtemp[b0:b1], d_tsurf[b0:b1], None, None, None, None, None,
-                                       None, out_b[b0 - s:b1 - s])
-        spectra = gather_columns(out_b.reshape(nloc, W * P), nj, rank, world, force=use_dist)
-        barrier()
-        jt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([jt], dtype=f8, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            jt = float(t.item())
-        assert spectra.shape == (nj, W * P)
-        jac = {"forward_models": nj, "wall_s": jt, "fm_per_s": nj / jt, "collective": "all_gather_into_tensor (RCCL)" if use_dist else None}
+        out_d = torch.empty((nloc, W, P), dtype=f8, device=dev)
+
+        def run_jac(dedup, out):
+            eng.set_layer_dedup(dedup)
+            step_models = nloc if dedup else sub
+            rows = 0
+            barrier()
+            t0 = time.perf_counter()
+            for b0 in range(s, e, step_models):
+                b1 = min(e, b0 + step_models)
+                nb = b1 - b0
+                eng.cirsrad_ck_thermal_dev(0, nb, L, d_lp[b0:b1], d_lt[b0:b1], d_am[b0:b1],
+                                           d_cont_b[:nb], P, L, d_nlayin, d_layinc,
+                                           d_scale[b0:b1], d_emtemp[b0:b1], d_tsurf[b0:b1], None, None, None, None, None,
+                                           None, out[b0 - s:b1 - s])
+                rows += eng.last_layer_rows()[0]
+            spectra = gather_columns(out.reshape(nloc, W * P), nj, rank, world, force=use_dist)
+            barrier()
+            jt = time.perf_counter() - t0
+            if use_dist:
+                t = torch.tensor([jt], dtype=f8, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                jt = float(t.item())
+            assert spectra.shape == (nj, W * P)
+            return jt, rows
+
+        jt_all, rows_all = run_jac(False, out_b)
+        jt, rows = run_jac(True, out_d)
+        same = bool(torch.equal(out_b, out_d))
+        eng.set_layer_dedup(True)
+        jac = {"forward_models": nj, "wall_s": jt, "fm_per_s": nj / jt, "wall_s_all_layers": jt_all,
+               "layer_opacities_computed_rank0": rows, "layer_opacities_all_rank0": rows_all,
+               "dedup_bit_identical": same,
+               "collective": "all_gather_into_tensor (RCCL)" if use_dist else None}
 
     if rank != 0:
         if use_dist:

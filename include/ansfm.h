@@ -271,6 +271,15 @@ int ansfm_lblconv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const doub
                       const double *dydx, int nconv, const double *vconv, int nfilmax, const int32_t *nfil,
                       const double *vfil, const double *afil, double *yout, double *gradout);
 
+/* Layer de-duplication inside a batch (n_models > 1) of the cirsrad_ck_thermal entry points.  The states of a
+ * numerical Jacobian (ForwardModel_0.jacobian_nemesis :2234-2242) differ from the unperturbed one in two or three
+ * layers; every layer (m, l) whose pressure, temperature and S amounts equal those of layer l of model 0 to the last
+ * bit shares its gas opacity with it instead of being merged again.  Results are bit-identical with and without;
+ * on by default; costs one stream synchronisation per batched call.  ansfm_last_layer_rows reports how many layer
+ * opacities the last call computed out of n_models * L. */
+int ansfm_set_layer_dedup(ansfm_ctx *ctx, int enable);
+int ansfm_last_layer_rows(const ansfm_ctx *ctx, int *rows_computed, int *rows_total);
+
 /* Vertical gas opacity of the last cirsrad call's first model, TAUGAS[W][G][L]
  * (what CIRSrad leaves in LayerX.TAUGAS, ForwardModel_0.py:3925) -- host pointer out. */
 int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS);

@@ -522,3 +522,36 @@ def test_lblconv_fil_golden_and_large_vs_oracle(eng, oracle, golden_dir):
         np.testing.assert_allclose(go, gr, rtol=0, atol=1e-12 * np.max(np.abs(gr)))
     with pytest.raises(ValueError):
         eng.lblconv(nw, vw[::-1].copy(), y, nc, vc, 1, 0.4)
+
+
+def test_batch_layer_dedup_is_bit_identical(eng):
+    """A numerical-Jacobian batch (every state differs from the first in two layers): layers identical to the first
+    model's share its opacity rows -- same spectra and TAUGAS to the last bit, far fewer rows computed."""
+    from archnemesis_dist_amd import synthetic as syn
+    W, G, S, L, NP, NT = 260, 10, 4, 30, 8, 6
+    _, delg = syn.gauss_legendre_01(G, True)
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S, seed=21)
+    eng.upload_ktable(K, PRESS, TEMP, 150.0 + np.arange(W), delg)
+    base = syn.synth_atmosphere(L, S)
+    n = 2 * L + 1
+    lp = np.repeat(base["lay_press_pa"], n, 0); lt = np.repeat(base["lay_temp"], n, 0); am = np.repeat(base["amount"], n, 0)
+    for i in range(L):                            # temperature of layer i (and the density of its neighbour)
+        lt[1 + i, i] *= 1.01
+        am[1 + i, :, min(i + 1, L - 1)] *= 0.995
+        am[1 + L + i, 1, i] *= 1.05               # amount of gas 1 in layer i
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L)
+    EMTEMP = lt[:, LAYINC[:, 0]][:, :, None]
+    cont = np.repeat(syn.synth_continuum(W, L), n, 0)
+    args = (0, lp, lt, am, cont, NLAYIN, LAYINC, np.repeat(SCALE[None], n, 0), EMTEMP, np.full(n, -1.0))
+    eng.set_layer_dedup(True)
+    a = eng.cirsrad_ck_thermal(*args)
+    rows, total = eng.last_layer_rows()
+    tg_a = eng.get_taugas(L, model=7)
+    eng.set_layer_dedup(False)
+    b = eng.cirsrad_ck_thermal(*args)
+    rows_b, _ = eng.last_layer_rows()
+    tg_b = eng.get_taugas(L, model=7)
+    eng.set_layer_dedup(True)
+    assert total == n * L and rows_b == total and rows <= L + 3 * L + 2 and rows < total // 5
+    assert np.array_equal(a, b) and np.array_equal(tg_a, tg_b)
+    assert not np.array_equal(a[0], a[3])
