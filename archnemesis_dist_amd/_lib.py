@@ -25,6 +25,7 @@ EXPORTS = [
     "ansfm_cirsrad_ck_thermal_dev", "ansfm_get_taugas", "ansfm_last_kernel_ms",
     "ansfm_k_overlapg", "ansfm_cirsradg_ck_thermal", "ansfm_cirsradg_ck_thermal_dev", "ansfm_scloud11wave_core", "ansfm_upload_lbltable", "ansfm_calc_klbl", "ansfm_add_line_set_monochromatic_absorption", "ansfm_layer_average",
     "ansfm_map2pro", "ansfm_map2xvec", "ansfm_layer_averageg", "ansfm_lblconv", "ansfm_lblconv_fil", "ansfm_set_layer_dedup", "ansfm_last_layer_rows",
+    "ansfm_ktable_file_header", "ansfm_upload_ktable_files", "ansfm_ktable_grids",
 ]
 
 _lib = None
@@ -95,6 +96,9 @@ def load():
                                                                 vp, vp, vp, vp, vp, vp, cd, cd, cd]
     lib.ansfm_layer_average.argtypes = [vp, ci, cd, ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, vp, cd, ci, cd, ci, vp, vp] + [vp] * 11
     lib.ansfm_layer_averageg.argtypes = [vp, ci, cd, ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, vp, cd, ci, cd, ci, vp, vp] + [vp] * 15
+    lib.ansfm_ktable_file_header.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ansfm_upload_ktable_files.argtypes = [vp, ci, C.POINTER(C.c_char_p), cd, cd]
+    lib.ansfm_ktable_grids.argtypes = [vp, vp, vp, vp, vp]
     lib.ansfm_set_layer_dedup.argtypes = [vp, ci]
     lib.ansfm_last_layer_rows.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.ansfm_lblconv.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, ci, cd, vp, vp]
@@ -112,3 +116,19 @@ def load():
             fn.restype = ci
     _lib = lib
     return lib
+
+
+def read_ktable_header(path):
+    """Spectroscopy_0.read_ktahead (:2492) through the native reader (no GPU needed):
+    nwave, wave, fwhm, npress, ntemp, ng, gasID, isoID, g_ord, del_g, presslevels, templevels."""
+    import numpy as np
+    lib = load()
+    dims = (C.c_int64 * 4)(); ids = (C.c_int32 * 2)(); hdr = (C.c_double * 3)()
+    if lib.ansfm_ktable_file_header(os.fsencode(path), dims, ids, hdr, None, None, None, None, None) != ANSFM_OK:
+        raise ValueError("not a readable .kta table: %s" % path)
+    nwave, ng, npress, ntemp = (int(d) for d in dims)
+    wave = np.empty(nwave); g_ord = np.empty(ng, np.float32); del_g = np.empty(ng, np.float32)
+    press = np.empty(npress, np.float32); temp = np.empty(ntemp, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.ansfm_ktable_file_header(os.fsencode(path), dims, ids, hdr, p(wave), p(g_ord), p(del_g), p(press), p(temp))
+    return nwave, wave, float(hdr[2]), npress, ntemp, ng, int(ids[0]), int(ids[1]), g_ord, del_g, press, temp

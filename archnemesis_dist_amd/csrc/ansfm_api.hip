@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,7 @@ struct ansfm_ctx {
     // k-table
     int W = 0, Wpad = 0, G = 0, NP = 0, NT = 0, S = 0;
     int monotone = 0;
+    std::vector<double> h_wave, h_press, h_temp;   // host copies of the grids of the table in HBM
     int force_generic = 0;   // rerun of a call whose k-distributions turned out not to be sorted in g
     bool have_table = false;
     int grid_f32 = 0, delg_f32 = 0;
@@ -212,6 +214,7 @@ int ansfm_upload_ktable_dev(ansfm_ctx *ctx, int W, int G, int NP, int NT, int S,
     ctx->W = W; ctx->Wpad = Wpad; ctx->G = G; ctx->NP = NP; ctx->NT = NT; ctx->S = S;
     ctx->monotone = (flag & 1) ? 0 : 1;
     ctx->h_delg.assign(DELG, DELG + G);
+    ctx->h_wave.assign(WAVE, WAVE + W); ctx->h_press.assign(PRESS, PRESS + NP); ctx->h_temp.assign(TEMP, TEMP + NT);
     ctx->have_table = true;
     ctx->is_lbl = 0; ctx->temp2d = 0;
     return ANSFM_OK;
@@ -229,6 +232,163 @@ int ansfm_upload_ktable(ansfm_ctx *ctx, int W, int G, int NP, int NT, int S, con
     int rc = ansfm_upload_ktable_dev(ctx, W, G, NP, NT, S, ctx->tmp_in.as<double>(), PRESS, TEMP, WAVE, DELG);
     ctx->tmp_in.release();  // the reference-layout copy is only needed during the re-layout
     return rc;
+}
+
+/* ---- native .kta reader (Spectroscopy_0.read_ktahead :2492, read_ktable :2733, read_tables :1448) ---------- */
+namespace {
+struct KtaHeader {
+    int irec0 = 0, nwave = 0, npress = 0, ntemp = 0, ng = 0, gasID = 0, isoID = 0;
+    double vmin = 0, delv = 0, fwhm = 0;
+    std::vector<float> g_ord, del_g, press, temp;
+    std::vector<double> wave;
+};
+
+static double round7(double x) { return std::nearbyint(x * 1e7) / 1e7; }   // np.round(x, decimals=7)
+
+static bool kta_read_header(const char *path, KtaHeader &h, std::string &err)
+{
+    std::string fn(path);
+    if (fn.size() < 4 || fn.compare(fn.size() - 4, 4, ".kta") != 0) fn += ".kta";
+    FILE *f = fopen(fn.c_str(), "rb");
+    if (!f) { err = "cannot open " + fn; return false; }
+    auto rd = [&](void *dst, size_t sz, size_t n) { return fread(dst, sz, n, f) == n; };
+    int32_t i4[2]; float f3[3]; int32_t j5[5];
+    bool ok = rd(i4, 4, 2) && rd(f3, 4, 3) && rd(j5, 4, 5);
+    if (ok) {
+        h.irec0 = i4[0]; h.nwave = i4[1];
+        h.vmin = round7((double)f3[0]); h.delv = round7((double)f3[1]); h.fwhm = (double)f3[2];
+        h.npress = j5[0]; h.ntemp = j5[1]; h.ng = j5[2]; h.gasID = j5[3]; h.isoID = j5[4];
+        ok = h.nwave > 0 && h.npress > 0 && h.ntemp > 0 && h.ng > 0 && h.ng <= 1024 && h.irec0 > 0;
+        if (!ok) err = "not a k-table header (or NT < 0, a per-pressure temperature grid: .lta only): " + fn;
+    } else
+        err = "truncated header: " + fn;
+    if (ok) {
+        float pad[2];
+        h.g_ord.resize(h.ng); h.del_g.resize(h.ng); h.press.resize(h.npress); h.temp.resize(h.ntemp);
+        ok = rd(h.g_ord.data(), 4, h.ng) && rd(h.del_g.data(), 4, h.ng) && rd(pad, 4, 2) && rd(h.press.data(), 4, h.npress) &&
+             rd(h.temp.data(), 4, h.ntemp);
+        h.wave.resize(h.nwave);
+        if (ok && h.delv > 0.0) {                                   // np.linspace(vmin, vmax, nwave)
+            const double vmax = h.delv * (h.nwave - 1) + h.vmin;
+            const double step = h.nwave > 1 ? (vmax - h.vmin) / (h.nwave - 1) : 0.0;
+            for (int i = 0; i < h.nwave; ++i) h.wave[i] = i * step + h.vmin;
+            if (h.nwave > 1) h.wave[h.nwave - 1] = vmax;
+        } else if (ok) {
+            std::vector<float> wv(h.nwave);
+            ok = rd(wv.data(), 4, h.nwave);
+            for (int i = 0; i < h.nwave; ++i) h.wave[i] = (double)wv[i];
+        }
+        if (!ok) err = "truncated header arrays: " + fn;
+    }
+    fclose(f);
+    return ok;
+}
+}  // namespace
+
+int ansfm_ktable_file_header(const char *path, int64_t dims[4], int32_t ids[2], double hdr[3], double *wave, float *g_ord,
+                             float *del_g, float *press, float *temp)
+{
+    if (!path) return ANSFM_ERR_INVALID;
+    KtaHeader h; std::string err;
+    if (!kta_read_header(path, h, err)) return ANSFM_ERR_INVALID;
+    if (dims) { dims[0] = h.nwave; dims[1] = h.ng; dims[2] = h.npress; dims[3] = h.ntemp; }
+    if (ids) { ids[0] = h.gasID; ids[1] = h.isoID; }
+    if (hdr) { hdr[0] = h.vmin; hdr[1] = h.delv; hdr[2] = h.fwhm; }
+    if (wave) memcpy(wave, h.wave.data(), h.wave.size() * sizeof(double));
+    if (g_ord) memcpy(g_ord, h.g_ord.data(), h.ng * sizeof(float));
+    if (del_g) memcpy(del_g, h.del_g.data(), h.ng * sizeof(float));
+    if (press) memcpy(press, h.press.data(), h.npress * sizeof(float));
+    if (temp) memcpy(temp, h.temp.data(), h.ntemp * sizeof(float));
+    return ANSFM_OK;
+}
+
+int ansfm_upload_ktable_files(ansfm_ctx *ctx, int S, const char *const *paths, double wavemin, double wavemax)
+{
+    CHECK_CTX(ctx);
+    if (S <= 0 || !paths) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<KtaHeader> hs(S);
+    for (int s = 0; s < S; ++s) {
+        std::string err;
+        if (!paths[s] || !kta_read_header(paths[s], hs[s], err)) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: " + err);
+        if (hs[s].nwave != hs[0].nwave) FAIL(ANSFM_ERR_INVALID, "error :: Number of wavenumbers in all .kta files must be the same");
+        if (hs[s].npress != hs[0].npress) FAIL(ANSFM_ERR_INVALID, "error :: Number of pressure levels in all .kta files must be the same");
+        if (hs[s].ntemp != hs[0].ntemp) FAIL(ANSFM_ERR_INVALID, "error :: Number of temperature levels in all .kta files must be the same");
+        if (hs[s].ng != hs[0].ng) FAIL(ANSFM_ERR_INVALID, "error :: Number of g-ordinates in all .kta files must be the same");
+    }
+    // read_header keeps the grids of the LAST table (:1311-1334); read_tables then cuts WAVE to [wavemin, wavemax]
+    // with searchsorted (:1486-1494) and every gas is read over [WAVE.min(), WAVE.max()] of that cut (:1502)
+    const KtaHeader &hl = hs[S - 1];
+    const int G = hl.ng, NP = hl.npress, NT = hl.ntemp;
+    if (G > ANSFM_MAX_NG || NP < 2 || NT < 2) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: need 1<=G<=32, NP>=2, NT>=2");
+    const std::vector<double> &wv = hl.wave;
+    long iwl = (long)(std::upper_bound(wv.begin(), wv.end(), wavemin) - wv.begin()) - 1;
+    if (iwl < 0) iwl = 0;
+    long iwh = (long)(std::lower_bound(wv.begin(), wv.end(), wavemax) - wv.begin());
+    if (iwh >= (long)wv.size()) iwh = (long)wv.size() - 1;
+    if (iwh < iwl) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: empty wavenumber range");
+    const double wlo = wv[iwl], whi = wv[iwh];
+    const int W = (int)(iwh - iwl + 1);
+    std::vector<double> WAVE(wv.begin() + iwl, wv.begin() + iwh + 1), PRESS(hl.press.begin(), hl.press.end()),
+        TEMP(hl.temp.begin(), hl.temp.end()), DELG(hl.del_g.begin(), hl.del_g.end());
+    const int Wpad = round_up(W, kWave);
+    const size_t total = (size_t)NP * NT * S * G * Wpad;
+    HIPCHK(ctx->lnK.reserve(total * sizeof(double)));
+    HIPCHK(ctx->d_press.reserve(NP * sizeof(double)));
+    HIPCHK(ctx->d_temp.reserve(NT * sizeof(double)));
+    HIPCHK(ctx->d_wave.reserve((size_t)W * sizeof(double)));
+    HIPCHK(ctx->d_delg.reserve(kMaxG * sizeof(double)));
+    HIPCHK(ctx->d_flag.reserve(16 * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(ctx->d_press.p, PRESS.data(), NP * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_temp.p, TEMP.data(), NT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_wave.p, WAVE.data(), (size_t)W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_delg.p, DELG.data(), G * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_flag.p, 0, 16 * sizeof(int), ctx->stream));
+    const size_t per_wave = (size_t)NP * NT * G;
+    std::vector<float> block(per_wave * W);
+    HIPCHK(ctx->tmp_in.reserve(block.size() * sizeof(float)));
+    for (int s = 0; s < S; ++s) {
+        // the wavenumbers of THIS file inside [wlo, whi] (read_ktable :2818-2821) must be the same W points
+        const std::vector<double> &ws = hs[s].wave;
+        const long a = (long)(std::lower_bound(ws.begin(), ws.end(), wlo) - ws.begin());
+        const long b = (long)(std::upper_bound(ws.begin(), ws.end(), whi) - ws.begin());
+        if (b - a != W) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: the tables do not share one wavenumber grid");
+        std::string fn(paths[s]);
+        if (fn.size() < 4 || fn.compare(fn.size() - 4, 4, ".kta") != 0) fn += ".kta";
+        FILE *f = fopen(fn.c_str(), "rb");
+        if (!f) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: cannot open " + fn);
+        const long long off = ((long long)per_wave * a + (hs[s].irec0 - 1)) * 4;     // :2836-2838
+        const bool ok = fseeko(f, (off_t)off, SEEK_SET) == 0 && fread(block.data(), 4, block.size(), f) == block.size();
+        fclose(f);
+        if (!ok) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: truncated k data in " + fn);
+        HIPCHK(hipMemcpyAsync(ctx->tmp_in.p, block.data(), block.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_kta_relayout, dim3(nblk(per_wave * Wpad, 256)), dim3(256), 0, ctx->stream, ctx->tmp_in.as<float>(),
+                           ctx->lnK.as<double>(), W, Wpad, G, NP, NT, S, s, ctx->d_flag.as<int>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));                 // `block` is reused for the next gas
+    }
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, ctx->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->tmp_in.release();
+    ctx->W = W; ctx->Wpad = Wpad; ctx->G = G; ctx->NP = NP; ctx->NT = NT; ctx->S = S;
+    ctx->monotone = (flag & 1) ? 0 : 1;
+    ctx->h_delg = DELG; ctx->h_wave = WAVE; ctx->h_press = PRESS; ctx->h_temp = TEMP;
+    ctx->have_table = true;
+    ctx->is_lbl = 0; ctx->temp2d = 0;
+    ctx->grid_f32 = 1; ctx->delg_f32 = 1;      // PRESS / TEMP / DELG come out of the file as float32 arrays (:2544-2559)
+    return ANSFM_OK;
+}
+
+int ansfm_ktable_grids(const ansfm_ctx *ctx, double *WAVE, double *PRESS, double *TEMP, double *DELG)
+{
+    if (!ctx) return ANSFM_ERR_INVALID;
+    if (!ctx->have_table) return ANSFM_ERR_NOTABLE;
+    if (WAVE) memcpy(WAVE, ctx->h_wave.data(), ctx->h_wave.size() * sizeof(double));
+    if (PRESS) memcpy(PRESS, ctx->h_press.data(), ctx->h_press.size() * sizeof(double));
+    if (TEMP) memcpy(TEMP, ctx->h_temp.data(), ctx->h_temp.size() * sizeof(double));
+    if (DELG) memcpy(DELG, ctx->h_delg.data(), ctx->h_delg.size() * sizeof(double));
+    return ANSFM_OK;
 }
 
 int ansfm_ktable_info(const ansfm_ctx *ctx, int64_t dims[5], int *monotone)

@@ -1028,6 +1028,34 @@ __global__ void k_dk_to_ref(const double *__restrict__ src, double *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// .kta file block -> lnK.  The file stores k * 1e20 as float32 in the order [wave][press][temp][g] (Spectroscopy_0
+// .read_ktable :2829-2850); the reader divides the float32 array by the Python float 1e20, which NumPy does in float32.
+// One gas per launch: kf = the selected wavenumbers' block, as read.  Pad lanes (w >= W) get k = 0.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_kta_relayout(const float *__restrict__ kf, double *__restrict__ lnK, int W, int Wpad, int G, int NP,
+                               int NT, int S, int s, int *flag)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)NP * NT * G * Wpad;
+    if (idx >= total) return;
+    const int w = (int)(idx % Wpad);
+    size_t r = idx / Wpad;
+    const int g = (int)(r % G); r /= G;
+    const int t = (int)(r % NT);
+    const int p = (int)(r / NT);
+    double k = 0.0;
+    if (w < W) {
+        const size_t src = (((size_t)w * NP + p) * NT + t) * G + g;
+        const float q = kf[src] / 1.0e20f;
+        k = (double)q;
+        bool bad = !(k >= 0.0);
+        if (g > 0 && q < kf[src - 1] / 1.0e20f) bad = true;
+        if (bad) atomicOr(flag, 1);
+    }
+    lnK[((((size_t)p * NT + t) * S + s) * G + g) * Wpad + w] = encode_lnk(k);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Layer de-duplication inside a batch of atmospheric states.  The states of a numerical Jacobian differ from
 // the unperturbed one at a single profile level, i.e. in two or three layers; every other layer has bit-identical
 // (pressure, temperature, amounts) and therefore bit-identical gas opacities.  k_dedup_mark compares each layer

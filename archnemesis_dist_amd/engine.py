@@ -5,6 +5,7 @@ seams); `*_dev` methods take torch CUDA(HIP) tensors already resident in HBM and
 asynchronously on the engine's stream.  torch is plumbing only (device memory, streams).
 """
 import ctypes as C
+import os
 import numpy as np
 
 from . import _lib
@@ -100,6 +101,19 @@ class AnsfmEngine:
         self._check(rc, "upload_ktable")
         self.dims = (W, G, NP, NT, S)
         self.WAVE, self.DELG = WAVE, DELG
+
+    def upload_ktable_files(self, paths, wavemin=0.0, wavemax=1.0e10):
+        """Spectroscopy_0.read_tables (:1448) for binary .kta tables, straight from the files into HBM (the float64 K
+        array is never built on the host).  Returns WAVE, PRESS, TEMP, DELG of the uploaded table."""
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        rc = self._lib.ansfm_upload_ktable_files(self._ctx, len(paths), arr, float(wavemin), float(wavemax))
+        self._check(rc, "upload_ktable_files")
+        self.dims, _ = self.ktable_info()
+        self.grid_f32 = True
+        W, G, NP, NT, S = self.dims
+        WAVE, PRESS, TEMP, DELG = np.empty(W), np.empty(NP), np.empty(NT), np.empty(G)
+        self._check(self._lib.ansfm_ktable_grids(self._ctx, _ptr(WAVE), _ptr(PRESS), _ptr(TEMP), _ptr(DELG)), "ktable_grids")
+        return WAVE, PRESS.astype(np.float32), TEMP.astype(np.float32), DELG.astype(np.float32)
 
     def upload_lbltable(self, K, PRESS, TEMP, WAVE):
         """LBL table (ILBL = 2): K (W,NP,|NT|,S) float64 host array; TEMP (|NT|,) or (NP,|NT|) (NT < 0 form)."""

@@ -88,6 +88,23 @@ int ansfm_upload_lbltable(ansfm_ctx *ctx, int W, int NP, int NT, int S, const do
 int ansfm_calc_klbl(ansfm_ctx *ctx, int L, const double *press, const double *temp, double *k_out,
                     double *dkdT_out);
 
+/* ---- native .kta reader ------------------------------------------------------------------
+ * Spectroscopy_0.read_ktahead (Spectroscopy_0.py:2492) / read_ktable (:2733) / read_tables (:1448) for binary
+ * k-tables: header irec0, nwave, vmin, delv, fwhm, npress, ntemp, ng, gasID, isoID (vmin / delv rounded to 7 decimals
+ * like the reference), g_ord, del_g, two pad floats, P, T, the wavenumber list when delv <= 0, then k * 1e20 as
+ * float32 [wave][press][temp][g] from record irec0.
+ * ansfm_ktable_file_header needs no GPU: dims = {nwave, ng, npress, ntemp}, ids = {gasID, isoID},
+ * hdr = {vmin, delv, fwhm}; the array outputs may be NULL.
+ * ansfm_upload_ktable_files reads S tables that share one grid, cuts the wavenumbers to [wavemin, wavemax] with
+ * read_tables' searchsorted rule, and streams each file's float32 block to the GPU where it is divided by 1e20 in
+ * float32 (as NumPy does) and re-laid out -- the float64 K (NWAVE,NG,NP,NT,NGAS) array of the reference is never
+ * formed on the host.  Sets the float32 semantics of ansfm_set_f32_semantics (the file's grids are float32 arrays in
+ * the reference).  ansfm_ktable_grids returns the host copies of WAVE / PRESS / TEMP / DELG of the table in HBM. */
+int ansfm_ktable_file_header(const char *path, int64_t dims[4], int32_t ids[2], double hdr[3], double *wave,
+                             float *g_ord, float *del_g, float *press, float *temp);
+int ansfm_upload_ktable_files(ansfm_ctx *ctx, int S, const char *const *paths, double wavemin, double wavemax);
+int ansfm_ktable_grids(const ansfm_ctx *ctx, double *WAVE, double *PRESS, double *TEMP, double *DELG);
+
 /* ---- array-level seams (host pointers), one per numba/NumPy kernel of the reference ------- */
 
 /* Spectroscopy_0.calc_k (Spectroscopy_0.py:2298) / calc_kg (:2147), WAVECALC=None.
