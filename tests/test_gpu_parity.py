@@ -555,3 +555,28 @@ def test_batch_layer_dedup_is_bit_identical(eng):
     assert total == n * L and rows_b == total and rows <= L + 3 * L + 2 and rows < total // 5
     assert np.array_equal(a, b) and np.array_equal(tg_a, tg_b)
     assert not np.array_equal(a[0], a[3])
+
+
+@pytest.mark.parametrize("W,G,S,L", [(1, 1, 1, 1), (3, 1, 3, 2), (63, 2, 2, 3), (65, 3, 4, 2), (130, 32, 3, 2), (5, 31, 2, 1),
+                                       (64, 17, 5, 1)])
+def test_k_overlap_edge_sizes_vs_oracle(eng, oracle, W, G, S, L):
+    """Smallest / largest g-ordinate counts, single gas, single layer, wavenumber counts around the 64-lane tile."""
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(W * 1000 + G * 10 + S)
+    _, delg = syn.gauss_legendre_01(G, False)
+    k = np.sort(10.0 ** rng.uniform(-25, -20, (W, G, L, S)), axis=1)
+    k[rng.uniform(size=(W, 1, L, S)).repeat(G, 1) < 0.15] = 0.0                # whole (cell, gas) columns empty
+    amount = 10.0 ** rng.uniform(19, 22, (S, L))
+    tau = eng.k_overlap(delg, k, amount)
+    ref = oracle.k_overlap(delg, k, amount)
+    np.testing.assert_allclose(tau, ref, rtol=1e-11, atol=0)
+    dkdT = k * rng.uniform(-0.01, 0.01, k.shape)
+    tg, dk = eng.k_overlapg(delg, k, dkdT, amount)
+    rg, rdk = oracle.k_overlapg(delg, k, dkdT, amount)
+    np.testing.assert_allclose(tg, rg, rtol=1e-11, atol=0)
+    # G = 1 makes rankg divide 0 by 0 in the reference (restated by the oracle): the NaNs must be the same ones
+    assert np.array_equal(np.isnan(dk), np.isnan(rdk))
+    ok = ~np.isnan(rdk)
+    if ok.any():
+        scale = np.max(np.abs(np.where(ok, rdk, 0.0)), axis=(0, 1), keepdims=True) + 1e-300
+        assert np.max(np.where(ok, np.abs(dk - rdk) / scale, 0.0)) < 1e-9
