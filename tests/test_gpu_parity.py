@@ -580,3 +580,74 @@ def test_k_overlap_edge_sizes_vs_oracle(eng, oracle, W, G, S, L):
     if ok.any():
         scale = np.max(np.abs(np.where(ok, rdk, 0.0)), axis=(0, 1), keepdims=True) + 1e-300
         assert np.max(np.where(ok, np.abs(dk - rdk) / scale, 0.0)) < 1e-9
+
+
+@pytest.mark.parametrize("ispace", [0, 1])
+def test_cirsrad_multi_path_ragged_vs_oracle(eng, oracle, ispace):
+    """Three paths of different length in one call (nadir top->bottom, a short one, a limb-like down-and-up path with
+    repeated layers), surface + solar-reflection terms, wavenumber and wavelength units, two models."""
+    from archnemesis_dist_amd import synthetic as syn
+    W, G, S, L, NP, NT = 150, 10, 3, 14, 7, 6
+    _, delg = syn.gauss_legendre_01(G, True)
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S, seed=31)
+    WAVE = (400.0 + 2.0 * np.arange(W)) if ispace == 0 else np.linspace(5.0, 25.0, W)
+    eng.upload_ktable(K, PRESS, TEMP, WAVE, delg)
+    n = 2
+    atm = syn.synth_atmosphere(L, S, seed=4, n_models=n, perturb=0.03)
+    P = 3
+    LIMAX = 2 * 6
+    LAYINC = np.zeros((LIMAX, P), dtype=np.int32)
+    NLAYIN = np.array([L if L <= LIMAX else LIMAX, 5, 12], dtype=np.int32)
+    LAYINC[:NLAYIN[0], 0] = np.arange(L - 1, -1, -1)[:NLAYIN[0]]                # top -> bottom
+    LAYINC[:5, 1] = np.arange(L - 1, L - 6, -1)
+    LAYINC[:12, 2] = np.concatenate([np.arange(L - 1, L - 7, -1), np.arange(L - 6, L)])   # down, then up again
+    rng = np.random.default_rng(12)
+    SCALE = rng.uniform(1.0, 3.0, (n, LIMAX, P))
+    EMTEMP = np.stack([atm["lay_temp"][m][LAYINC] for m in range(n)])            # (n, LIMAX, P)
+    cont = syn.synth_continuum(W, L, n_models=n)
+    TSURF = np.array([250.0, -1.0])
+    EMIS = np.linspace(0.8, 1.0, W); SOLF = 10.0 ** rng.uniform(-9, -8, W); REFL = rng.uniform(0, 0.3, W)
+    SOL = np.array([20.0, 120.0, 45.0]); EMI = np.array([10.0, 30.0, 85.0])
+    out = eng.cirsrad_ck_thermal(ispace, atm["lay_press_pa"], atm["lay_temp"], atm["amount"], cont, NLAYIN, LAYINC, SCALE, EMTEMP,
+                                 TSURF, EMISSIVITY=EMIS, SOLFLUX=SOLF, REFLECTANCE=REFL, SOL_ANG=SOL, EMISS_ANG=EMI)
+    assert out.shape == (n, W, P)
+    for m in range(n):
+        ref = oracle.cirsrad_ck_thermal(ispace, K, PRESS, TEMP, WAVE, delg, atm["lay_press_pa"][m], atm["lay_temp"][m],
+                                        atm["amount"][m], cont[m], NLAYIN, LAYINC, SCALE[m], EMTEMP[m], TSURF[m], EMISSIVITY=EMIS,
+                                        SOLFLUX=SOLF, REFLECTANCE=REFL, SOL_ANG=SOL, EMISS_ANG=EMI)
+        np.testing.assert_allclose(out[m], ref, rtol=1e-10, atol=0, err_msg=f"model {m}")
+
+
+def test_cirsradg_multi_path_ragged_vs_oracle(eng, oracle):
+    """CIRSrad(return_grad=True) with three paths of different length (one visiting layers twice): dSPECOUT (W,NPAR,LIMAX,P)."""
+    from archnemesis_dist_amd import synthetic as syn
+    W, G, S, L, NP, NT = 100, 10, 3, 12, 7, 6
+    _, delg = syn.gauss_legendre_01(G, True)
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S, seed=32)
+    WAVE = 300.0 + 1.5 * np.arange(W)
+    eng.upload_ktable(K, PRESS, TEMP, WAVE, delg)
+    atm = syn.synth_atmosphere(L, S, seed=5)
+    P, LIMAX = 3, 12
+    LAYINC = np.zeros((LIMAX, P), dtype=np.int32)
+    NLAYIN = np.array([12, 4, 10], dtype=np.int32)
+    LAYINC[:12, 0] = np.arange(L - 1, -1, -1)
+    LAYINC[:4, 1] = np.arange(L - 1, L - 5, -1)
+    LAYINC[:10, 2] = np.concatenate([np.arange(L - 1, L - 6, -1), np.arange(L - 5, L)])
+    rng = np.random.default_rng(13)
+    SCALE = rng.uniform(1.0, 3.0, (LIMAX, P))
+    EMTEMP = atm["lay_temp"][0][LAYINC]
+    cont = syn.synth_continuum(W, L)[0]
+    NVMR, NDUST = S, 1
+    NPAR = NVMR + 2 + NDUST
+    dcont = cont[:, None, :] * rng.uniform(0.0, 1e-22, size=(W, NPAR, L))
+    spec, dspec, dts = eng.cirsradg_ck_thermal(0, atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0], cont, dcont, NVMR, NPAR,
+                                               np.arange(S, dtype=np.int32), NLAYIN, LAYINC, SCALE, EMTEMP, 240.0,
+                                               EMISSIVITY=np.linspace(0.8, 1.0, W))
+    rs, rd, rt = oracle.cirsradg_ck_thermal(0, K, PRESS, TEMP, WAVE, delg, atm["lay_press_pa"][0], atm["lay_temp"][0],
+                                            atm["amount"][0], cont, dcont, NVMR, NPAR, np.arange(S, dtype=np.int32), NLAYIN, LAYINC,
+                                            SCALE, EMTEMP, 240.0, EMISSIVITY=np.linspace(0.8, 1.0, W))
+    assert dspec.shape == (W, NPAR, LIMAX, P)
+    np.testing.assert_allclose(spec, rs, rtol=1e-10)
+    np.testing.assert_allclose(dts, rt, rtol=1e-10, atol=0)
+    scale = np.abs(rd).max(axis=(0, 2), keepdims=True) + 1e-300
+    assert np.max(np.abs(dspec - rd) / scale) < 1e-9
