@@ -595,6 +595,33 @@ __device__ __forceinline__ void ms_inv16(double *A, double *Ainv, int lane)
     }
 }
 
+// (E - B)^-1 for a 16x16 B given in D layout, on the matrix cores: the product form of the Neumann series,
+//     (E - B)^-1 = (E + B)(E + B^2)(E + B^4)...,
+// two MFMA products per factor; it stops when the next power is below 1e-17 in Frobenius norm (B = R R' of physical
+// reflection operators has spectral radius < 1: 6 factors at |B| = 0.5, 9 at 0.9).  Returns false when it has not
+// converged after 12 squarings (the caller then falls back on Gauss-Jordan).  mA / mB: LDS scratch matrices.
+__device__ __forceinline__ bool ms_inv16_series(const Ms16 &L, ms_v4f64 B, double *mA, double *mB, ms_v4f64 &X)
+{
+    X = L.eye_plus(B, 1.0);
+    ms_v4f64 Pw = B;
+    for (int it = 0; it < 12; ++it) {
+        double aP[4], aX[4];
+        L.store_d(mA, Pw);
+        L.store_d(mB, X);
+        MS16_FENCE();
+        L.load_a(mA, aP);
+        const ms_v4f64 P2 = Ms16::mm(aP, Pw);                  // B^(2^(it+1))
+        if (!(Ms16::frob(P2) >= 1e-17)) return true;           // also leaves on NaN
+        L.load_a(mB, aX);
+        const ms_v4f64 XP = Ms16::mm(aX, P2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[r] = X[r] + XP[r];       // X (E + P2)
+        Pw = P2;
+        MS16_FENCE();
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
 {
     extern __shared__ double sm[];
@@ -689,11 +716,13 @@ __global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
                 L.load_a(r1, aR);
                 const ms_v4f64 bcom = Ms16::mm(aR, bR);                       // r1 r1
                 ms_v4f64 acom;
-                if (Ms16::frob(bR) > 0.1) {
-                    L.store_d(mA, L.eye_plus(bcom, -1.0));
-                    MS16_FENCE();
-                    ms_inv16(mA, mB, lane);                                   // inv(e - bcom)
-                    acom = L.load_d(mB);
+                if (Ms16::frob(bR) > 0.1) {                                   // inv(e - bcom)
+                    if (!ms_inv16_series(L, bcom, mA, mB, acom)) {
+                        L.store_d(mA, L.eye_plus(bcom, -1.0));
+                        MS16_FENCE();
+                        ms_inv16(mA, mB, lane);
+                        acom = L.load_d(mB);
+                    }
                 } else
                     acom = L.eye_plus(bcom, 1.0);
                 L.load_a(t1, aT);
@@ -736,10 +765,12 @@ __global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
             const ms_v4f64 rsq = Ms16::mm(aRc, bR1);                          // rsub r1
             ms_v4f64 acom;
             if (Ms16::frob(rsq) > 0.01) {
-                L.store_d(mA, L.eye_plus(rsq, -1.0));
-                MS16_FENCE();
-                ms_inv16(mA, mB, lane);
-                acom = L.load_d(mB);
+                if (!ms_inv16_series(L, rsq, mA, mB, acom)) {
+                    L.store_d(mA, L.eye_plus(rsq, -1.0));
+                    MS16_FENCE();
+                    ms_inv16(mA, mB, lane);
+                    acom = L.load_d(mB);
+                }
             } else
                 acom = L.eye_plus(rsq, 1.0);
             L.load_a(t1, aT);
