@@ -25,7 +25,7 @@ EXPORTS = [
     "ansfm_cirsrad_ck_thermal_dev", "ansfm_get_taugas", "ansfm_last_kernel_ms",
     "ansfm_k_overlapg", "ansfm_cirsradg_ck_thermal", "ansfm_cirsradg_ck_thermal_dev", "ansfm_scloud11wave_core", "ansfm_upload_lbltable", "ansfm_calc_klbl", "ansfm_add_line_set_monochromatic_absorption", "ansfm_layer_average",
     "ansfm_map2pro", "ansfm_map2xvec", "ansfm_layer_averageg", "ansfm_lblconv", "ansfm_lblconv_fil", "ansfm_set_layer_dedup", "ansfm_last_layer_rows",
-    "ansfm_ktable_file_header", "ansfm_upload_ktable_files", "ansfm_ktable_grids",
+    "ansfm_ktable_file_header", "ansfm_upload_ktable_files", "ansfm_ktable_grids", "ansfm_calc_tau_cia",
 ]
 
 _lib = None
@@ -96,6 +96,8 @@ def load():
                                                                 vp, vp, vp, vp, vp, vp, cd, cd, cd]
     lib.ansfm_layer_average.argtypes = [vp, ci, cd, ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, vp, cd, ci, cd, ci, vp, vp] + [vp] * 11
     lib.ansfm_layer_averageg.argtypes = [vp, ci, cd, ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, vp, cd, ci, cd, ci, vp, vp] + [vp] * 15
+    lib.ansfm_calc_tau_cia.argtypes = [vp, ci, vp, ci, vp, ci, ci, ci, vp, vp, ci, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp, ci, vp,
+                                       ci, vp, vp, vp]
     lib.ansfm_ktable_file_header.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ansfm_upload_ktable_files.argtypes = [vp, ci, C.POINTER(C.c_char_p), cd, cd]
     lib.ansfm_ktable_grids.argtypes = [vp, vp, vp, vp, vp]

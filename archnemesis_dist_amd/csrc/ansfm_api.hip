@@ -6,6 +6,7 @@
 #include "ansfm_layer_kernels.hip.h"
 #include "ansfm_map_kernels.hip.h"
 #include "ansfm_conv_kernels.hip.h"
+#include "ansfm_cont_kernels.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -1348,6 +1349,104 @@ int ansfm_lblconv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const doub
 {
     if (ctx && !nfil) FAIL(ANSFM_ERR_INVALID, "lblconv_fil: bad argument");
     return ils_conv_impl(ctx, nwave, vwave, y, nx, dydx, nconv, vconv, 0, 0.0, 0, nfilmax, nfil, vfil, afil, yout, gradout);
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* continuum: collision-induced absorption (ForwardModel_0.calc_tau_cia)                       */
+/* ------------------------------------------------------------------------------------------ */
+int ansfm_calc_tau_cia(ansfm_ctx *ctx, int W, const double *WAVEN, int NWC, const double *cia_waven, int NPAIR, int NPE,
+                       int NT, const double *K_CIA, const double *cia_temp, int nfrac, const double *cia_frac, int NPARA,
+                       const int32_t *igas1, const int32_t *igas2, int L, int NVMR, const double *lay_temp,
+                       const double *lay_frac, const double *q, const double *xfac, int ico2, const double *k_co2, int in2,
+                       const double *k_n2n2, int ih2, const double *k_n2h2, double *TAUCIA, double *dTAUCIA)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || NWC < 2 || NPAIR < 0 || NPE < 1 || NT < 2 || nfrac < 1 || L <= 0 || NVMR < 2 || !WAVEN || !cia_waven ||
+        !K_CIA || !cia_temp || !cia_frac || (NPAIR > 0 && (!igas1 || !igas2)) || !lay_temp || !lay_frac || !q || !xfac ||
+        !TAUCIA || (ico2 >= 0 && !k_co2) || (in2 >= 0 && !k_n2n2) || (in2 >= 0 && ih2 >= 0 && !k_n2h2) ||
+        ico2 >= NVMR || in2 >= NVMR || ih2 >= NVMR)
+        FAIL(ANSFM_ERR_INVALID, "calc_tau_cia: bad argument");
+    for (int i = 0; i < NPAIR; ++i)
+        if (igas1[i] >= NVMR || igas2[i] >= NVMR) FAIL(ANSFM_ERR_INVALID, "calc_tau_cia: pair gas index outside the atmosphere");
+    for (int i = 1; i < W; ++i)
+        if (!(WAVEN[i] >= WAVEN[i - 1])) FAIL(ANSFM_ERR_UNSORTED, "calc_tau_cia: wavenumbers must be ascending");
+    // per-layer brackets and weights (:4588-4666), including the reference's overwrite of temp1 in the upper
+    // para-fraction clamp (:4623)
+    std::vector<CiaLayer> lay(L);
+    for (int l = 0; l < L; ++l) {
+        double temp1 = lay_temp[l];
+        int it = 0;
+        for (int k = 1; k < NT; ++k) if (fabs(cia_temp[k] - temp1) < fabs(cia_temp[it] - temp1)) it = k;
+        int itl, ithi;
+        if (cia_temp[it] >= temp1) {
+            ithi = it;
+            if (it == 0) { temp1 = cia_temp[0]; itl = 0; ithi = 1; } else itl = it - 1;
+        } else {
+            itl = it;
+            if (it == NT - 1) { temp1 = cia_temp[it]; ithi = NT - 1; itl = NT - 2; } else ithi = it + 1;
+        }
+        double frac1 = lay_frac[l];
+        int ip = 0;
+        for (int k = 1; k < nfrac; ++k) if (fabs(cia_frac[k] - frac1) < fabs(cia_frac[ip] - frac1)) ip = k;
+        int ipl, iphi;
+        if (cia_frac[ip] >= frac1) {
+            iphi = ip;
+            if (ip == 0) { frac1 = cia_frac[0]; ipl = 0; iphi = 1; } else ipl = ip - 1;
+        } else {
+            ipl = ip;
+            if (ip == NPARA - 1) { temp1 = cia_frac[ip]; iphi = NPARA - 1; ipl = NPARA - 2; } else iphi = ip + 1;
+        }
+        if (NPARA == 0) { ipl = 0; iphi = 0; }
+        if (ipl < 0 || iphi < 0 || ipl >= NPE || iphi >= NPE || (nfrac > 1 && iphi >= nfrac))
+            FAIL(ANSFM_ERR_INVALID, "calc_tau_cia: para-H2 bracket outside K_CIA (the reference raises IndexError here)");
+        CiaLayer c;
+        c.itl = itl; c.ithi = ithi; c.ipl = ipl; c.iphi = iphi;
+        c.fhl_t = (temp1 - cia_temp[itl]) / (cia_temp[ithi] - cia_temp[itl]);
+        c.fhh_t = (cia_temp[ithi] - temp1) / (cia_temp[ithi] - cia_temp[itl]);
+        c.dfhldT = 1.0 / (cia_temp[ithi] - cia_temp[itl]);
+        if (nfrac > 1) {
+            c.fhl_f = (frac1 - cia_frac[ipl]) / (cia_frac[iphi] - cia_frac[ipl]);
+            c.fhh_f = (cia_frac[iphi] - frac1) / (cia_frac[iphi] - cia_frac[ipl]);
+        } else { c.fhl_f = 0.5; c.fhh_f = 0.5; }
+        c.xfac = xfac[l];
+        lay[l] = c;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t D = sizeof(double);
+    const void *d[12] = {nullptr};
+    int rc;
+    double cmin = cia_waven[0], cmax = cia_waven[0];
+    for (int i = 1; i < NWC; ++i) { cmin = std::min(cmin, cia_waven[i]); cmax = std::max(cmax, cia_waven[i]); }
+    const int covers = (cmin <= WAVEN[0] && cmax >= WAVEN[W - 1]) ? 1 : 0;      // :4671
+    if ((rc = h2d(ctx, ctx->hb[0], WAVEN, W * D, &d[0]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[1], cia_waven, NWC * D, &d[1]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[2], K_CIA, (size_t)NPAIR * NPE * NT * NWC * D, &d[2]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[3], lay.data(), L * sizeof(CiaLayer), &d[3]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[4], igas1, NPAIR * sizeof(int32_t), &d[4]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[5], igas2, NPAIR * sizeof(int32_t), &d[5]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[6], q, (size_t)L * NVMR * D, &d[6]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[7], ico2 >= 0 ? k_co2 : nullptr, W * D, &d[7]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[8], in2 >= 0 ? k_n2n2 : nullptr, W * D, &d[8]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[9], (in2 >= 0 && ih2 >= 0) ? k_n2h2 : nullptr, W * D, &d[9]))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));                     // `lay` is a host temporary
+    const size_t nt = (size_t)W * L, nd = dTAUCIA ? nt * (NVMR + 2) : 0;
+    HIPCHK(ctx->tmp_out.reserve((nt + nd) * D));
+    CiaParams p;
+    memset(&p, 0, sizeof p);
+    p.waven = (const double *)d[0]; p.cia_waven = (const double *)d[1]; p.K = (const double *)d[2];
+    p.lay = (const CiaLayer *)d[3]; p.g1 = (const int32_t *)d[4]; p.g2 = (const int32_t *)d[5]; p.q = (const double *)d[6];
+    p.k_co2 = (const double *)d[7]; p.k_n2n2 = (const double *)d[8]; p.k_n2h2 = (const double *)d[9];
+    p.tau = ctx->tmp_out.as<double>(); p.dtau = dTAUCIA ? p.tau + nt : nullptr;
+    p.W = W; p.NWC = NWC; p.NPAIR = NPAIR; p.NPE = NPE; p.NT = NT; p.L = L; p.NVMR = NVMR; p.covers = covers;
+    p.ico2 = ico2; p.in2 = in2; p.ih2 = ih2;
+    if (p.dtau) HIPCHK(hipMemsetAsync(p.dtau, 0, nd * D, ctx->stream));
+    hipLaunchKernelGGL(k_tau_cia, dim3(nblk((size_t)W, 128), (unsigned)L), dim3(128), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(TAUCIA, p.tau, nt * D, hipMemcpyDeviceToHost, ctx->stream));
+    if (dTAUCIA) HIPCHK(hipMemcpyAsync(dTAUCIA, p.dtau, nd * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
 }
 
 /* ------------------------------------------------------------------------------------------ */

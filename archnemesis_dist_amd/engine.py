@@ -377,6 +377,47 @@ class AnsfmEngine:
         self._check(rc, "map2xvec")
         return out
 
+    # ---- continuum -----------------------------------------------------------------------------------------------
+    def calc_tau_cia(self, ISPACE, WAVEC, CIA_WAVEN, CIA_TEMP, CIA_FRAC, NPARA, K_CIA, IPAIRG1, IPAIRG2, INORMALT, INORMAL,
+                     INORMALD, ID, ISO, PP, PRESS, TEMP, FRAC, TOTAM, DELH, k_co2=None, k_n2n2=None, k_n2h2=None, with_grad=True):
+        """ForwardModel_0.calc_tau_cia (:4516) with the reference's objects flattened into arrays (CIA.WAVEN/TEMP/FRAC/
+        NPARA/K_CIA/IPAIRG1/IPAIRG2/INORMALT/INORMAL, CIA.locate_INORMAL_pairs(), Atmosphere.ID/ISO, Layer.PP/PRESS/TEMP/
+        FRAC/TOTAM/DELH) and co2cia / n2n2cia / n2h2cia(WAVEN) as vectors.  -> TAUCIA (NWAVE,NLAY), dTAUCIA (NWAVE,NLAY,NVMR+2)."""
+        WAVEC = _np(WAVEC); ID = np.asarray(ID); ISO = np.asarray(ISO)
+        NVMR = ID.size
+        if int(ISPACE) == 0:
+            WAVEN, isort = WAVEC, None
+        else:                                              # :4565-4568
+            WAVEN = 1.e4 / WAVEC; isort = np.argsort(WAVEN); WAVEN = _np(WAVEN[isort])
+        K = _np(K_CIA); NPAIR, NPE, NT, NWC = K.shape
+        g1 = np.full(NPAIR, -1, np.int32); g2 = np.full(NPAIR, -1, np.int32)
+        for ip in range(NPAIR):                            # :4676-4701
+            a = np.where(ID == int(IPAIRG1[ip]))[0]; b = np.where(ID == int(IPAIRG2[ip]))[0]
+            if len(a) > 1: a = np.where((ID == int(IPAIRG1[ip])) & (ISO == 1))[0]
+            if len(b) > 1: b = np.where((ID == int(IPAIRG2[ip])) & (ISO == 1))[0]
+            if len(a) == 1 and len(b) == 1 and not (INORMALD[ip] and int(INORMALT[ip]) != int(INORMAL)):
+                g1[ip], g2[ip] = a[0], b[0]
+        ico2 = ih2 = in2 = -1                              # :4545-4561
+        for i in range(NVMR):
+            if ID[i] == 39 and ISO[i] in (0, 1): ih2 = i
+            if ID[i] == 22: in2 = i
+            if ID[i] == 2 and ISO[i] in (0, 1): ico2 = i
+        q = _np((_np(PP).T / _np(PRESS)).T)
+        L = q.shape[0]
+        xfac = _np((_np(TOTAM) * 1.0e-4) ** 2. / (_np(DELH) * 1.0e2))
+        frac = _np(np.asarray(CIA_FRAC, float).reshape(-1))
+        W = WAVEN.size
+        tau = np.empty((W, L)); dtau = np.empty((W, L, NVMR + 2)) if with_grad else None
+        rc = self._lib.ansfm_calc_tau_cia(self._ctx, W, _ptr(WAVEN), NWC, _ptr(_np(CIA_WAVEN)), NPAIR, NPE, NT, _ptr(K),
+                                          _ptr(_np(CIA_TEMP)), frac.size, _ptr(frac), int(NPARA), _ptr(g1), _ptr(g2), L, NVMR,
+                                          _ptr(_np(TEMP)), _ptr(_np(FRAC)), _ptr(q), _ptr(xfac), ico2, _ptr(_np(k_co2)), in2,
+                                          _ptr(_np(k_n2n2)), ih2, _ptr(_np(k_n2h2)), _ptr(tau), _ptr(dtau))
+        self._check(rc, "calc_tau_cia")
+        if isort is not None:                              # :4741-4743
+            tau = tau[isort, :]
+            dtau = None if dtau is None else dtau[isort, :, :]
+        return (tau, dtau) if with_grad else tau
+
     # ---- instrument line shape ---------------------------------------------------------------------------------
     def lblconv(self, nwave, vwave, y, nconv, vconv, ishape, fwhm):
         """Measurement_0.lblconv (:3335), one geometry: y (nwave) -> yout (nconv)."""

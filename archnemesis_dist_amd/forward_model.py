@@ -345,3 +345,37 @@ def install_gpu_convolution(device=0):
 
     m0.lblconv, m0.lblconvg, m0.lblconv_fil, m0.lblconvg_fil = lblconv, lblconvg, lblconv_fil, lblconvg_fil
     return lblconv, lblconvg, lblconv_fil, lblconvg_fil
+
+
+def install_gpu_continuum(device=0):
+    """Route ForwardModel_0.calc_tau_cia (ForwardModel_0.py:4516) -- per forward model ~2 scipy interp1d constructions per
+    (layer, CIA pair) on the host -- through the GPU.  The wavenumber-only parametrisations co2cia / n2n2cia / n2h2cia
+    (CIA_0.py:631-880, embedded data tables) are still evaluated by the reference's own functions and passed as vectors."""
+    import importlib
+    fm = importlib.import_module("archnemesis.ForwardModel_0")
+    cm = importlib.import_module("archnemesis.CIA_0")
+    eng = get_engine(device)
+    cls = fm.ForwardModel_0
+    ref = getattr(cls, "_ansfm_reference_calc_tau_cia", None) or cls.calc_tau_cia
+
+    def calc_tau_cia(self, ISPACE=None, WAVEC=None, CIA=None, Atmosphere=None, Layer=None, MakePlot=False):
+        if MakePlot:
+            return ref(self, ISPACE, WAVEC, CIA, Atmosphere, Layer, MakePlot)
+        ISPACE = int(self.MeasurementX.ISPACE) if ISPACE is None else int(ISPACE)
+        WAVEC = self.SpectroscopyX.WAVE if WAVEC is None else WAVEC
+        CIA = self.CIAX if CIA is None else CIA
+        A = self.AtmosphereX if Atmosphere is None else Atmosphere
+        L = self.LayerX if Layer is None else Layer
+        WAVEC = np.asarray(WAVEC, dtype=np.float64)
+        WAVEN = WAVEC if ISPACE == 0 else np.sort(1.e4 / WAVEC)
+        ID = np.asarray(A.ID); ISO = np.asarray(A.ISO)
+        has = lambda gid: np.any((ID == gid))
+        return eng.calc_tau_cia(ISPACE, WAVEC, CIA.WAVEN, CIA.TEMP, CIA.FRAC, int(CIA.NPARA), CIA.K_CIA,
+                                [int(g) for g in CIA.IPAIRG1], [int(g) for g in CIA.IPAIRG2], [int(g) for g in CIA.INORMALT],
+                                int(CIA.INORMAL), CIA.locate_INORMAL_pairs(), ID, ISO, L.PP, L.PRESS, L.TEMP, L.FRAC, L.TOTAM, L.DELH,
+                                k_co2=cm.co2cia(WAVEN) if has(2) else None, k_n2n2=cm.n2n2cia(WAVEN) if has(22) else None,
+                                k_n2h2=cm.n2h2cia(WAVEN) if (has(22) and has(39)) else None)
+
+    cls._ansfm_reference_calc_tau_cia = ref
+    cls.calc_tau_cia = calc_tau_cia
+    return calc_tau_cia

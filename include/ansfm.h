@@ -288,6 +288,24 @@ int ansfm_lblconv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const doub
                       const double *dydx, int nconv, const double *vconv, int nfilmax, const int32_t *nfil,
                       const double *vfil, const double *afil, double *yout, double *gradout);
 
+/* ---- continuum ---------------------------------------------------------------------------
+ * ForwardModel_0.calc_tau_cia (ForwardModel_0.py:4516-4760), wavenumber space (the caller converts and re-orders a
+ * wavelength grid as the reference does, :4565-4568 / :4741-4743).  WAVEN[W] ascending; the CIA table
+ * K_CIA[NPAIR][NPE][NT][NWC] on cia_waven / cia_temp / cia_frac[nfrac] (NPE = size of the para axis of K_CIA, NPARA =
+ * CIA.NPARA, 0 for tables without ortho/para dependence); igas1 / igas2[NPAIR] = index of each partner among the NVMR
+ * atmospheric gases, -1 when the pair is not to be used (gas missing or ambiguous :4676-4684, or the pair's INORMALT
+ * differs from CIA.INORMAL :4696-4701); per layer temperature, para-H2 fraction, mixing ratios q[L][NVMR] = PP/PRESS
+ * and xfac[L] = (TOTAM*1e-4)^2 / (DELH*1e2); ico2 / in2 / ih2 = index of CO2 / N2 / H2 (or -1) with the reference's
+ * co2cia / n2n2cia / n2h2cia(WAVEN) vectors (wavenumber-only parametrisations; NULL when the index is -1).
+ * -> TAUCIA[W][L], dTAUCIA[W][L][NVMR+2] (NULL to skip).  Reference quirks kept (temp1 overwritten by the upper
+ * para-fraction clamp :4623; temperature gradient in slot NVMR-2 :4695). */
+int ansfm_calc_tau_cia(ansfm_ctx *ctx, int W, const double *WAVEN, int NWC, const double *cia_waven, int NPAIR,
+                       int NPE, int NT, const double *K_CIA, const double *cia_temp, int nfrac,
+                       const double *cia_frac, int NPARA, const int32_t *igas1, const int32_t *igas2, int L,
+                       int NVMR, const double *lay_temp, const double *lay_frac, const double *q,
+                       const double *xfac, int ico2, const double *k_co2, int in2, const double *k_n2n2, int ih2,
+                       const double *k_n2h2, double *TAUCIA, double *dTAUCIA);
+
 /* Layer de-duplication inside a batch (n_models > 1) of the cirsrad_ck_thermal entry points.  The states of a
  * numerical Jacobian (ForwardModel_0.jacobian_nemesis :2234-2242) differ from the unperturbed one in two or three
  * layers; every layer (m, l) whose pressure, temperature and S amounts equal those of layer l of model 0 to the last

@@ -403,3 +403,98 @@ def lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil, dydx=None):
         idx = np.where((vwave >= xp[0]) & (vwave <= xp[-1]))[0]
         out[j] = _ils_sum(np.interp(vwave[idx], xp, yp), cols[idx])
     return (out[:, -1], out[:, :-1]) if grad else out[:, 0]
+
+
+# ---- collision-induced absorption (ForwardModel_0.calc_tau_cia :4516-4760) -----------------------------------------
+def calc_tau_cia(ISPACE, WAVEC, CIA_WAVEN, CIA_TEMP, CIA_FRAC, NPARA, K_CIA, IPAIRG1, IPAIRG2, INORMALT, INORMAL, INORMALD,
+                 ID, ISO, PP, PRESS, TEMP, FRAC, TOTAM, DELH, k_co2=None, k_n2n2=None, k_n2h2=None):
+    """NumPy restatement with the reference's objects flattened into arrays.  k_co2 / k_n2n2 / k_n2h2 are the reference's
+    co2cia / n2n2cia / n2h2cia(WAVEN) (wavenumber-only parametrisations with embedded data tables, taken as inputs).
+    Returns TAUCIA (NWAVE, NLAY), dTAUCIA (NWAVE, NLAY, NVMR+2).  Quirks kept: the upper para-fraction clamp overwrites
+    temp1 (:4623), the temperature gradient goes to slot NVMR-2 (:4695), dktdT = (kthi - ktlo) * dfhldT (:4667) and the
+    wavelength-space result is gathered with isort (:4741-4743)."""
+    WAVEC = np.asarray(WAVEC, float); ID = np.asarray(ID); ISO = np.asarray(ISO)
+    NVMR = ID.size; NLAY = np.asarray(TEMP).size; NPAIR = len(IPAIRG1)
+    CIA_TEMP = np.asarray(CIA_TEMP, float); CIA_FRAC = np.asarray(CIA_FRAC, float); NT = CIA_TEMP.size
+    q = (np.asarray(PP, float).T / np.asarray(PRESS, float)).T
+    ico2 = ih2 = in2 = -1
+    for i in range(NVMR):
+        if ID[i] == 39 and ISO[i] in (0, 1): ih2 = i
+        if ID[i] == 22: in2 = i
+        if ID[i] == 2 and ISO[i] in (0, 1): ico2 = i
+    XFAC = (np.asarray(TOTAM, float) * 1.0e-4) ** 2. / (np.asarray(DELH, float) * 1.0e2)
+    if ISPACE == 0:
+        WAVEN = WAVEC; isort = None
+    else:
+        WAVEN = 1.e4 / WAVEC; isort = np.argsort(WAVEN); WAVEN = WAVEN[isort]
+    NW = WAVEC.size
+    tau = np.zeros((NW, NLAY)); dtau = np.zeros((NW, NLAY, NVMR + 2))
+    covers = (CIA_WAVEN.min() <= WAVEN.min()) and (CIA_WAVEN.max() >= WAVEN.max())
+    # linear interp1d over CIA_WAVEN: idx = clip(searchsorted(x, xn, 'left'), 1, n-1); slope*(xn - x_lo) + y_lo
+    iw = np.clip(np.searchsorted(CIA_WAVEN, WAVEN, side="left"), 1, CIA_WAVEN.size - 1)
+    xlo = CIA_WAVEN[iw - 1]; dx = CIA_WAVEN[iw] - xlo
+    for l in range(NLAY):
+        temp1 = float(TEMP[l])
+        it = int(np.argmin(np.abs(CIA_TEMP - temp1)))
+        if CIA_TEMP[it] >= temp1:
+            ithi = it
+            if it == 0: temp1 = CIA_TEMP[0]; itl = 0; ithi = 1
+            else: itl = it - 1
+        else:
+            itl = it
+            if it == NT - 1: temp1 = CIA_TEMP[it]; ithi = NT - 1; itl = NT - 2
+            else: ithi = it + 1
+        frac1 = float(FRAC[l])
+        ip = int(np.argmin(np.abs(CIA_FRAC - frac1)))
+        if CIA_FRAC[ip] >= frac1:
+            iphi = ip
+            if ip == 0: frac1 = CIA_FRAC[0]; ipl = 0; iphi = 1
+            else: ipl = ip - 1
+        else:
+            ipl = ip
+            if ip == NPARA - 1: temp1 = CIA_FRAC[ip]; iphi = NPARA - 1; ipl = NPARA - 2       # sic: temp1
+            else: iphi = ip + 1
+        if NPARA == 0: ipl = iphi = 0
+        fhl_t = (temp1 - CIA_TEMP[itl]) / (CIA_TEMP[ithi] - CIA_TEMP[itl])
+        fhh_t = (CIA_TEMP[ithi] - temp1) / (CIA_TEMP[ithi] - CIA_TEMP[itl])
+        dfhldT = 1.0 / (CIA_TEMP[ithi] - CIA_TEMP[itl])
+        if CIA_FRAC.size > 1:
+            fhl_f = (frac1 - CIA_FRAC[ipl]) / (CIA_FRAC[iphi] - CIA_FRAC[ipl])
+            fhh_f = (CIA_FRAC[iphi] - frac1) / (CIA_FRAC[iphi] - CIA_FRAC[ipl])
+        else:
+            fhl_f = fhh_f = 0.5
+        ktlo = K_CIA[:, ipl, itl, :] * fhh_t + K_CIA[:, ipl, ithi, :] * fhl_t
+        kthi = K_CIA[:, iphi, itl, :] * fhh_t + K_CIA[:, iphi, ithi, :] * fhl_t
+        kt = ktlo * fhh_f + kthi * fhl_f
+        dktdT = (kthi - ktlo) * dfhldT
+        sum1 = np.zeros(NW)
+        if covers:
+            for ipair in range(NPAIR):
+                g1 = np.where(ID == IPAIRG1[ipair])[0]; g2 = np.where(ID == IPAIRG2[ipair])[0]
+                if len(g1) > 1: g1 = np.where((ID == IPAIRG1[ipair]) & (ISO == 1))[0]
+                if len(g2) > 1: g2 = np.where((ID == IPAIRG2[ipair]) & (ISO == 1))[0]
+                if len(g1) == 1 and len(g2) == 1:
+                    g1 = int(g1[0]); g2 = int(g2[0])
+                    if INORMALD[ipair] and INORMALT[ipair] != INORMAL:
+                        continue
+                    y = kt[ipair]; k_cia = ((y[iw] - y[iw - 1]) / dx) * (WAVEN - xlo) + y[iw - 1]
+                    y = dktdT[ipair]; dk = ((y[iw] - y[iw - 1]) / dx) * (WAVEN - xlo) + y[iw - 1]
+                    sum1 = sum1 + k_cia * q[l, g1] * q[l, g2]
+                    dtau[:, l, g1] = dtau[:, l, g1] + q[l, g2] * k_cia
+                    dtau[:, l, g2] = dtau[:, l, g2] + q[l, g1] * k_cia
+                    dtau[:, l, NVMR - 2] = dtau[:, l, NVMR - 2] + dk * q[l, g1] * q[l, g2]
+        if ico2 != -1:
+            sum1 = sum1 + k_co2 * q[l, ico2] * q[l, ico2]
+            dtau[:, l, ico2] = dtau[:, l, ico2] + 2. * q[l, ico2] * k_co2
+        if in2 != -1:
+            sum1 = sum1 + k_n2n2 * q[l, in2] * q[l, in2]
+            dtau[:, l, in2] = dtau[:, l, in2] + 2. * q[l, in2] * k_n2n2
+        if in2 != -1 and ih2 != -1:
+            sum1 = sum1 + k_n2h2 * q[l, in2] * q[l, ih2]
+            dtau[:, l, ih2] = dtau[:, l, ih2] + q[l, in2] * k_n2h2
+            dtau[:, l, in2] = dtau[:, l, in2] + q[l, ih2] * k_n2h2
+        tau[:, l] = sum1 * XFAC[l]
+        dtau[:, l, :] = dtau[:, l, :] * XFAC[l]
+    if isort is not None:
+        tau = tau[isort, :]; dtau = dtau[isort, :, :]
+    return tau, dtau

@@ -52,6 +52,11 @@ class OracleEngineDouble:
         self.lay_calls = getattr(self, "lay_calls", 0) + 1
         return self.orc.layer_averageg(*a, **k)
 
+    def calc_tau_cia(self, *a, **k):
+        self.cia_calls = getattr(self, "cia_calls", 0) + 1
+        k.pop("with_grad", None)
+        return self.orc.calc_tau_cia(*a, **k)
+
     def map2pro(self, *a, **k):
         self.map_calls = getattr(self, "map_calls", 0) + 1
         return self.orc.map2pro(*a, **k)
@@ -156,6 +161,7 @@ def test_nemesisfmg_with_gradient_maps_routed_through_the_engine(c1_run, oracle,
     try:
         fmod.install_gpu_gradient_maps()
         fmod.install_gpu_layering()
+        fmod.install_gpu_continuum()
         FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
         Atm, Meas, Spec, Scat, Stel, Surf, CIA, Lay, Var, Ret = ans.Files.read_input_files("cirstest")
         fm = FMGPU(runname="cirstest", Atmosphere=Atm, Surface=Surf, Measurement=Meas, Spectroscopy=Spec, Stellar=Stel,
@@ -164,10 +170,13 @@ def test_nemesisfmg_with_gradient_maps_routed_through_the_engine(c1_run, oracle,
     finally:
         fm0.map2pro, fm0.map2xvec = orig
         l0.layer_average, l0.layer_averageg = orig_l
+        if hasattr(fm0.ForwardModel_0, "_ansfm_reference_calc_tau_cia"):
+            fm0.ForwardModel_0.calc_tau_cia = fm0.ForwardModel_0._ansfm_reference_calc_tau_cia
+            del fm0.ForwardModel_0._ansfm_reference_calc_tau_cia
         for mod, name in ((fm0, "_ansfm_reference_maps"), (l0, "_ansfm_reference_layering")):
             if hasattr(mod, name):
                 delattr(mod, name)
-    assert double.map_calls >= 2 and double.lay_calls >= 1
+    assert double.map_calls >= 2 and double.lay_calls >= 1 and double.cia_calls >= 1
     z = np.load(os.path.join(golden_dir, "c1_cirsrad_grad.npz"))
     ref = z["dSPECONV"]
     scale = np.abs(ref).max(axis=(0, 1), keepdims=True) + 1e-300

@@ -651,3 +651,18 @@ def test_cirsradg_multi_path_ragged_vs_oracle(eng, oracle):
     np.testing.assert_allclose(dts, rt, rtol=1e-10, atol=0)
     scale = np.abs(rd).max(axis=(0, 2), keepdims=True) + 1e-300
     assert np.max(np.abs(dspec - rd) / scale) < 1e-9
+
+
+@pytest.mark.parametrize("tag,space", [(t, sp) for t in ("eq", "normal", "para") for sp in (0, 1)])
+def test_calc_tau_cia_golden(eng, golden_dir, tag, space):
+    """Collision-induced absorption vs the reference's calc_tau_cia (golden): ortho/para pair selection, table clamps in
+    temperature and para fraction, the co2cia / n2n2cia / n2h2cia terms, wavenumber and wavelength grids, gradients."""
+    from test_cia_oracle import cia_args
+    z = _load(golden_dir, "tau_cia")
+    a, kw = cia_args(z, tag, space)
+    tau, dtau = eng.calc_tau_cia(*a, **kw)
+    ref_t, ref_d = z[f"{tag}_{space}_tau"], z[f"{tag}_{space}_dtau"]
+    np.testing.assert_allclose(tau, ref_t, rtol=1e-12, atol=0)
+    scale = np.max(np.abs(ref_d), axis=(0, 1), keepdims=True) + 1e-300
+    assert np.max(np.abs(dtau - ref_d) / scale) < 1e-12
+    assert np.array_equal(eng.calc_tau_cia(*a, with_grad=False, **kw), tau)
