@@ -59,6 +59,29 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so; libansfm.so is linked against the
+    one under /opt/rocm.  Whichever is loaded first must serve both, or the second initialisation fails (seen as
+    torch.cuda.is_available() == False after an engine was created).  If torch is installed and not yet imported, its
+    copy is loaded first (by path, no `import torch`), so libansfm.so's DT_NEEDED entry resolves to it."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                                         # torch's runtime is already the process's runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass                                       # fall back on the system runtime; torch must then be imported first
+
+
 def load():
     """dlopen libansfm.so and declare prototypes.  Raises AnsfmError if it is not built."""
     global _lib
@@ -67,6 +90,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise AnsfmError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, ci, cd = C.c_void_p, C.c_int, C.c_double
     lib.ansfm_abi_version.restype = ci
