@@ -105,7 +105,8 @@ def main():
     torch.cuda.synchronize()
     table_relayout_s = time.time() - t0
     Wc = min(args.cpu_sample_waves, W)
-    K_sample = Kdev[:Wc].cpu().numpy() if (rank == 0 and not args.no_cpu_baseline) else None
+    do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline      # contract: rank 0 at N = 1 only
+    K_sample = Kdev[:Wc].cpu().numpy() if do_cpu else None
     del Kdev
     torch.cuda.empty_cache()
 
@@ -226,7 +227,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port) on a bounded sample, rank 0 only ---------------------------------
     cpu = None
-    if not args.no_cpu_baseline:
+    if do_cpu:
         from oracle import oracle as orc
         orc.build()
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
