@@ -12,3 +12,16 @@ import csv,glob
 f=glob.glob("$OUT/**/*kernel_stats.csv",recursive=True)[0]
 for r in list(csv.DictReader(open(f)))[:10]: print(r["Name"][:70], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"])
 PY
+# optional MFMA counters of the same section (own pass, counters only): bash tools/prof_extra.sh ms <tag> pmc
+if [ "$3" = "pmc" ]; then
+  rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc -- python3 tools/bench_extra.py $SEC > $OUT/pmc.log 2>&1 || exit 1
+  python3 - <<PY
+import csv,glob
+from collections import defaultdict
+f=glob.glob("$OUT/pmc/**/*counter_collection.csv",recursive=True)[0]
+acc=defaultdict(lambda: defaultdict(list))
+for r in csv.DictReader(open(f)):
+    if "ansfm" in r["Kernel_Name"]: acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,cs in acc.items(): print(k, {c: sum(v)/len(v) for c,v in cs.items()})
+PY
+fi
