@@ -11,6 +11,7 @@ Everything else (subprofretg, calc_path, conv, ...) is the reference's own host 
 EmissionsX), so tests drive it with plain namespaces rebuilt from the C1 golden fixture.
 """
 import hashlib
+import os
 
 import numpy as np
 
@@ -37,12 +38,50 @@ def get_engine(device=0):
     return _ENGINES[device]
 
 
+class KtaTableOnDevice:
+    """Stand-in for Spectroscopy.K when the k-table is taken from the .kta files straight into HBM
+    (install_gpu_table_reader): knows the files, the wavenumber range and the shape the array would have.  Code that
+    really needs the numbers on the host (a CPU path of the reference) gets them through __array__, read by the
+    reference's own read_ktable -- slowly, once."""
+
+    def __init__(self, paths, wavemin, wavemax, shape, reader):
+        self.paths = [str(p) for p in paths]
+        self.wavemin, self.wavemax = float(wavemin), float(wavemax)
+        self.shape = tuple(int(x) for x in shape)
+        self.ndim = len(self.shape)
+        self.dtype = np.dtype(np.float64)
+        self._reader = reader
+        self._host = None
+        st = []
+        for p in self.paths:
+            q = p if p.endswith(".kta") else p + ".kta"
+            s = os.stat(q)
+            st.append((q, s.st_size, s.st_mtime_ns))
+        self.fingerprint = hashlib.blake2b(repr((st, self.wavemin, self.wavemax, self.shape)).encode(), digest_size=16).hexdigest()
+
+    def __array__(self, dtype=None, copy=None):
+        if self._host is None:
+            k = np.zeros(self.shape)
+            for i, p in enumerate(self.paths):
+                k[..., i] = self._reader(p, self.wavemin, self.wavemax)[12]
+            self._host = k
+        return self._host if dtype is None else self._host.astype(dtype, copy=False)
+
+    def __deepcopy__(self, memo):
+        return self                      # immutable description of files; nemesisfm deep-copies Spectroscopy per call
+
+
 def _table_fingerprint(S):
     """Cheap content fingerprint of the k-table held by a Spectroscopy object.  nemesisfm
     deep-copies Spectroscopy and re-reads the tables for every forward model
     (ForwardModel_0.py:480-482); the table in HBM is re-used when nothing changed."""
     K = S.K
     h = hashlib.blake2b(digest_size=16)
+    if isinstance(K, KtaTableOnDevice):
+        h.update(K.fingerprint.encode())
+        for a in (S.WAVE, S.PRESS, S.TEMP, S.DELG):
+            h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        return h.hexdigest()
     h.update(np.asarray(K.shape, dtype=np.int64).tobytes())
     h.update(str(int(S.ILBL)).encode())
     flat = K.reshape(-1)
@@ -140,7 +179,11 @@ class CIRSradGPU:
         S = self.SpectroscopyX
         fp = _table_fingerprint(S)
         if getattr(eng, "_table_fp", None) != fp:
-            if int(S.ILBL) == ILBL_LBL_TABLES:      # K (NWAVE,NP,|NT|,NGAS); TEMP (NP,|NT|) when NT < 0
+            if isinstance(S.K, KtaTableOnDevice):   # .kta files -> HBM without a host array (install_gpu_table_reader)
+                WAVE = eng.upload_ktable_files(S.K.paths, S.K.wavemin, S.K.wavemax)[0]
+                if WAVE.shape != np.shape(S.WAVE) or not np.array_equal(WAVE, np.asarray(S.WAVE, dtype=np.float64)):
+                    raise ValueError("the .kta files no longer give the wavenumber grid Spectroscopy.WAVE holds")
+            elif int(S.ILBL) == ILBL_LBL_TABLES:      # K (NWAVE,NP,|NT|,NGAS); TEMP (NP,|NT|) when NT < 0
                 eng.upload_lbltable(np.ascontiguousarray(S.K, dtype=np.float64), S.PRESS, S.TEMP, S.WAVE)
             else:
                 eng.upload_ktable(np.ascontiguousarray(S.K, dtype=np.float64), S.PRESS, S.TEMP, S.WAVE, S.DELG)
@@ -379,3 +422,39 @@ def install_gpu_continuum(device=0):
     cls._ansfm_reference_calc_tau_cia = ref
     cls.calc_tau_cia = calc_tau_cia
     return calc_tau_cia
+
+
+def install_gpu_table_reader(device=0):
+    """Spectroscopy_0.read_tables (Spectroscopy_0.py:1448) for binary k-tables without the host array: the header logic
+    (read_header, the searchsorted cut of WAVE to [wavemin, wavemax], :1482-1494) is the reference's, but instead of
+    unpacking every table with the Python loops of read_ktable (:2846-2850) into a float64 (NWAVE,NG,NP,NT,NGAS) array,
+    Spectroscopy.K becomes a KtaTableOnDevice description and the GPU CIRSrad streams the files into HBM
+    (ansfm_upload_ktable_files) -- once, since nemesisfm re-reads the tables for every forward model (:480-482) and the
+    fingerprint of unchanged files matches.  Other table kinds go to the reference's read_tables."""
+    import importlib
+    sp = importlib.import_module("archnemesis.Spectroscopy_0")
+    cls = sp.Spectroscopy_0
+    ref = getattr(cls, "_ansfm_reference_read_tables", None) or cls.read_tables
+
+    def read_tables(self, wavemin=0., wavemax=1.0e10, wavedelta=1.0):
+        binary = (int(self.ILBL) == ILBL_K_TABLES and self.LOCATION is not None and not getattr(self, "ONLINE", False)
+                  and len(self.LOCATION) > 0 and all(str(p).endswith("kta") for p in self.LOCATION))
+        if not binary:
+            return ref(self, wavemin, wavemax, wavedelta)
+        if self.WAVE is None:
+            self.read_header()
+        iwl = np.searchsorted(self.WAVE, wavemin, side='right') - 1      # :1486-1494
+        if iwl < 0:
+            iwl = 0
+        iwh = np.searchsorted(self.WAVE, wavemax, side='left')
+        if iwh >= self.NWAVE:
+            iwh = self.NWAVE - 1
+        wave1 = self.WAVE[iwl:iwh + 1]
+        self.NWAVE = len(wave1)
+        self.WAVE = wave1
+        self.K = KtaTableOnDevice(self.LOCATION, self.WAVE.min(), self.WAVE.max(),
+                                  (self.NWAVE, self.NG, self.NP, self.NT, self.NGAS), sp.read_ktable)
+
+    cls._ansfm_reference_read_tables = ref
+    cls.read_tables = read_tables
+    return read_tables

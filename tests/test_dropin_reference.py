@@ -27,6 +27,17 @@ class OracleEngineDouble:
         self.t = (K, PRESS, TEMP, WAVE, DELG)
         self.dims = K.shape
 
+    def upload_ktable_files(self, paths, wavemin, wavemax):
+        """what the engine does on the GPU, answered here with the reference's reader"""
+        import importlib
+        sp = importlib.import_module("archnemesis.Spectroscopy_0")
+        self.file_uploads = getattr(self, "file_uploads", 0) + 1
+        r = [sp.read_ktable(p, wavemin, wavemax) for p in paths]
+        h = sp.read_ktahead(paths[-1])
+        K = np.stack([x[12] for x in r], axis=-1)
+        self.upload_ktable(K, h[10], h[11], r[0][3], h[9])
+        return r[0][3], h[10], h[11], h[9]
+
     def cirsrad_ck_thermal(self, ISPACE, lp, lt, am, cont, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None,
                            SOL_ANG=None, EMISS_ANG=None, xfac=None, **kw):
         K, P, T, W, D = self.t
@@ -181,3 +192,34 @@ def test_nemesisfmg_with_gradient_maps_routed_through_the_engine(c1_run, oracle,
     ref = z["dSPECONV"]
     scale = np.abs(ref).max(axis=(0, 1), keepdims=True) + 1e-300
     assert np.max(np.abs(dSPECONV - ref) / scale) < 1e-5
+
+
+def test_nemesisfm_with_tables_streamed_from_the_kta_files(c1_run, oracle, golden_dir, monkeypatch):
+    """install_gpu_table_reader: Spectroscopy.read_tables keeps the reference's header logic but leaves the k data in
+    the files (K is a KtaTableOnDevice); the adapter hands the files to the engine once although nemesisfm re-reads the
+    tables on every call, and the spectrum is still the reference's."""
+    ans = c1_run
+    import importlib
+    import archnemesis_dist_amd.forward_model as fmod
+    sp = importlib.import_module("archnemesis.Spectroscopy_0")
+    double = OracleEngineDouble(oracle)
+    monkeypatch.setattr(fmod, "get_engine", lambda device=0: double)
+    orig = sp.Spectroscopy_0.read_tables
+    try:
+        fmod.install_gpu_table_reader()
+        FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+        Atm, Meas, Spec, Scat, Stel, Surf, CIA, Lay, Var, Ret = ans.Files.read_input_files("cirstest")
+        fm = FMGPU(runname="cirstest", Atmosphere=Atm, Surface=Surf, Measurement=Meas, Spectroscopy=Spec, Stellar=Stel,
+                   Scatter=Scat, CIA=CIA, Layer=Lay, Variables=Var)
+        SPECONV = fm.nemesisfm()
+        assert isinstance(fm.SpectroscopyX.K, fmod.KtaTableOnDevice)
+        SPECONV2 = fm.nemesisfm()
+    finally:
+        sp.Spectroscopy_0.read_tables = orig
+        if hasattr(sp.Spectroscopy_0, "_ansfm_reference_read_tables"):
+            del sp.Spectroscopy_0._ansfm_reference_read_tables
+    z = np.load(os.path.join(golden_dir, "c1_cirsrad.npz"))
+    np.testing.assert_allclose(SPECONV, z["SPECONV"], rtol=1e-10)
+    assert np.array_equal(SPECONV, SPECONV2) and double.file_uploads == 1
+    # a CPU path that needs the numbers still gets them
+    assert np.asarray(fm.SpectroscopyX.K).shape == fm.SpectroscopyX.K.shape
