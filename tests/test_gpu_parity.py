@@ -666,3 +666,29 @@ def test_calc_tau_cia_golden(eng, golden_dir, tag, space):
     scale = np.max(np.abs(ref_d), axis=(0, 1), keepdims=True) + 1e-300
     assert np.max(np.abs(dtau - ref_d) / scale) < 1e-12
     assert np.array_equal(eng.calc_tau_cia(*a, with_grad=False, **kw), tau)
+
+
+def test_lbl_table_batch_with_dedup(eng):
+    """ILBL = LINE_BY_LINE_TABLES in a batch: per-model results equal the single-model calls, with and without layer
+    de-duplication."""
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(14)
+    W, NP, NT, S, L, n = 200, 6, 5, 2, 10, 4
+    PRESS = np.logspace(-6, 1.1, NP); TEMP = np.linspace(80.0, 420.0, NT)
+    K = 10.0 ** rng.uniform(-27, -20, size=(W, NP, NT, S))
+    eng.upload_lbltable(K, PRESS, TEMP, 2000.0 + 0.01 * np.arange(W))
+    atm = syn.synth_atmosphere(L, S, seed=3, n_models=n, perturb=0.04)
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L, 15.0)
+    EMTEMP = atm["lay_temp"][:, LAYINC[:, 0]][:, :, None]
+    args = (0, atm["lay_press_pa"], atm["lay_temp"], atm["amount"], None, NLAYIN, LAYINC, np.repeat(SCALE[None], n, 0), EMTEMP,
+            np.full(n, 200.0))
+    a = eng.cirsrad_ck_thermal(*args)
+    assert eng.last_layer_rows()[0] < n * L
+    eng.set_layer_dedup(False)
+    b = eng.cirsrad_ck_thermal(*args)
+    eng.set_layer_dedup(True)
+    assert np.array_equal(a, b)
+    for m in range(n):
+        one = eng.cirsrad_ck_thermal(0, atm["lay_press_pa"][m], atm["lay_temp"][m], atm["amount"][m], None, NLAYIN, LAYINC, SCALE,
+                                     EMTEMP[m], 200.0)
+        assert np.array_equal(one, a[m])
