@@ -692,3 +692,28 @@ def test_lbl_table_batch_with_dedup(eng):
         one = eng.cirsrad_ck_thermal(0, atm["lay_press_pa"][m], atm["lay_temp"][m], atm["amount"][m], None, NLAYIN, LAYINC, SCALE,
                                      EMTEMP[m], 200.0)
         assert np.array_equal(one, a[m])
+
+
+@pytest.mark.parametrize("ishape", [0, 1, 2])
+def test_lblconv_reference_known_answer(eng, ishape):
+    """Mirror of the reference's own tests/test_measurement_class.py::test_lblconv (:8-79): a Gaussian line on a 0.1 cm-1
+    grid convolved with a FWHM = 1 ILS must agree with numpy.convolve of the same kernel where the signal is >= 1 % of
+    its maximum (the reference asserts rtol = 3e-2; the kernels agree far better away from the grid ends)."""
+    dvx = 0.1
+    vwave = np.arange(0, 50. + dvx, dvx)
+    sig0 = 0.5 * 1.0 / np.sqrt(np.log(2))
+    y = np.exp(-((vwave - 35.) / sig0) ** 2)
+    dy = (y * 0.01)[:, None]
+    fwhm = 1.0
+    yc = eng.lblconv(vwave.size, vwave, y, vwave.size, vwave, ishape, fwhm)
+    yc2, g2 = eng.lblconvg(vwave.size, vwave, y, dy, vwave.size, vwave, ishape, fwhm)
+    half = {0: 0.5 * fwhm, 1: fwhm, 2: 3. * sig0}[ishape]
+    nk = int(round(half / dvx))
+    xk = dvx * np.arange(-nk, nk + 1)
+    kern = {0: np.ones_like(xk), 1: 1.0 - np.abs(xk) / fwhm, 2: np.exp(-(xk / sig0) ** 2)}[ishape]
+    kern = np.where(kern > 0, kern, 0.0); kern /= kern.sum()
+    ynp = np.convolve(y, kern, mode="same")
+    big = yc / yc.max() >= 1.0e-2
+    assert np.allclose(yc[big], ynp[big], rtol=3.0e-2)
+    assert np.allclose(yc2[big], ynp[big], rtol=3.0e-2)
+    np.testing.assert_allclose(g2[big, 0], 0.01 * yc2[big], rtol=1e-12)
