@@ -1,0 +1,58 @@
+"""The reference's own known-answer test for the layering step (tests/test_layer_class.py:12-157), mirrored: the profile
+subprofretg() produces for the Jupiter_test_layer inputs goes through layer_split + layer_average and must match the
+literal arrays from the Fortran NEMESIS code at the reference test's rtol = 1e-2 -- and the reference's own results to
+rounding.  Fixture: oracle/gen_golden_nemesis_layers.py."""
+import os
+import numpy as np
+import pytest
+
+NAMES = ["HEIGHT", "PRESS", "TEMP", "TOTAM", "AMOUNT", "PP", "CONT", "FRAC", "DELH", "BASET", "LAYSF"]
+
+
+def _args(z):
+    kw = dict(LAYANG=float(z["avg_LAYANG"]), LAYINT=int(z["avg_LAYINT"]), LAYHT=float(z["avg_LAYHT"]), NINT=int(z["avg_NINT"]),
+              DUST_UNITS=z["avg_DUST_UNITS"].astype(np.int32), XMOLWT=z["avg_XMOLWT"])
+    return (float(z["avg_RADIUS"]), z["avg_H"], z["avg_P"], z["avg_T"], None, z["avg_VMR"], z["avg_DUST"], None), kw
+
+
+def _check_nemesis(z, BASEH, BASEP, r):
+    L = dict(zip(NAMES, r))
+    assert np.allclose(BASEH / 1.0e3, z["nemesis_BASEH"], rtol=1.0e-2)
+    assert np.allclose(BASEP / 101325., z["nemesis_BASEP"], rtol=1.0e-2)
+    assert np.allclose(L["PRESS"] / 101325., z["nemesis_PRESS"], rtol=1.0e-2)
+    assert np.allclose(L["TEMP"], z["nemesis_TEMP"], rtol=1.0e-2)
+    assert np.allclose(L["TOTAM"] * 1.0e-4, z["nemesis_TOTAM"], rtol=1.0e-2)
+    for j, key in ((0, "AMOUNT0"), (5, "AMOUNT5"), (10, "AMOUNT10")):
+        assert np.allclose(L["AMOUNT"][:, j] * 1.0e-4, z["nemesis_" + key], rtol=1.0e-2), key
+    assert np.allclose(L["CONT"][:, 0] * 1.0e-4, z["nemesis_CONT0"], rtol=1.0e-2)
+
+
+def _split(z):
+    from archnemesis_dist_amd import layers
+    kw = {k[len("split_kw_"):]: z[k] for k in z.files if k.startswith("split_kw_")}
+    return layers.layer_split(float(kw["RADIUS"]), kw["H"], kw["P"], LAYANG=float(kw["LAYANG"]), LAYHT=float(kw["LAYHT"]),
+                              NLAY=int(kw["NLAY"]), LAYTYP=int(kw["LAYTYP"]))
+
+
+def test_oracle_against_nemesis_literals(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "nemesis_layers.npz"))
+    BASEH, BASEP = _split(z)
+    np.testing.assert_allclose(BASEH, z["split_BASEH"], rtol=1e-12)
+    np.testing.assert_allclose(BASEP, z["split_BASEP"], rtol=1e-12)
+    a, kw = _args(z)
+    r = oracle.layer_average(*a, BASEH, BASEP, **kw)
+    _check_nemesis(z, BASEH, BASEP, r)
+    for n, v in zip(NAMES, r):
+        np.testing.assert_allclose(v, z["ref_" + n], rtol=1e-10, atol=1e-300, err_msg=n)
+
+
+@pytest.mark.gpu
+def test_gpu_against_nemesis_literals(golden_dir):
+    import archnemesis_dist_amd as pkg
+    z = np.load(os.path.join(golden_dir, "nemesis_layers.npz"))
+    BASEH, BASEP = _split(z)
+    a, kw = _args(z)
+    r = pkg.AnsfmEngine(0).layer_average(*a, BASEH, BASEP, **kw)
+    _check_nemesis(z, BASEH, BASEP, r)
+    for n, v in zip(NAMES, r):
+        np.testing.assert_allclose(v, z["ref_" + n], rtol=1e-10, atol=1e-300, err_msg=n)
