@@ -56,3 +56,27 @@ def test_gpu_against_nemesis_literals(golden_dir):
     _check_nemesis(z, BASEH, BASEP, r)
     for n, v in zip(NAMES, r):
         np.testing.assert_allclose(v, z["ref_" + n], rtol=1e-10, atol=1e-300, err_msg=n)
+
+
+def test_oracle_layerg_against_nemesis_literals(oracle, golden_dir):
+    """tests/test_layer_class.py:160-310 (calc_pathg -> layer_averageg) pins the same NEMESIS literals."""
+    z = np.load(os.path.join(golden_dir, "nemesis_layers.npz"))
+    BASEH, BASEP = _split(z)
+    a, kw = _args(z)
+    r = oracle.layer_averageg(*a, BASEH, BASEP, **kw)
+    _check_nemesis(z, BASEH, BASEP, r[:11])
+    DTE, DAM = r[11], r[12]
+    np.testing.assert_allclose(DTE.sum(axis=1), 1.0, rtol=1e-10)          # temperature weights of a layer sum to one
+
+
+@pytest.mark.gpu
+def test_gpu_layerg_against_nemesis_literals(oracle, golden_dir):
+    import archnemesis_dist_amd as pkg
+    z = np.load(os.path.join(golden_dir, "nemesis_layers.npz"))
+    BASEH, BASEP = _split(z)
+    a, kw = _args(z)
+    r = pkg.AnsfmEngine(0).layer_averageg(*a, BASEH, BASEP, **kw)
+    _check_nemesis(z, BASEH, BASEP, r[:11])
+    ro = oracle.layer_averageg(*a, BASEH, BASEP, **kw)
+    for i, (v, w) in enumerate(zip(r, ro)):
+        np.testing.assert_allclose(v, w, rtol=1e-10, atol=1e-13 * np.max(np.abs(w)), err_msg=str(i))
