@@ -488,7 +488,8 @@ static int lbl_prep_fwd(ansfm_ctx *ctx, int n_layers, const double *lay_press, c
 static int launch_rt(ansfm_ctx *ctx, const RtParams &p, int n_models)
 {
     dim3 grid((unsigned)(p.Wpad / kWave), (unsigned)p.P, (unsigned)n_models);
-    hipLaunchKernelGGL(k_thermal_rt, grid, dim3(kWave, kGY), 0, ctx->stream, p);
+    if (p.LIMAX > 1500) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: at most 1500 layers along a path");
+    hipLaunchKernelGGL(k_thermal_rt, grid, dim3(kWave, kGY), (size_t)4 * p.LIMAX * sizeof(double), ctx->stream, p);
     HIPCHK(hipGetLastError());
     return ANSFM_OK;
 }

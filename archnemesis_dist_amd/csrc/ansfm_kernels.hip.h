@@ -1301,20 +1301,42 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
     for (int k = 0; k < kGPer; ++k) { taud[k] = 0.0; trold[k] = 1.0; spec[k] = 0.0; }
 
     const size_t pathbase = (size_t)m * p.LIMAX * p.P + ip;
-    for (int j = 0; j < nl; ++j) {
+    // Per-layer metadata of the path (opacity row, SCALE, Planck function at EMTEMP) once into LDS: the layer loop then
+    // has no dependent index -> row -> data chain, and the opacity loads of layer j+1 are issued before layer j is
+    // integrated (the loop is a serial recurrence in the optical depth; without this it runs at memory latency).
+    extern __shared__ double rt_meta[];                 // [3][LIMAX]: row index (as double), scale, B(nu-independent part: T)
+    double *m_row = rt_meta, *m_sc = rt_meta + p.LIMAX, *m_T = rt_meta + 2 * p.LIMAX;
+    for (int j = lane + gy * kWave; j < nl; j += kWave * kGY) {
         const int lay = p.layinc[(size_t)j * p.P + ip];
-        const double sc = p.scale[pathbase + (size_t)j * p.P];
-        const double T = p.emtemp[pathbase + (size_t)j * p.P];
-        const double tc = p.cont ? p.cont[((size_t)m * p.L + lay) * p.Wpad + nu] : 0.0;
-        const double bb = planck_bb(a, c2y, T);
-        const double em = p.emi ? p.emi[(size_t)j * p.Wpad + nu] : 0.0;
-        const size_t trow_i = p.tau_slot ? (size_t)p.tau_slot[(size_t)m * p.L + lay] : (size_t)m * p.L + lay;
-        const double *trow = p.tau + (trow_i * G) * p.Wpad + nu;
+        const size_t ri = p.tau_slot ? (size_t)p.tau_slot[(size_t)m * p.L + lay] : (size_t)m * p.L + lay;
+        m_row[j] = (double)ri;                          // < 2^53, exact
+        m_sc[j] = p.scale[pathbase + (size_t)j * p.P];
+        m_T[j] = p.emtemp[pathbase + (size_t)j * p.P];
+        rt_meta[3 * p.LIMAX + j] = (double)lay;
+    }
+    __syncthreads();
+    const double *m_lay = rt_meta + 3 * p.LIMAX;
+    auto fetch = [&](int j, double tv[kGPer], double &tc, double &em) {
+        const size_t ri = (size_t)m_row[j];
+        const int lay = (int)m_lay[j];
+        const double *trow = p.tau + (ri * G) * p.Wpad + nu;
+        tc = p.cont ? p.cont[((size_t)m * p.L + lay) * p.Wpad + nu] : 0.0;
+        em = p.emi ? p.emi[(size_t)j * p.Wpad + nu] : 0.0;
+#pragma unroll
+        for (int k = 0; k < kGPer; ++k) {
+            const int g = gy + k * kGY;
+            tv[k] = (g < G) ? trow[(size_t)g * p.Wpad] : 0.0;
+        }
+    };
+    double tvA[kGPer], tvB[kGPer], tcA = 0.0, tcB = 0.0, emA = 0.0, emB = 0.0;
+    auto integrate = [&](int j, const double tv[kGPer], double tc, double em) {
+        const double sc = m_sc[j];
+        const double bb = planck_bb(a, c2y, m_T[j]);
 #pragma unroll
         for (int k = 0; k < kGPer; ++k) {
             const int g = gy + k * kGY;
             if (g < G) {
-                const double t = (trow[(size_t)g * p.Wpad] + tc) * sc;  // :3989, :4006
+                const double t = (tv[k] + tc) * sc;  // :3989, :4006
                 taud[k] += t;
                 const double tr = exp(-taud[k]);
                 spec[k] += (trold[k] - tr) * bb;  // :6345-6348
@@ -1322,7 +1344,16 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
                 trold[k] = tr;
             }
         }
+    };
+    if (nl > 0) fetch(0, tvA, tcA, emA);
+    int j = 0;
+    for (; j + 1 < nl; j += 2) {                         // ping-pong buffers: no register rotation
+        fetch(j + 1, tvB, tcB, emB);
+        integrate(j, tvA, tcA, emA);
+        if (j + 2 < nl) fetch(j + 2, tvA, tcA, emA);
+        integrate(j + 1, tvB, tcB, emB);
     }
+    if (j < nl) integrate(j, tvA, tcA, emA);
     // surface / bottom-of-atmosphere term  (:6354-6365)
     int i1 = (int)(nl / 2.0) - 1;
     if (i1 < 0) i1 += nl;
