@@ -38,6 +38,25 @@ def get_engine(device=0):
     return _ENGINES[device]
 
 
+# What the adapter does with a case the GPU path does not cover (another IMOD, a line shape that is not built, an unsorted
+# calculation grid, a non-binary table ...): by default the call goes to the reference's own function -- the reference's
+# code in the reference's process, never a CPU re-implementation of this package -- and is counted in DELEGATED; with
+# set_strict(True) it raises NotImplementedError instead, so a run can prove that nothing left the GPU path.
+STRICT = False
+DELEGATED = {}
+
+
+def set_strict(on=True):
+    global STRICT
+    STRICT = bool(on)
+
+
+def _delegate(what):
+    if STRICT:
+        raise NotImplementedError("ansfm (strict): %s is outside the GPU path and delegation to the reference is off" % what)
+    DELEGATED[what] = DELEGATED.get(what, 0) + 1
+
+
 class KtaTableOnDevice:
     """Stand-in for Spectroscopy.K when the k-table is taken from the .kta files straight into HBM
     (install_gpu_table_reader): knows the files, the wavenumber range and the shape the array would have.  Code that
@@ -200,6 +219,7 @@ class CIRSradGPU:
     # ---- the seam ---------------------------------------------------------------------------------
     def CIRSrad(self, return_grad=False):
         if not self._ansfm_supported(return_grad):
+            _delegate("CIRSrad case (IMOD / ILBL / emissions)")
             base = super()
             if hasattr(base, "CIRSrad"):
                 return base.CIRSrad(return_grad)      # the reference's own implementation, in its process
@@ -264,6 +284,7 @@ def install_gpu_scattering_core(device=0):
             return eng.scloud11wave_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, int(lowbc), brdf_matrix, mu1, wt1,
                                          nf, vwaves, bnu, taus, tauray, omegas_s, nphi, int(iray), int(imie), lfrac)
         except NotImplementedError:
+            _delegate("scloud11wave_core size (nmu > 20 or > 16 paths)")
             return ref_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, lowbc, brdf_matrix, mu1, wt1, nf, vwaves, bnu,
                             taus, tauray, omegas_s, nphi, iray, imie, lfrac)
 
@@ -290,6 +311,7 @@ def install_gpu_line_kernel(device=0):
         ok = (lid is not None and isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous
               and (store is None or (store.dtype == np.float64 and store.flags.c_contiguous)))
         if not ok:
+            _delegate("line shape / buffer layout of add_line_set_monochromatic_absorption")
             return ref_fn(wn_grid, lineshape_fn, t_calc, t_ref, p_calc, p_ref, q_ratio, isotopic_abundance, isotopic_mass,
                           mol_mix_frac, broadening_params, nu, sw, e_lower, stimulated_emission_at_t_ref, out, store, s_floor,
                           wn_calc_window, wn_approx_window)
@@ -368,21 +390,25 @@ def install_gpu_convolution(device=0):
 
     def lblconv(nwave, vwave, y, nconv, vconv, ishape, fwhm):
         if np.ndim(y) != 1 or not _ascending(vwave):
+            _delegate("lblconv on an unsorted grid or several geometries")
             return ref[0](nwave, vwave, y, nconv, vconv, ishape, fwhm)
         return eng.lblconv(nwave, vwave, y, nconv, vconv, int(ishape), fwhm)
 
     def lblconvg(nwave, vwave, y, dydx, nconv, vconv, ishape, fwhm):
         if np.ndim(y) != 1 or np.ndim(dydx) != 2 or not _ascending(vwave):
+            _delegate("lblconvg on an unsorted grid or several geometries")
             return ref[1](nwave, vwave, y, dydx, nconv, vconv, ishape, fwhm)
         return eng.lblconvg(nwave, vwave, y, dydx, nconv, vconv, int(ishape), fwhm)
 
     def lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil):
         if np.ndim(y) != 1 or not _ascending(vwave):
+            _delegate("lblconv_fil on an unsorted grid or several geometries")
             return ref[2](nwave, vwave, y, nconv, vconv, nfil, vfil, afil)
         return eng.lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil)
 
     def lblconvg_fil(nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil):
         if np.ndim(y) != 1 or np.ndim(dydx) != 2 or not _ascending(vwave):
+            _delegate("lblconvg_fil on an unsorted grid or several geometries")
             return ref[3](nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil)
         return eng.lblconvg_fil(nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil)
 
@@ -403,6 +429,7 @@ def install_gpu_continuum(device=0):
 
     def calc_tau_cia(self, ISPACE=None, WAVEC=None, CIA=None, Atmosphere=None, Layer=None, MakePlot=False):
         if MakePlot:
+            _delegate("calc_tau_cia(MakePlot=True)")
             return ref(self, ISPACE, WAVEC, CIA, Atmosphere, Layer, MakePlot)
         ISPACE = int(self.MeasurementX.ISPACE) if ISPACE is None else int(ISPACE)
         WAVEC = self.SpectroscopyX.WAVE if WAVEC is None else WAVEC
@@ -440,6 +467,7 @@ def install_gpu_table_reader(device=0):
         binary = (int(self.ILBL) == ILBL_K_TABLES and self.LOCATION is not None and not getattr(self, "ONLINE", False)
                   and len(self.LOCATION) > 0 and all(str(p).endswith("kta") for p in self.LOCATION))
         if not binary:
+            _delegate("read_tables for tables that are not binary .kta files")
             return ref(self, wavemin, wavemax, wavedelta)
         if self.WAVE is None:
             self.read_header()
