@@ -96,21 +96,12 @@ struct ansfm_ctx {
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline unsigned nblk(size_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
-static void loser_tree_init(int G, unsigned char *init_loser, int *depth)
+// length of the register-resident row-head list of the merge kernels: smallest instantiated size >= G
+static int merge_list_len(int G)
 {
-    // heap layout: internal nodes 1..G-1, leaf y = G + row.  At the start every row's head is
-    // a_row + b_0 and a is ascending, so the winner of any subtree is its smallest row index.
-    int m[2 * kMaxG];
-    for (int y = G; y < 2 * G; ++y) m[y] = y - G;
-    for (int x = 0; x < kMaxG; ++x) init_loser[x] = 0;
-    for (int x = G - 1; x >= 1; --x) {
-        int a = m[2 * x], b = m[2 * x + 1];
-        m[x] = a < b ? a : b;
-        init_loser[x] = (unsigned char)(a < b ? b : a);
-    }
-    int d = 0;
-    for (int x = (2 * G - 1) >> 1; x >= 1; x >>= 1) ++d;
-    *depth = d;
+    static const int sizes[] = {4, 8, 10, 16, 20, 24, 32};
+    for (int v : sizes) if (v >= G) return v;
+    return 32;
 }
 
 extern "C" {
@@ -423,7 +414,6 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     p.tile_counter = reinterpret_cast<unsigned int *>(ctx->d_flag.as<int>() + 4);
     HIPCHK(hipMemsetAsync(p.tile_counter, 0, 8 * sizeof(unsigned int), ctx->stream));
     p.W = W; p.Wpad = Wpad; p.G = G; p.NT = ctx->NT; p.S = S; p.L = L; p.n_models = n_models;
-    loser_tree_init(G, p.init_loser, &p.depth);
     p.delg_f32 = ctx->delg_f32;
     {   // g_ord = [0, cumsum(del_g)], g_ord[ng] = 1 (ForwardModel_0.py:6141-6143); float32 cumsum when DELG is
         double acc = 0.0;
@@ -436,7 +426,7 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
         p.g_ord[G] = 1.0;
         p.g_ord[G + 1] = __builtin_inf();
     }
-    const size_t lds = (size_t)(3 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) +
+    const size_t lds = (size_t)(2 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) +
                        (sorted ? 0 : (size_t)2 * G * kWave);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
@@ -459,23 +449,18 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     do {                                                                                              \
         if (ctx->delg_f32) LAUNCH_OV2(D, FK, true); else LAUNCH_OV2(D, FK, false);                    \
     } while (0)
-    if (from_k) {
-        switch (p.depth) {
-            case 1: LAUNCH_OV(1, true); break;
-            case 2: LAUNCH_OV(2, true); break;
-            case 3: LAUNCH_OV(3, true); break;
-            case 4: LAUNCH_OV(4, true); break;
-            default: LAUNCH_OV(5, true); break;
-        }
-    } else {
-        switch (p.depth) {
-            case 1: LAUNCH_OV(1, false); break;
-            case 2: LAUNCH_OV(2, false); break;
-            case 3: LAUNCH_OV(3, false); break;
-            case 4: LAUNCH_OV(4, false); break;
-            default: LAUNCH_OV(5, false); break;
-        }
+#define LAUNCH_OVN(FK)                                                \
+    switch (merge_list_len(G)) {                                      \
+        case 4: LAUNCH_OV(4, FK); break;                              \
+        case 8: LAUNCH_OV(8, FK); break;                              \
+        case 10: LAUNCH_OV(10, FK); break;                            \
+        case 16: LAUNCH_OV(16, FK); break;                            \
+        case 20: LAUNCH_OV(20, FK); break;                            \
+        case 24: LAUNCH_OV(24, FK); break;                            \
+        default: LAUNCH_OV(32, FK); break;                            \
     }
+    if (from_k) { LAUNCH_OVN(true); } else { LAUNCH_OVN(false); }
+#undef LAUNCH_OVN
 #undef LAUNCH_OV
 #undef LAUNCH_OV2
     HIPCHK(hipGetLastError());
@@ -900,7 +885,6 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     p.tau = tau;
     p.err_flag = ctx->d_flag.as<int>() + 1;
     p.W = W; p.Wpad = Wpad; p.G = G; p.NT = ctx->NT; p.S = S; p.L = L; p.n_models = n_models;
-    loser_tree_init(G, p.init_loser, &p.depth);
     p.delg_f32 = ctx->delg_f32;
     {
         double acc = 0.0;
@@ -940,13 +924,15 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
         else                                                                                                        \
             hipLaunchKernelGGL((k_ck_overlapg<D, FK, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg); \
     } while (0)
-#define LAUNCH_OVG_D(FK)                                                                                            \
-    switch (p.depth) {                                                                                              \
-    case 1: LAUNCH_OVG(1, FK); break;                                                                               \
-    case 2: LAUNCH_OVG(2, FK); break;                                                                               \
-    case 3: LAUNCH_OVG(3, FK); break;                                                                               \
-    case 4: LAUNCH_OVG(4, FK); break;                                                                               \
-    default: LAUNCH_OVG(5, FK); break;                                                                              \
+#define LAUNCH_OVG_D(FK)                                              \
+    switch (merge_list_len(G)) {                                      \
+        case 4: LAUNCH_OVG(4, FK); break;                             \
+        case 8: LAUNCH_OVG(8, FK); break;                             \
+        case 10: LAUNCH_OVG(10, FK); break;                           \
+        case 16: LAUNCH_OVG(16, FK); break;                           \
+        case 20: LAUNCH_OVG(20, FK); break;                           \
+        case 24: LAUNCH_OVG(24, FK); break;                           \
+        default: LAUNCH_OVG(32, FK); break;                           \
     }
     if (from_k) { LAUNCH_OVG_D(true); } else { LAUNCH_OVG_D(false); }
 #undef LAUNCH_OVG_D

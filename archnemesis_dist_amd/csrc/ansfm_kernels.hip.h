@@ -231,9 +231,8 @@ struct OverlapParams {
     double *scratch;          // [gridDim.x][2][G][64]
     int *err_flag;            // bit0: unsorted input k-distribution
     unsigned int *tile_counter;  // [8] dynamic tile queues, one per XCD (zeroed before every launch)
-    int W, Wpad, G, NT, S, L, n_models, depth;
+    int W, Wpad, G, NT, S, L, n_models;
     int delg_f32;             // DELG is a float32 array: del_g[i]*del_g[j] is a float32 product
-    unsigned char init_loser[kMaxG];
     double g_ord[kMaxG + 2];  // [0, cumsum(del_g)] (float32 cumsum when delg_f32), g_ord[G]=1, +inf
 };
 
@@ -327,29 +326,24 @@ __device__ __forceinline__ double fast_div(double n, double d)
     return fma(fma(-d, q, n), r, q);
 }
 
-// One popped element of the merge with everything the replay and the rank walk need, fetched from LDS
-// as soon as the winner key is known (software pipelining: the walk of element t runs while the
-// operands of element t+1 are in flight).
-// LDS accessed through 32-bit byte addresses (address space 3): a tree-path node costs two integer instructions
-// (bit-field extract, shift-add onto the lane's base) and the same register serves the write-back.
+// One popped element of the merge with everything the rank walk and the row's next key need, fetched from LDS
+// as soon as the winner key is known (software pipelining: the walk of element t and the rest of the insertion
+// pass run while the operands of element t+1 are in flight).
 typedef __attribute__((address_space(3))) double lds_double;
 __device__ __forceinline__ unsigned lds_addr(const double *p) { return (unsigned)(size_t)(const lds_double *)p; }
 __device__ __forceinline__ double lds_ld(unsigned a) { return *(const lds_double *)(size_t)a; }
 __device__ __forceinline__ void lds_st(unsigned a, double v) { *(lds_double *)(size_t)a = v; }
 
-template <int DEPTH>
 struct MergeElem {
     double ai, bc, bn, w;
-    double tv[DEPTH];
-    unsigned off[DEPTH];   // LDS byte addresses of the tree path (re-used for the write-back)
     int ci, np;
 };
 
 // SORTED = false (generic path): the rows / columns were sorted per lane beforehand; PA / PB give the original
 // g-ordinate of each sorted position, which is the one whose weight applies.
-template <int DEPTH, bool W32, bool SORTED = true>
-__device__ __forceinline__ void merge_fetch(double key, int G, int lane, const double *A, const double *B,
-                                            const double *NV, const double *DG, MergeElem<DEPTH> &e,
+template <bool W32, bool SORTED = true>
+__device__ __forceinline__ void merge_fetch(double key, int lane, const double *A, const double *B,
+                                            const double *DG, MergeElem &e,
                                             const unsigned char *PA = nullptr, const unsigned char *PB = nullptr)
 {
     const unsigned kb = (unsigned)__double_as_longlong(key);
@@ -364,15 +358,6 @@ __device__ __forceinline__ void merge_fetch(double key, int G, int lane, const d
     else w = DG[PA[ci * kWave + lane]] * DG[PB[cp * kWave + lane]];
     if constexpr (W32) w = (double)(float)w;     // -> the float32 product NumPy forms (DELG float32)
     e.w = w;
-    const unsigned t = (unsigned)(G + ci);
-    const unsigned nvl = lds_addr(NV + lane);
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-        unsigned node;                                                        // (G+ci) >> (d+1); asm keeps it one v_bfe
-        asm("v_bfe_u32 %0, %1, %2, 6" : "=v"(node) : "v"(t), "n"(d + 1));      // (the compiler expands it to shl+and)
-        e.off[d] = (node << 9) + nvl;                                         // rows of 512 bytes: one v_lshl_add
-        e.tv[d] = lds_ld(e.off[d]);
-    }
 }
 
 // keys: value with the low 11 mantissa bits = (col << 5) | row   (col <= 32, row <= 31)
@@ -391,8 +376,8 @@ struct WalkState {
     int ig;
 };
 
-template <int DEPTH, bool REC_CODE>
-__device__ __forceinline__ bool merge_walk(const MergeElem<DEPTH> &e, WalkState &ws, double *rec, const double *GORD,
+template <bool REC_CODE>
+__device__ __forceinline__ bool merge_walk(const MergeElem &e, WalkState &ws, double *rec, const double *GORD,
                                            int lane)
 {
     const double cv = e.ai + e.bc;
@@ -416,28 +401,50 @@ __device__ __forceinline__ bool merge_walk(const MergeElem<DEPTH> &e, WalkState 
     return cross;
 }
 
+// The heads of the G rows are kept as a SORTED LIST IN REGISTERS (R[0] = the current winner): popping is free and the
+// row's next key is inserted by one pass of v_max_f64 + v_min_f64 pairs over statically indexed
+// registers -- no tree in LDS, no lane-dependent addressing, and the next winner is known after the FIRST
+// compare-exchange, so its operands' LDS reads are hidden behind the rest of the pass and the walk.  NR = list length
+// (compile time, >= G; unused entries hold "huge" keys).
 // Returns the consumed element's (row, column) and whether it closed a bin, as 16 bits: the gradient kernel
 // records them and replays the sorted order for the gradient rows.
-template <int DEPTH, bool W32, bool REC_CODE = false, bool SORTED = true>
-__device__ __forceinline__ unsigned merge_step(MergeElem<DEPTH> &e, MergeElem<DEPTH> &en, WalkState &ws, int G,
-                                               int lane, const double *A, const double *B, double *NV,
+template <int NR, bool W32, bool REC_CODE = false, bool SORTED = true>
+__device__ __forceinline__ unsigned merge_step(double (&R)[NR], MergeElem &e, MergeElem &en, WalkState &ws,
+                                               int lane, const double *A, const double *B,
                                                const double *DG, const double *GORD, double *rec,
                                                const unsigned char *PA = nullptr, const unsigned char *PB = nullptr)
 {
-    // 1. replay the tree path of the popped leaf with the row's next element
-    double car = pack_key11(e.ai + e.bn, e.ci, e.np);
+    // 1. the popped row's next element x enters the list s_1 <= s_2 <= ... (s_0 was popped):
+    //        t_0 = min(x, s_1),   t_k = min(max(x, s_k), s_{k+1}),   t_{NR-1} = max(x, s_{NR-1})
+    //    -- every output independent of the others (no carry chain), in place in ascending k.
+    const double x = pack_key11(e.ai + e.bn, e.ci, e.np);
+    asm("v_min_f64 %0, %1, %2" : "=v"(R[0]) : "v"(x), "v"(R[1]));
+    // 2. fetch the operands of the new winner (LDS reads in flight during the rest of the pass and the walk)
+    merge_fetch<W32, SORTED>(R[0], lane, A, B, DG, en, PA, PB);
+    // 3. finish the insertion (maxes and mins in blocks, so no result is consumed by the next instruction)
+    constexpr int kBlk = 6;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-        double lo, hi;
-        minmax_f64(e.tv[d], car, lo, hi);
-        lds_st(e.off[d], hi);
-        car = lo;
+    for (int k0 = 1; k0 < NR - 1; k0 += kBlk) {
+        double mk[kBlk];
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j)
+            if (k0 + j < NR - 1) asm("v_max_f64 %0, %1, %2" : "=v"(mk[j]) : "v"(x), "v"(R[k0 + j]));
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j)
+            if (k0 + j < NR - 1) asm("v_min_f64 %0, %1, %2" : "=v"(R[k0 + j]) : "v"(mk[j]), "v"(R[k0 + j + 1]));
     }
-    // 2. fetch the operands of the new winner (LDS reads in flight during the walk)
-    merge_fetch<DEPTH, W32, SORTED>(car, G, lane, A, B, NV, DG, en, PA, PB);
-    // 3. rank walk on the element just consumed
-    const bool cross = merge_walk<DEPTH, REC_CODE>(e, ws, rec, GORD, lane);
+    asm("v_max_f64 %0, %1, %2" : "=v"(R[NR - 1]) : "v"(x), "v"(R[NR - 1]));
+    // 4. rank walk on the element just consumed
+    const bool cross = merge_walk<REC_CODE>(e, ws, rec, GORD, lane);
     return (unsigned)(e.ci | ((e.np - 1) << 5) | (cross ? 0x8000 : 0));
+}
+
+// R[i] = head of row i = a_i + b_0: ascending in i because a is (fast path: by precondition; generic: sorted first).
+template <int NR>
+__device__ __forceinline__ void merge_init(double (&R)[NR], int G, int lane, const double *A, double b0, double huge)
+{
+#pragma unroll
+    for (int i = 0; i < NR; ++i) R[i] = (i < G) ? pack_key11(A[(i < G ? i : 0) * kWave + lane] + b0, i, 0) : huge;
 }
 
 // Dynamic tile queues.  With 5 resident waves per CU one SIMD hosts two waves that run slower than the solo
@@ -501,7 +508,7 @@ __device__ __forceinline__ void sort_column(double *X, unsigned char *P, int G, 
 // (product, weight) is unchanged, so rank()'s walk sees the same sequence up to the order of exact ties -- and the
 // skip rules keep looking at the LAST g-ordinate in the original order (:6075-6102).  A spectrum that passes through
 // unmerged comes out in its original order.
-template <int DEPTH, bool FROM_K, bool W32, bool SORTED = true>
+template <int NR, bool FROM_K, bool W32, bool SORTED = true>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_ck_overlap(OverlapParams p)
 {
     extern __shared__ double smem[];
@@ -509,8 +516,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     const int G = p.G;
     double *A = smem;
     double *B = A + G * kWave;                   // G+1 rows
-    double *NV = B + (G + 1) * kWave;
-    double *DG = NV + G * kWave;
+    double *DG = B + (G + 1) * kWave;
     double *GORD = DG + kMaxG;
     unsigned char *PA = reinterpret_cast<unsigned char *>(GORD + kMaxG + 2);     // SORTED = false only
     unsigned char *PB = PA + G * kWave;
@@ -556,23 +562,19 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 }
             }
             if (do_merge) {
-                // ---- loser tree over the G rows (row i = a_i + b_j, j ascending) ----------------
-                const double b0 = B[lane];
-                for (int x = 1; x < G; ++x) {
-                    const int row = p.init_loser[x];
-                    NV[x * kWave + lane] = pack_key11(A[row * kWave + lane] + b0, row, 0);
-                }
-                NV[lane] = HUGE_KEY;  // node 0: dummy level for the shallower leaves
-                MergeElem<DEPTH> e0, e1;
-                merge_fetch<DEPTH, W32, SORTED>(pack_key11(A[lane] + b0, 0, 0), G, lane, A, B, NV, DG, e0, PA, PB);
+                // ---- sorted list of the G row heads (row i = a_i + b_j, j ascending) -------------
+                double R[NR];
+                merge_init<NR>(R, G, lane, A, B[lane], HUGE_KEY);
+                MergeElem e0, e1;
+                merge_fetch<W32, SORTED>(R[0], lane, A, B, DG, e0, PA, PB);
                 WalkState ws{0.0, 0.0, 0.0, GORD[1], 0};
                 const int nloop = G * G;
                 int it = 0;
                 for (; it + 1 < nloop; it += 2) {   // ping-pong: no register rotation
-                    merge_step<DEPTH, W32, false, SORTED>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec, PA, PB);
-                    merge_step<DEPTH, W32, false, SORTED>(e1, e0, ws, G, lane, A, B, NV, DG, GORD, rec, PA, PB);
+                    merge_step<NR, W32, false, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    merge_step<NR, W32, false, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
                 }
-                if (it < nloop) merge_step<DEPTH, W32, false, SORTED>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec, PA, PB);
+                if (it < nloop) merge_step<NR, W32, false, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
                 // ---- resolve the bins --------------------------------------------------------------------
                 double ck = 0.0, cs = 0.0;   // (1-frac) share carried into the next bin
                 const int ig = ws.ig;
@@ -831,7 +833,7 @@ __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const doub
     }
 }
 
-template <int DEPTH, bool FROM_K, bool W32>
+template <int NR, bool FROM_K, bool W32>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_ck_overlapg(OverlapGParams pg)
 {
     const OverlapParams &p = pg.o;
@@ -908,30 +910,26 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
             } else {
                 // ---- the forward merge, recording the order -------------------------------------------------
                 B[G * kWave + lane] = HUGE_KEY;
-                const double b0 = B[lane];
-                for (int x = 1; x < G; ++x) {
-                    const int row = p.init_loser[x];
-                    NV[x * kWave + lane] = pack_key11(A[row * kWave + lane] + b0, row, 0);
-                }
-                NV[lane] = HUGE_KEY;
-                MergeElem<DEPTH> e0, e1;
-                merge_fetch<DEPTH, W32>(pack_key11(A[lane] + b0, 0, 0), G, lane, A, B, NV, DG, e0);
+                double R[NR];
+                merge_init<NR>(R, G, lane, A, B[lane], HUGE_KEY);
+                MergeElem e0, e1;
+                merge_fetch<W32>(R[0], lane, A, B, DG, e0);
                 WalkState ws{0.0, 0.0, 0.0, GORD[1], 0};
                 unsigned long long *pw = perm + lane;
                 int it = 0;
                 for (; it + 3 < nloop; it += 4) {
-                    const unsigned long long c0 = merge_step<DEPTH, W32, true>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec);
-                    const unsigned long long c1 = merge_step<DEPTH, W32, true>(e1, e0, ws, G, lane, A, B, NV, DG, GORD, rec);
-                    const unsigned long long c2 = merge_step<DEPTH, W32, true>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec);
-                    const unsigned long long c3 = merge_step<DEPTH, W32, true>(e1, e0, ws, G, lane, A, B, NV, DG, GORD, rec);
+                    const unsigned long long c0 = merge_step<NR, W32, true>(R, e0, e1, ws, lane, A, B, DG, GORD, rec);
+                    const unsigned long long c1 = merge_step<NR, W32, true>(R, e1, e0, ws, lane, A, B, DG, GORD, rec);
+                    const unsigned long long c2 = merge_step<NR, W32, true>(R, e0, e1, ws, lane, A, B, DG, GORD, rec);
+                    const unsigned long long c3 = merge_step<NR, W32, true>(R, e1, e0, ws, lane, A, B, DG, GORD, rec);
                     *pw = c0 | (c1 << 16) | (c2 << 32) | (c3 << 48);
                     pw += kWave;
                 }
                 if (it < nloop) {   // G*G not a multiple of 4: a partial last word
                     unsigned long long word = 0;
                     for (int k = 0; it < nloop; ++it, ++k) {
-                        const unsigned long long c = (k & 1) ? merge_step<DEPTH, W32, true>(e1, e0, ws, G, lane, A, B, NV, DG, GORD, rec)
-                                                             : merge_step<DEPTH, W32, true>(e0, e1, ws, G, lane, A, B, NV, DG, GORD, rec);
+                        const unsigned long long c = (k & 1) ? merge_step<NR, W32, true>(R, e1, e0, ws, lane, A, B, DG, GORD, rec)
+                                                             : merge_step<NR, W32, true>(R, e0, e1, ws, lane, A, B, DG, GORD, rec);
                         word |= c << (16 * k);
                     }
                     *pw = word;
