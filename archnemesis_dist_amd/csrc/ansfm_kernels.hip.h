@@ -339,6 +339,19 @@ struct MergeElem {
     int ci, np;
 };
 
+// Weight of element (i, j) = del_g[i] * del_g[j].  DELG float32 (W32): NumPy forms the float32 product, which is one
+// v_mul_f32 of the float32 copies kept behind the double tables (DG, GORD) in LDS.
+__device__ __forceinline__ const float *delg_f32_table(const double *DG) { return reinterpret_cast<const float *>(DG + 2 * kMaxG + 2); }
+template <bool W32>
+__device__ __forceinline__ double pair_weight(const double *DG, int i, int j)
+{
+    if constexpr (W32) {
+        const float *DGF = delg_f32_table(DG);
+        return (double)(DGF[i] * DGF[j]);
+    } else
+        return DG[i] * DG[j];
+}
+
 // SORTED = false (generic path): the rows / columns were sorted per lane beforehand; PA / PB give the original
 // g-ordinate of each sorted position, which is the one whose weight applies.
 template <bool W32, bool SORTED = true>
@@ -351,13 +364,11 @@ __device__ __forceinline__ void merge_fetch(double key, int lane, const double *
     e.ci = ci;
     e.np = cp + 1;
     e.ai = A[ci * kWave + lane];
-    e.bc = B[cp * kWave + lane];
-    e.bn = B[(cp + 1) * kWave + lane];          // B[G] = sentinel column: an exhausted row re-enters as "huge"
-    double w;
-    if constexpr (SORTED) w = DG[ci] * DG[cp];   // exact in double when both are float32 values
-    else w = DG[PA[ci * kWave + lane]] * DG[PB[cp * kWave + lane]];
-    if constexpr (W32) w = (double)(float)w;     // -> the float32 product NumPy forms (DELG float32)
-    e.w = w;
+    const unsigned ab = lds_addr(B + lane) + ((unsigned)cp << 9);
+    e.bc = lds_ld(ab);
+    e.bn = lds_ld(ab + 512);                    // B[G] = sentinel column: an exhausted row re-enters as "huge"
+    if constexpr (SORTED) e.w = pair_weight<W32>(DG, ci, cp);
+    else e.w = pair_weight<W32>(DG, PA[ci * kWave + lane], PB[cp * kWave + lane]);
 }
 
 // keys: value with the low 11 mantissa bits = (col << 5) | row   (col <= 32, row <= 31)
@@ -518,9 +529,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     double *B = A + G * kWave;                   // G+1 rows
     double *DG = B + (G + 1) * kWave;
     double *GORD = DG + kMaxG;
-    unsigned char *PA = reinterpret_cast<unsigned char *>(GORD + kMaxG + 2);     // SORTED = false only
+    unsigned char *PA = reinterpret_cast<unsigned char *>(GORD + kMaxG + 2) + kMaxG * sizeof(float);   // SORTED = false only
     unsigned char *PB = PA + G * kWave;
-    if (lane < G) DG[lane] = p.del_g[lane];
+    if (lane < G) {
+        DG[lane] = p.del_g[lane];
+        const_cast<float *>(delg_f32_table(DG))[lane] = (float)p.del_g[lane];
+    }
     if (lane < G + 2) GORD[lane] = p.g_ord[lane];
     const double HUGE_KEY = __longlong_as_double(0x7FE0000000000000LL);   // finite, above any optical depth
     B[G * kWave + lane] = HUGE_KEY;
@@ -746,13 +760,12 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
     int bo = lane;                                  // b * 64 + lane
     // four steps of one code word: all LDS operands first (one LDS round trip per word), then the dependent part
     auto group = [&](unsigned long long word, int nst) {
-        double g[4], wr[4], wc[4];
+        double g[4], wr[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned code = (unsigned)(word >> (16 * k)) & 0xFFFFu;
             const int row = code & 31, col = (code >> 5) & 31;
-            wr[k] = DG[row];
-            wc[k] = DG[col];
+            wr[k] = pair_weight<W32>(DG, row, col);
             g[k] = SL0[row * kWave + lane];
             if constexpr (DUAL) g[k] += SL1[col * kWave + lane];
         }
@@ -760,8 +773,7 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
         for (int k = 0; k < 4; ++k) {
             if (k < nst) {
                 const bool cross = ((word >> (16 * k + 15)) & 1ULL) != 0;
-                double w = wr[k] * wc[k];
-                if constexpr (W32) w = (double)(float)w;
+                const double w = wr[k];
                 OUTL[bo] = acc;
                 const double an = acc + g[k] * w;
                 acc = cross ? 0.0 : an;
@@ -846,7 +858,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     double *NV = B + (G + 1) * kWave;
     double *DG = NV + G * kWave;
     double *GORD = DG + kMaxG;
-    if (lane < G) DG[lane] = p.del_g[lane];
+    if (lane < G) {
+        DG[lane] = p.del_g[lane];
+        const_cast<float *>(delg_f32_table(DG))[lane] = (float)p.del_g[lane];
+    }
     if (lane < G + 2) GORD[lane] = p.g_ord[lane];
     const double HUGE_KEY = __longlong_as_double(0x7FE0000000000000LL);
     __syncthreads();
