@@ -901,7 +901,7 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     pg.dk = dk;
     const int NP1 = S + 1;
     if (NP1 > 21) FAIL(ANSFM_ERR_UNSUPPORTED, "gradient path supports at most 20 spectroscopic gases");
-    const size_t lds = (size_t)(3 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) + kMaxG * sizeof(float);
+    const size_t lds = (size_t)(2 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) + kMaxG * sizeof(float);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;

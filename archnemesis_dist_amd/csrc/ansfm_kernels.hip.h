@@ -747,14 +747,15 @@ __device__ __forceinline__ void stage_slice(double *dst_lds, const double *__res
     }
 }
 
-// Replay of the recorded order for one gathered vector: SL0[row], or (DUAL, the temperature slot)
-// SL0[row] + SL1[col].  Store-free and branch-free: the running sum is written every step to the LDS row of
+// Replay of the recorded order for one gathered vector: SL[row] (slots of the earlier gases, row part of the
+// temperature slot) or, COL, SL[col] (the new gas's slot, column part of the temperature slot).
+// Store-free and branch-free: the running sum is written every step to the LDS row of
 // the lane's current bin, so each row ends up holding the sum before the element that closed the bin; global
 // stores inside this loop would sit in front of the code-word loads in the (in-order) vmcnt queue.
 // OUTL has G+1 rows (row G collects what follows the last bin).  Returns the sum after the last boundary.
-template <bool DUAL, bool W32>
+template <bool COL, bool W32>
 __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigned long long *__restrict__ perm,
-                                              const double *SL0, const double *SL1, double *OUTL, const double *DG)
+                                              const double *SL, double *OUTL, const double *DG)
 {
     double acc = 0.0;
     int bo = lane;                                  // b * 64 + lane
@@ -766,8 +767,7 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
             const unsigned code = (unsigned)(word >> (16 * k)) & 0xFFFFu;
             const int row = code & 31, col = (code >> 5) & 31;
             wr[k] = pair_weight<W32>(DG, row, col);
-            g[k] = SL0[row * kWave + lane];
-            if constexpr (DUAL) g[k] += SL1[col * kWave + lane];
+            g[k] = SL[(COL ? col : row) * kWave + lane];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -811,19 +811,22 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
 }
 
 // deferred bin boundaries of one replayed vector: rec[b] = (frac, 1/weight-sum, -, w, -, code) from the merge
-template <bool DUAL>
+// ACCUM: the column part of the temperature slot is added to the row part already in OUT.
+template <bool COL, bool ACCUM>
 __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const double *__restrict__ rec,
-                                             const double *SL0, const double *SL1, const double *OUTL, double tail,
+                                             const double *SL, const double *OUTL, double tail,
                                              double *__restrict__ OUT)
 {
     double carry = 0.0;
     constexpr int kRB = 5;
     for (int b0 = 0; b0 < G; b0 += kRB) {
-        double rfr[kRB], rri[kRB], rw[kRB], rcd[kRB];
+        double rfr[kRB], rri[kRB], rw[kRB], rcd[kRB], rold[kRB];
 #pragma unroll
         for (int k = 0; k < kRB; ++k) {
-            const double *rp = rec + (size_t)((b0 + k < G) ? b0 + k : G - 1) * 6 * kWave + lane;
+            const int bi = (b0 + k < G) ? b0 + k : G - 1;
+            const double *rp = rec + (size_t)bi * 6 * kWave + lane;
             rfr[k] = rp[0]; rri[k] = rp[kWave]; rw[k] = rp[3 * kWave]; rcd[k] = rp[5 * kWave];
+            if constexpr (ACCUM) rold[k] = OUT[bi * kWave + lane];
         }
 #pragma unroll
         for (int k = 0; k < kRB; ++k) {
@@ -832,13 +835,13 @@ __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const doub
                 double v = 0.0;
                 if (b < ig) {
                     const unsigned code = (unsigned)__double_as_longlong(rcd[k]);
-                    double g = SL0[(code & 31) * kWave + lane];
-                    if constexpr (DUAL) g += SL1[((code >> 5) & 31) * kWave + lane];
+                    const double g = SL[(COL ? ((code >> 5) & 31) : (code & 31)) * kWave + lane];
                     const double gw = g * rw[k];
                     v = ((carry + OUTL[b * kWave + lane]) + rfr[k] * gw) * rri[k];
                     carry = (1.0 - rfr[k]) * gw;
                 } else if (b == ig)
                     v = (carry + tail) * rri[k];
+                if constexpr (ACCUM) v += rold[k];
                 OUT[b * kWave + lane] = v;
             }
         }
@@ -855,8 +858,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     const int NP1 = p.S + 1;
     double *A = smem;
     double *B = A + G * kWave;                   // G+1 rows
-    double *NV = B + (G + 1) * kWave;
-    double *DG = NV + G * kWave;
+    double *DG = B + (G + 1) * kWave;
     double *GORD = DG + kMaxG;
     if (lane < G) {
         DG[lane] = p.del_g[lane];
@@ -987,26 +989,25 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                         }
                     }
                 }
-                // ---- replay, one slot per pass: slices in A / NV, bin sums in B (G+1 rows) ------------------
-                {   // temperature slot: D_old[igas+1][row] + dkdT_new[col]*amount
+                // ---- replay, one gathered vector per pass: the vector in A, bin sums in B (G+1 rows) ---------
+                {   // temperature slot: D_old[igas+1][row] + dkdT_new[col]*amount, as a row pass plus a column pass
+                    double *DT = Dnew + (size_t)(igas + 2) * GW;
                     stage_slice(A, Dold + (size_t)(igas + 1) * GW, G, lane);
-                    stage_slice(NV, DTB, G, lane);
-                    const double tail = grad_replay<true, W32>(nloop, lane, perm, A, NV, B, DG);
-                    grad_resolve<true>(G, lane, ig, rec, A, NV, B, tail, Dnew + (size_t)(igas + 2) * GW);
+                    double tail = grad_replay<false, W32>(nloop, lane, perm, A, B, DG);
+                    grad_resolve<false, false>(G, lane, ig, rec, A, B, tail, DT);
+                    stage_slice(A, DTB, G, lane);
+                    tail = grad_replay<true, W32>(nloop, lane, perm, A, B, DG);
+                    grad_resolve<true, true>(G, lane, ig, rec, A, B, tail, DT);
                 }
-                for (int pp = 0; pp <= igas + 1; ++pp) {
-                    // pp <= igas: D_old[pp][row];  pp == igas+1: k_new[col] (col gather = DUAL with a zero row part)
-                    const bool colsrc = (pp == igas + 1);
-                    const double *src = colsrc ? KRB : Dold + (size_t)pp * GW;
-                    stage_slice(colsrc ? NV : A, src, G, lane);
-                    if (colsrc) {
-                        for (int g = 0; g < G; ++g) A[g * kWave + lane] = 0.0;
-                        const double tail = grad_replay<true, W32>(nloop, lane, perm, A, NV, B, DG);
-                        grad_resolve<true>(G, lane, ig, rec, A, NV, B, tail, Dnew + (size_t)pp * GW);
-                    } else {
-                        const double tail = grad_replay<false, W32>(nloop, lane, perm, A, A, B, DG);
-                        grad_resolve<false>(G, lane, ig, rec, A, A, B, tail, Dnew + (size_t)pp * GW);
-                    }
+                {   // the new gas's slot: k_new[col]
+                    stage_slice(A, KRB, G, lane);
+                    const double tail = grad_replay<true, W32>(nloop, lane, perm, A, B, DG);
+                    grad_resolve<true, false>(G, lane, ig, rec, A, B, tail, Dnew + (size_t)(igas + 1) * GW);
+                }
+                for (int pp = 0; pp <= igas; ++pp) {   // earlier gases: D_old[pp][row]
+                    stage_slice(A, Dold + (size_t)pp * GW, G, lane);
+                    const double tail = grad_replay<false, W32>(nloop, lane, perm, A, B, DG);
+                    grad_resolve<false, false>(G, lane, ig, rec, A, B, tail, Dnew + (size_t)pp * GW);
                 }
                 for (int pp = n; pp < NP1; ++pp)
                     for (int g = 0; g < G; ++g) Dnew[(size_t)pp * GW + g * kWave + lane] = 0.0;
