@@ -223,7 +223,7 @@ def main():
     roof = {"bound": "hbm", "kernel": "k_ck_overlap", "achieved": abytes / ov / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": abytes / ov / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": abytes, "kernel_ms": ov * 1e3, "rt_kernel_ms": float(np.mean(rt_ms)),
-            "note": "second bound (LDS/VALU of the in-LDS G-way merge) dominates; see DESIGN.md"}
+            "note": "second bound (fp64 VALU of the per-lane G-way merge, kernel at ~71% of it) dominates; see DESIGN.md 4.1"}
 
     # ---- CPU baseline: the oracle (port) on a bounded sample, rank 0 only ---------------------------------
     cpu = None
