@@ -1273,15 +1273,16 @@ int ansfm_map2xvec(ansfm_ctx *ctx, int W, int NPAR, int NPRO, int P, int NX, con
 
 
 /* ------------------------------------------------------------------------------------------ */
-/* ILS convolution (Measurement_0.lblconv / lblconvg / lblconv_fil / lblconvg_fil)             */
+/* ILS convolution (Measurement_0.lblconv / lblconvg / lblconv_fil / lblconvg_fil, *_ngeom)    */
 /* ------------------------------------------------------------------------------------------ */
-static int ils_conv_impl(ansfm_ctx *ctx, int nwave, const double *vwave, const double *y, int nx, const double *dydx,
-                         int nconv, const double *vconv, int ishape, double fwhm, int grad_rules, int nfilmax,
-                         const int32_t *nfil, const double *vfil, const double *afil, double *yout, double *gradout)
+static int ils_conv_impl(ansfm_ctx *ctx, int nwave, const double *vwave, int ny, const double *y, int nx, const double *dydx,
+                         int nconv, const double *vconv, int ishape, double fwhm, int hamming_rule, int nfilmax,
+                         const int32_t *nfil, const double *vfil, const double *afil, double *yout, double *gradout,
+                         bool bracket = false)
 {
     CHECK_CTX(ctx);
     const bool filter = nfil != nullptr;
-    if (nwave <= 0 || nconv <= 0 || nx < 0 || !vwave || !y || !vconv || !yout || (nx > 0 && (!dydx || !gradout)) ||
+    if (nwave <= 0 || nconv <= 0 || nx < 0 || ny <= 0 || !vwave || !y || !vconv || !yout || (nx > 0 && (!dydx || !gradout)) ||
         (filter && (!vfil || !afil || nfilmax < 2)))
         FAIL(ANSFM_ERR_INVALID, "lblconv: bad argument");
     for (int i = 1; i < nwave; ++i)
@@ -1292,13 +1293,16 @@ static int ils_conv_impl(ansfm_ctx *ctx, int nwave, const double *vwave, const d
             for (int k = 1; k < nfil[j]; ++k)
                 if (!(vfil[(size_t)k * nconv + j] > vfil[(size_t)(k - 1) * nconv + j]))
                     FAIL(ANSFM_ERR_UNSORTED, "lblconv_fil: filter wavenumbers must be strictly ascending");
+            if (bracket && (!(vwave[0] < vfil[j]) || !(vwave[nwave - 1] > vfil[(size_t)(nfil[j] - 1) * nconv + j])))
+                FAIL(ANSFM_ERR_INVALID, "conv: every filter must lie strictly inside the calculation grid (the reference "
+                                        "raises IndexError otherwise)");
         }
     HIPCHK(hipSetDevice(ctx->device));
     const size_t D = sizeof(double);
     const void *d[8] = {nullptr};
     int rc;
     if ((rc = h2d(ctx, ctx->hb[0], vwave, nwave * D, &d[0]))) return rc;
-    if ((rc = h2d(ctx, ctx->hb[1], y, nwave * D, &d[1]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[1], y, (size_t)nwave * ny * D, &d[1]))) return rc;
     if ((rc = h2d(ctx, ctx->hb[2], dydx, (size_t)nwave * nx * D, &d[2]))) return rc;
     if ((rc = h2d(ctx, ctx->hb[3], vconv, nconv * D, &d[3]))) return rc;
     if (filter) {
@@ -1306,17 +1310,18 @@ static int ils_conv_impl(ansfm_ctx *ctx, int nwave, const double *vwave, const d
         if ((rc = h2d(ctx, ctx->hb[5], vfil, (size_t)nfilmax * nconv * D, &d[5]))) return rc;
         if ((rc = h2d(ctx, ctx->hb[6], afil, (size_t)nfilmax * nconv * D, &d[6]))) return rc;
     }
-    HIPCHK(ctx->tmp_out.reserve(((size_t)nconv * (nx + 1)) * D));
+    HIPCHK(ctx->tmp_out.reserve(((size_t)nconv * (nx + ny)) * D));
     ConvParams p;
     memset(&p, 0, sizeof p);
     p.vwave = (const double *)d[0]; p.y = (const double *)d[1]; p.dydx = (const double *)d[2]; p.vconv = (const double *)d[3];
     p.nfil = (const int32_t *)d[4]; p.vfil = (const double *)d[5]; p.afil = (const double *)d[6];
-    p.yout = ctx->tmp_out.as<double>(); p.gradout = p.yout + nconv;
-    p.nwave = nwave; p.nx = nx; p.nconv = nconv; p.ishape = ishape; p.grad_rules = grad_rules; p.filter = filter ? 1 : 0;
+    p.yout = ctx->tmp_out.as<double>(); p.gradout = p.yout + (size_t)nconv * ny;
+    p.nwave = nwave; p.nx = nx; p.ny = ny; p.nconv = nconv; p.ishape = ishape; p.hamming_rule = hamming_rule;
+    p.filter = filter ? (bracket ? 2 : 1) : 0;
     p.fwhm = fwhm;
-    hipLaunchKernelGGL(k_ils_conv, dim3((unsigned)nconv, (unsigned)((nx + 1 + 127) / 128)), dim3(128), 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_ils_conv, dim3((unsigned)nconv, (unsigned)((nx + ny + 127) / 128)), dim3(128), 0, ctx->stream, p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(yout, p.yout, nconv * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(yout, p.yout, (size_t)nconv * ny * D, hipMemcpyDeviceToHost, ctx->stream));
     if (nx > 0) HIPCHK(hipMemcpyAsync(gradout, p.gradout, (size_t)nconv * nx * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ANSFM_OK;
@@ -1326,8 +1331,17 @@ int ansfm_lblconv(ansfm_ctx *ctx, int nwave, const double *vwave, const double *
                   const double *vconv, int ishape, double fwhm, double *yout, double *gradout)
 {
     if (ctx && !(fwhm > 0.0)) FAIL(ANSFM_ERR_INVALID, "lblconv: only valid if FWHM > 0");
-    return ils_conv_impl(ctx, nwave, vwave, y, nx, dydx, nconv, vconv, ishape, fwhm, nx > 0 ? 1 : 0, 0, nullptr, nullptr, nullptr,
-                         yout, gradout);
+    return ils_conv_impl(ctx, nwave, vwave, 1, y, nx, dydx, nconv, vconv, ishape, fwhm, nx > 0 ? 1 : 0, 0, nullptr, nullptr,
+                         nullptr, yout, gradout);
+}
+
+int ansfm_lblconv_ngeom(ansfm_ctx *ctx, int nwave, const double *vwave, int ngeom, const double *y, int nx,
+                        const double *dydx, int nconv, const double *vconv, int ishape, double fwhm, double *yout,
+                        double *gradout)
+{
+    if (ctx && (!(fwhm > 0.0) || ngeom <= 0)) FAIL(ANSFM_ERR_INVALID, "lblconv_ngeom: only valid if FWHM > 0, NGEOM > 0");
+    return ils_conv_impl(ctx, nwave, vwave, ngeom, y, ngeom * nx, dydx, nconv, vconv, ishape, fwhm, 2, 0, nullptr, nullptr,
+                         nullptr, yout, gradout);
 }
 
 int ansfm_lblconv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const double *y, int nx, const double *dydx, int nconv,
@@ -1335,7 +1349,25 @@ int ansfm_lblconv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const doub
                       double *yout, double *gradout)
 {
     if (ctx && !nfil) FAIL(ANSFM_ERR_INVALID, "lblconv_fil: bad argument");
-    return ils_conv_impl(ctx, nwave, vwave, y, nx, dydx, nconv, vconv, 0, 0.0, 0, nfilmax, nfil, vfil, afil, yout, gradout);
+    return ils_conv_impl(ctx, nwave, vwave, 1, y, nx, dydx, nconv, vconv, 0, 0.0, 0, nfilmax, nfil, vfil, afil, yout, gradout);
+}
+
+int ansfm_conv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const double *y, int nx, const double *dydx, int nconv,
+                   const double *vconv, int nfilmax, const int32_t *nfil, const double *vfil, const double *afil,
+                   double *yout, double *gradout)
+{
+    if (ctx && !nfil) FAIL(ANSFM_ERR_INVALID, "conv_fil: bad argument");
+    return ils_conv_impl(ctx, nwave, vwave, 1, y, nx, dydx, nconv, vconv, 0, 0.0, 0, nfilmax, nfil, vfil, afil, yout, gradout,
+                         true);
+}
+
+int ansfm_lblconv_fil_ngeom(ansfm_ctx *ctx, int nwave, const double *vwave, int ngeom, const double *y, int nx,
+                            const double *dydx, int nconv, const double *vconv, int nfilmax, const int32_t *nfil,
+                            const double *vfil, const double *afil, double *yout, double *gradout)
+{
+    if (ctx && (!nfil || ngeom <= 0)) FAIL(ANSFM_ERR_INVALID, "lblconv_fil_ngeom: bad argument");
+    return ils_conv_impl(ctx, nwave, vwave, ngeom, y, ngeom * nx, dydx, nconv, vconv, 0, 0.0, 0, nfilmax, nfil, vfil, afil,
+                         yout, gradout);
 }
 
 

@@ -1,6 +1,7 @@
 // ansfm_conv_kernels.hip.h -- instrument-line-shape convolution of a monochromatic spectrum and its gradients.
 //
-// Measurement_0.lblconv (:3335), lblconvg (:3799), lblconv_fil (:3549), lblconvg_fil (:3992): for every convolution
+// Measurement_0.lblconv (:3335), lblconvg (:3799), lblconv_fil (:3549), lblconvg_fil (:3992) and their *_ngeom
+// variants (:3444, :3685, :3614, :3912; ny spectra and ny*nx gradient columns on one grid): for every convolution
 // wavenumber a weighted mean over the calculation points inside the ILS window,
 //     yout[j] = sum_i f1_i y_i / sum_i f1_i  (only f1_i > 0 counts),   gradout[j,x] likewise with dydx[i,x],
 // f1 from ISHAPE (square, triangular, gaussian, Hamming; Hanning assigns no weight in the reference -> 0/0) or from a
@@ -15,12 +16,12 @@
 namespace ansfm {
 
 struct ConvParams {
-    const double *vwave, *y, *dydx;      // [nwave], [nwave], [nwave][nx] or nullptr
+    const double *vwave, *y, *dydx;      // [nwave], [nwave][ny], [nwave][nx] or nullptr   (ngeom: ny = NGEOM, nx = NGEOM*NX)
     const double *vconv;                 // [nconv]
     const int32_t *nfil;                 // filter mode: [nconv]
     const double *vfil, *afil;           // filter mode: [nfilmax][nconv]
-    double *yout, *gradout;              // [nconv], [nconv][nx]
-    int nwave, nx, nconv, ishape, grad_rules, filter;
+    double *yout, *gradout;              // [nconv][ny], [nconv][nx]
+    int nwave, nx, ny, nconv, ishape, hamming_rule, filter;   // filter 2: Measurement_0.conv / convg window (bracketing points)
     double fwhm;
 };
 
@@ -44,8 +45,8 @@ __global__ __launch_bounds__(128) void k_ils_conv(ConvParams p)
 {
     __shared__ double fw[128];
     const int j = blockIdx.x, tid = threadIdx.x;
-    const int c = blockIdx.y * 128 + tid;                 // column: < nx gradient, == nx the spectrum
-    const int ncol = p.nx + 1;
+    const int c = blockIdx.y * 128 + tid;                 // column: < nx gradient, then the ny spectra
+    const int ncol = p.nx + p.ny;
     const double vcen = p.vconv[j];
     double v1, v2, sig = 0.0;
     const double *xp = nullptr, *yp = nullptr;
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(128) void k_ils_conv(ConvParams p)
     else if (p.ishape == 1) { v1 = vcen - p.fwhm; v2 = vcen + p.fwhm; }
     else if (p.ishape == 2) { sig = 0.5 * p.fwhm / sqrt(log(2.0)); v1 = vcen - 3. * sig; v2 = vcen + 3. * sig; }
     else if (p.ishape == 3) {
-        if (p.grad_rules) { v1 = vcen - p.fwhm; v2 = vcen + p.fwhm; }                 // lblconvg :3866-3868
+        if (p.hamming_rule == 1) { v1 = vcen - p.fwhm; v2 = vcen + p.fwhm; }          // lblconvg :3866-3868
+        else if (p.hamming_rule == 2) { v1 = vcen - p.fwhm; v2 = vcen - p.fwhm; }     // *_ngeom  :3501-3503, :3753-3755
         else { v1 = vcen - 1.1 * p.fwhm; v2 = vcen - 1.1 * p.fwhm; }                  // lblconv  :3391-3393
     } else { v1 = vcen - 3. * p.fwhm; v2 = vcen + 3. * p.fwhm; }
     // window [i0, i1): vwave >= v1 and vwave <= v2
@@ -67,9 +69,11 @@ __global__ __launch_bounds__(128) void k_ils_conv(ConvParams p)
     const int i0 = lo;
     hi = p.nwave;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (p.vwave[mid] <= v2) lo = mid + 1; else hi = mid; }
-    const int i1 = lo;
+    int i1 = lo;
+    int i0x = i0;
+    if (p.filter == 2) { i0x = i0 - 1; i1 = i1 + 1; }     // conv/convg (:2437-2442): from the last point below v1 to the first above v2 (host checked both exist)
     double acc = 0.0, nor = 0.0;
-    for (int base = i0; base < i1; base += 128) {
+    for (int base = i0x; base < i1; base += 128) {
         const int i = base + tid;
         double f = 0.0;
         if (i < i1) {
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(128) void k_ils_conv(ConvParams p)
                 while (b - a > 1) { const int mid = (a + b) >> 1; if (xp[(size_t)mid * p.nconv] <= v) a = mid; else b = mid; }
                 const double x0 = xp[(size_t)a * p.nconv], x1 = xp[(size_t)(a + 1) * p.nconv];
                 const double y0 = yp[(size_t)a * p.nconv], y1 = yp[(size_t)(a + 1) * p.nconv];
-                f = (v >= v2) ? yp[(size_t)(nf - 1) * p.nconv] : ((y1 - y0) / (x1 - x0)) * (v - x0) + y0;
+                f = (v >= v2) ? yp[(size_t)(nf - 1) * p.nconv] : (v <= v1) ? yp[0] : ((y1 - y0) / (x1 - x0)) * (v - x0) + y0;
             } else
                 f = conv_shape(p.ishape, v, vcen, p.fwhm, sig);
         }
@@ -91,7 +95,8 @@ __global__ __launch_bounds__(128) void k_ils_conv(ConvParams p)
             for (int k = 0; k < n; ++k) {
                 const double fk = fw[k];
                 if (fk > 0.0) {                            // :3433
-                    const double val = (c < p.nx) ? p.dydx[(size_t)(base + k) * p.nx + c] : p.y[base + k];
+                    const double val = (c < p.nx) ? p.dydx[(size_t)(base + k) * p.nx + c]
+                                                  : p.y[(size_t)(base + k) * p.ny + (c - p.nx)];
                     acc = acc + fk * val;
                     nor = nor + fk;
                 }
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(128) void k_ils_conv(ConvParams p)
         }
     }
     if (c < p.nx) p.gradout[(size_t)j * p.nx + c] = acc / nor;
-    else if (c == p.nx) p.yout[j] = acc / nor;
+    else if (c < ncol) p.yout[(size_t)j * p.ny + (c - p.nx)] = acc / nor;
 }
 
 }  // namespace ansfm

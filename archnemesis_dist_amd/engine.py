@@ -435,23 +435,61 @@ class AnsfmEngine:
         """Measurement_0.lblconvg_fil (:3992)."""
         return self._lblconv(vwave, y, dydx, nconv, vconv, None, None, (nfil, vfil, afil))
 
-    def _lblconv(self, vwave, y, dydx, nconv, vconv, ishape, fwhm, fil=None):
+    def lblconv_ngeom(self, nwave, vwave, y, nconv, vconv, ishape, fwhm):
+        """Measurement_0.lblconv_ngeom (:3444): y (nwave, ngeom) -> yout (nconv, ngeom)."""
+        return self._lblconv(vwave, y, None, nconv, vconv, ishape, fwhm, ngeom=True)[0]
+
+    def lblconvg_ngeom(self, nwave, vwave, y, dydx, nconv, vconv, ishape, fwhm):
+        """Measurement_0.lblconvg_ngeom (:3685): -> yout (nconv, ngeom), gradout (nconv, ngeom, nx)."""
+        return self._lblconv(vwave, y, dydx, nconv, vconv, ishape, fwhm, ngeom=True)
+
+    def lblconv_fil_ngeom(self, nwave, vwave, y, nconv, vconv, nfil, vfil, afil):
+        """Measurement_0.lblconv_fil_ngeom (:3614)."""
+        return self._lblconv(vwave, y, None, nconv, vconv, None, None, (nfil, vfil, afil), ngeom=True)[0]
+
+    def lblconvg_fil_ngeom(self, nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil):
+        """Measurement_0.lblconvg_fil_ngeom (:3912)."""
+        return self._lblconv(vwave, y, dydx, nconv, vconv, None, None, (nfil, vfil, afil), ngeom=True)
+
+    def conv_fil(self, vwave, y, dydx, nconv, vconv, nfil, vfil, afil):
+        """FWHM < 0 branch of Measurement_0.conv (:2425-2461; dydx None) / convg (:2655-2691): filter average over the
+        window bracketing each filter -> yout (nconv) [, gradout (nconv, nx)]."""
+        r = self._lblconv(vwave, y, dydx, nconv, vconv, None, None, (nfil, vfil, afil), bracket=True)
+        return r if dydx is not None else r[0]
+
+    def _lblconv(self, vwave, y, dydx, nconv, vconv, ishape, fwhm, fil=None, ngeom=False, bracket=False):
         vwave = _np(vwave); y = _np(y); vconv = _np(np.asarray(vconv)[:nconv])
-        if y.ndim != 1 or (dydx is not None and np.ndim(dydx) != 2):
-            raise ValueError("one geometry per call: y (nwave), dydx (nwave, nx)")
+        nd = 2 if ngeom else 1
+        if y.ndim != nd or (dydx is not None and np.ndim(dydx) != nd + 1):
+            raise ValueError("y (nwave) and dydx (nwave, nx), or the *_ngeom shapes y (nwave, ngeom), dydx (nwave, ngeom, nx)")
         dydx = None if dydx is None else _np(dydx)
-        nx = 0 if dydx is None else dydx.shape[1]
-        yout = np.empty(nconv); gout = np.empty((nconv, nx))
+        nx = 0 if dydx is None else dydx.shape[-1]
+        ng = y.shape[1] if ngeom else 1
+        if dydx is not None and ngeom and dydx.shape[1] != ng:
+            raise ValueError("dydx (nwave, ngeom, nx) must have the NGEOM of y")
+        yout = np.empty((nconv, ng)); gout = np.empty((nconv, ng, nx))
+        if fil is not None:
+            nfil = _np(np.asarray(fil[0])[:nconv], np.int32)
+            vfil = _np(np.asarray(fil[1])[:, :nconv]); afil = _np(np.asarray(fil[2])[:, :nconv])
+        if ngeom:
+            if fil is None:
+                rc = self._lib.ansfm_lblconv_ngeom(self._ctx, vwave.size, _ptr(vwave), ng, _ptr(y), nx, _ptr(dydx), int(nconv),
+                                                   _ptr(vconv), int(ishape), float(fwhm), _ptr(yout), _ptr(gout))
+            else:
+                rc = self._lib.ansfm_lblconv_fil_ngeom(self._ctx, vwave.size, _ptr(vwave), ng, _ptr(y), nx, _ptr(dydx),
+                                                       int(nconv), _ptr(vconv), vfil.shape[0], _ptr(nfil), _ptr(vfil),
+                                                       _ptr(afil), _ptr(yout), _ptr(gout))
+            self._check(rc, "lblconv_ngeom")
+            return yout, gout
         if fil is None:
             rc = self._lib.ansfm_lblconv(self._ctx, vwave.size, _ptr(vwave), _ptr(y), nx, _ptr(dydx), int(nconv), _ptr(vconv),
                                          int(ishape), float(fwhm), _ptr(yout), _ptr(gout))
         else:
-            nfil = _np(np.asarray(fil[0])[:nconv], np.int32)
-            vfil = _np(np.asarray(fil[1])[:, :nconv]); afil = _np(np.asarray(fil[2])[:, :nconv])
-            rc = self._lib.ansfm_lblconv_fil(self._ctx, vwave.size, _ptr(vwave), _ptr(y), nx, _ptr(dydx), int(nconv), _ptr(vconv),
-                                             vfil.shape[0], _ptr(nfil), _ptr(vfil), _ptr(afil), _ptr(yout), _ptr(gout))
+            fn = self._lib.ansfm_conv_fil if bracket else self._lib.ansfm_lblconv_fil
+            rc = fn(self._ctx, vwave.size, _ptr(vwave), _ptr(y), nx, _ptr(dydx), int(nconv), _ptr(vconv),
+                    vfil.shape[0], _ptr(nfil), _ptr(vfil), _ptr(afil), _ptr(yout), _ptr(gout))
         self._check(rc, "lblconv")
-        return yout, gout
+        return yout[:, 0], gout[:, 0, :]
 
     def get_taugas(self, L, model=0):
         W, G = self.dims[0], self.dims[1]

@@ -374,14 +374,16 @@ def install_gpu_layering(device=0):
 
 
 def install_gpu_convolution(device=0):
-    """Route the single-geometry ILS convolution kernels of Measurement_0 -- lblconv (:3335), lblconvg (:3799), lblconv_fil
-    (:3549), lblconvg_fil (:3992), which the Measurement_0.lblconv / lblconvg methods call by module-global name with
-    IGEOM = int (the way nemesisfm / nemesisfmg use them) -- through the GPU.  The *_ngeom variants stay the reference's."""
+    """Route the ILS convolution kernels of Measurement_0 -- lblconv (:3335), lblconvg (:3799), lblconv_fil (:3549),
+    lblconvg_fil (:3992), which the Measurement_0.lblconv / lblconvg methods call by module-global name with IGEOM = int
+    (the way nemesisfm / nemesisfmg use them), and the *_ngeom variants (:3444, :3685, :3614, :3912; IGEOM = 'All') --
+    through the GPU, and the filter-function branch of the k-table methods Measurement_0.conv / convg."""
     import importlib
     m0 = importlib.import_module("archnemesis.Measurement_0")
     eng = get_engine(device)
     if not hasattr(m0, "_ansfm_reference_conv"):
-        m0._ansfm_reference_conv = (m0.lblconv, m0.lblconvg, m0.lblconv_fil, m0.lblconvg_fil)
+        m0._ansfm_reference_conv = (m0.lblconv, m0.lblconvg, m0.lblconv_fil, m0.lblconvg_fil, m0.lblconv_ngeom,
+                                    m0.lblconvg_ngeom, m0.lblconv_fil_ngeom, m0.lblconvg_fil_ngeom)
     ref = m0._ansfm_reference_conv
 
     def _ascending(v):
@@ -390,29 +392,84 @@ def install_gpu_convolution(device=0):
 
     def lblconv(nwave, vwave, y, nconv, vconv, ishape, fwhm):
         if np.ndim(y) != 1 or not _ascending(vwave):
-            _delegate("lblconv on an unsorted grid or several geometries")
+            _delegate("lblconv on an unsorted grid")
             return ref[0](nwave, vwave, y, nconv, vconv, ishape, fwhm)
         return eng.lblconv(nwave, vwave, y, nconv, vconv, int(ishape), fwhm)
 
     def lblconvg(nwave, vwave, y, dydx, nconv, vconv, ishape, fwhm):
         if np.ndim(y) != 1 or np.ndim(dydx) != 2 or not _ascending(vwave):
-            _delegate("lblconvg on an unsorted grid or several geometries")
+            _delegate("lblconvg on an unsorted grid")
             return ref[1](nwave, vwave, y, dydx, nconv, vconv, ishape, fwhm)
         return eng.lblconvg(nwave, vwave, y, dydx, nconv, vconv, int(ishape), fwhm)
 
     def lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil):
         if np.ndim(y) != 1 or not _ascending(vwave):
-            _delegate("lblconv_fil on an unsorted grid or several geometries")
+            _delegate("lblconv_fil on an unsorted grid")
             return ref[2](nwave, vwave, y, nconv, vconv, nfil, vfil, afil)
         return eng.lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil)
 
     def lblconvg_fil(nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil):
         if np.ndim(y) != 1 or np.ndim(dydx) != 2 or not _ascending(vwave):
-            _delegate("lblconvg_fil on an unsorted grid or several geometries")
+            _delegate("lblconvg_fil on an unsorted grid")
             return ref[3](nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil)
         return eng.lblconvg_fil(nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil)
 
+    def lblconv_ngeom(nwave, vwave, y, nconv, vconv, ishape, fwhm):
+        if np.ndim(y) != 2 or not _ascending(vwave) or not fwhm > 0.0:     # (the reference returns nothing for y.ndim != 2)
+            _delegate("lblconv_ngeom on an unsorted grid")
+            return ref[4](nwave, vwave, y, nconv, vconv, ishape, fwhm)
+        return eng.lblconv_ngeom(nwave, vwave, y, nconv, vconv, int(ishape), fwhm)
+
+    def lblconvg_ngeom(nwave, vwave, y, dydx, nconv, vconv, ishape, fwhm):
+        if np.ndim(y) != 2 or np.ndim(dydx) != 3 or not _ascending(vwave) or not fwhm > 0.0:
+            _delegate("lblconvg_ngeom on an unsorted grid")
+            return ref[5](nwave, vwave, y, dydx, nconv, vconv, ishape, fwhm)
+        return eng.lblconvg_ngeom(nwave, vwave, y, dydx, nconv, vconv, int(ishape), fwhm)
+
+    def lblconv_fil_ngeom(nwave, vwave, y, nconv, vconv, nfil, vfil, afil):
+        if np.ndim(y) != 2 or not _ascending(vwave):
+            _delegate("lblconv_fil_ngeom on an unsorted grid")
+            return ref[6](nwave, vwave, y, nconv, vconv, nfil, vfil, afil)
+        return eng.lblconv_fil_ngeom(nwave, vwave, y, nconv, vconv, nfil, vfil, afil)
+
+    def lblconvg_fil_ngeom(nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil):
+        if np.ndim(y) != 2 or np.ndim(dydx) != 3 or not _ascending(vwave):
+            _delegate("lblconvg_fil_ngeom on an unsorted grid")
+            return ref[7](nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil)
+        return eng.lblconvg_fil_ngeom(nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil)
+
+    # k-table runs: Measurement_0.conv (:2288) / convg (:2467).  Their FWHM < 0 branch (one filter per convolution point,
+    # Python loops over NCONV x window with NX-vectors) goes to the GPU; FWHM == 0 (one scipy interp1d call) and the
+    # cubic-spline FWHM > 0 branch of conv (convg raises there in the reference, :2611) are the reference's own host code.
+    cls = m0.Measurement_0
+    if not hasattr(cls, "_ansfm_reference_conv_methods"):
+        cls._ansfm_reference_conv_methods = (cls.conv, cls.convg)
+    rconv, rconvg = cls._ansfm_reference_conv_methods
+
+    def _fil_case(self, Wave, IGEOM):
+        return (not isinstance(IGEOM, str)) and self.FWHM < 0.0 and _ascending(Wave)
+
+    def conv(self, Wave, ModSpec, IGEOM='All', FWHMEXIST=''):
+        if not _fil_case(self, Wave, IGEOM):
+            if self.FWHM != 0.0:
+                _delegate("Measurement_0.conv outside the filter-function branch (FWHM > 0 spline, IGEOM='All')")
+            return rconv(self, Wave, ModSpec, IGEOM=IGEOM, FWHMEXIST=FWHMEXIST)
+        n = int(self.NCONV[IGEOM])
+        return eng.conv_fil(Wave, np.asarray(ModSpec)[:len(Wave)], None, n, self.VCONV[:n, IGEOM], self.NFIL, self.VFIL, self.AFIL)
+
+    def convg(self, Wave, ModSpec, ModGrad, IGEOM='All', FWHMEXIST=''):
+        if not _fil_case(self, Wave, IGEOM):
+            if self.FWHM != 0.0:
+                _delegate("Measurement_0.convg outside the filter-function branch (FWHM > 0, IGEOM='All')")
+            return rconvg(self, Wave, ModSpec, ModGrad, IGEOM=IGEOM, FWHMEXIST=FWHMEXIST)
+        n = int(self.NCONV[IGEOM])
+        return eng.conv_fil(Wave, np.asarray(ModSpec)[:len(Wave)], ModGrad, n, self.VCONV[:n, IGEOM], self.NFIL, self.VFIL,
+                            self.AFIL)
+
+    cls.conv, cls.convg = conv, convg
     m0.lblconv, m0.lblconvg, m0.lblconv_fil, m0.lblconvg_fil = lblconv, lblconvg, lblconv_fil, lblconvg_fil
+    m0.lblconv_ngeom, m0.lblconvg_ngeom = lblconv_ngeom, lblconvg_ngeom
+    m0.lblconv_fil_ngeom, m0.lblconvg_fil_ngeom = lblconv_fil_ngeom, lblconvg_fil_ngeom
     return lblconv, lblconvg, lblconv_fil, lblconvg_fil
 
 

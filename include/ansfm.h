@@ -287,6 +287,24 @@ int ansfm_lblconv(ansfm_ctx *ctx, int nwave, const double *vwave, const double *
 int ansfm_lblconv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const double *y, int nx,
                       const double *dydx, int nconv, const double *vconv, int nfilmax, const int32_t *nfil,
                       const double *vfil, const double *afil, double *yout, double *gradout);
+/* lblconv_ngeom (:3444) / lblconvg_ngeom (:3685) / lblconv_fil_ngeom (:3614) / lblconvg_fil_ngeom (:3912): NGEOM spectra
+ * on one grid, y[nwave][ngeom], dydx[nwave][ngeom][nx] (nx = 0: none) -> yout[nconv][ngeom], gradout[nconv][ngeom][nx].
+ * Same arithmetic per column; the Hamming window of both ISHAPE variants is the single point vcen - FWHM (:3501-3503,
+ * :3753-3755).  (The reference's lblconv_ngeom is an un-jitted Python loop.) */
+int ansfm_lblconv_ngeom(ansfm_ctx *ctx, int nwave, const double *vwave, int ngeom, const double *y, int nx,
+                        const double *dydx, int nconv, const double *vconv, int ishape, double fwhm, double *yout,
+                        double *gradout);
+int ansfm_lblconv_fil_ngeom(ansfm_ctx *ctx, int nwave, const double *vwave, int ngeom, const double *y, int nx,
+                            const double *dydx, int nconv, const double *vconv, int nfilmax, const int32_t *nfil,
+                            const double *vfil, const double *afil, double *yout, double *gradout);
+
+/* Measurement_0.conv (:2288) / convg (:2467), k-table runs, FWHM < 0 branch (:2425-2461, :2655-2691): the filter
+ * average of lblconv_fil, but over the window from the last calculation point BELOW vfil[0][j] to the first ABOVE
+ * vfil[nfil[j]-1][j] (both must exist: the reference raises IndexError otherwise -> ANSFM_ERR_INVALID), np.interp
+ * clamping to the edge values outside the filter. */
+int ansfm_conv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const double *y, int nx, const double *dydx,
+                   int nconv, const double *vconv, int nfilmax, const int32_t *nfil, const double *vfil,
+                   const double *afil, double *yout, double *gradout);
 
 /* ---- continuum ---------------------------------------------------------------------------
  * ForwardModel_0.calc_tau_cia (ForwardModel_0.py:4516-4760), wavenumber space (the caller converts and re-orders a

@@ -1,5 +1,6 @@
 """Golden fixture for the ILS convolution kernels: the REFERENCE's Measurement_0.lblconv / lblconvg / lblconv_fil /
-lblconvg_fil (:3335, :3799, :3549, :3992) on a seeded spectrum, every ISHAPE (incl. the shapes whose result is 0/0).
+lblconvg_fil (:3335, :3799, :3549, :3992) and their *_ngeom variants (:3444, :3685, :3614, :3912) on a seeded
+spectrum, every ISHAPE (incl. the shapes whose result is 0/0).
 Build container only.   python oracle/gen_golden_conv.py"""
 import os
 import sys
@@ -47,8 +48,34 @@ def main():
         out["fil"] = M0.lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil)
         yo, go = M0.lblconvg_fil(nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil)
         out["filg_y"] = yo; out["filg_g"] = go
+        # several geometries on one grid (the *_ngeom kernels)
+        ngeom = 3
+        y2 = np.column_stack([y * s for s in (1.0, 0.7, 1.9)]) * rng.uniform(0.95, 1.05, (nwave, ngeom))
+        dydx3 = rng.normal(size=(nwave, ngeom, nx)) * 10.0 ** rng.uniform(-10, -7, (1, 1, nx))
+        out.update(y_ngeom=y2, dydx_ngeom=dydx3)
+        for ishape in range(5):
+            out[f"ngconv_{ishape}"] = M0.lblconv_ngeom(nwave, vwave, y2, nconv, vconv, ishape, fwhm)
+            yo, go = M0.lblconvg_ngeom(nwave, vwave, y2, dydx3, nconv, vconv, ishape, fwhm)
+            out[f"ngconvg_{ishape}_y"] = yo; out[f"ngconvg_{ishape}_g"] = go
+        out["ngfil_y"] = M0.lblconv_fil_ngeom(nwave, vwave, y2, nconv, vconv, nfil, vfil, afil)
+        yo, go = M0.lblconvg_fil_ngeom(nwave, vwave, y2, dydx3, nconv, vconv, nfil, vfil, afil)
+        out["ngfilg_y"] = yo; out["ngfilg_g"] = go
+        # k-table methods Measurement_0.conv / convg, FWHM < 0 (filter per convolution point, bracketing window) and
+        # FWHM == 0 (plain interpolation); afil[0] > 0 for some filters so the bracketing points carry weight
+        Meas = M0.Measurement_0()
+        Meas.NGEOM = 1; Meas.FWHM = -1.0; Meas.NCONV = np.array([nconv]); Meas.VCONV = vconv[:, None].copy()
+        afil2 = afil.copy(); afil2[0, ::2] = 0.3
+        Meas.NFIL = nfil; Meas.VFIL = vfil; Meas.AFIL = afil2
+        out["afil_k"] = afil2
+        out["kconv_fil"] = Meas.conv(vwave, y, IGEOM=0)
+        yo, go = Meas.convg(vwave, y, dydx, IGEOM=0)
+        out["kconvg_fil_y"] = yo; out["kconvg_fil_g"] = go
+        Meas.FWHM = 0.0
+        out["kconv_0"] = Meas.conv(vwave, y, IGEOM=0)
+        yo, go = Meas.convg(vwave, y, dydx, IGEOM=0)
+        out["kconvg_0_y"] = yo; out["kconvg_0_g"] = go
     np.savez_compressed(os.path.join(OUT, "ils_conv.npz"), **out)
-    print({k: (np.shape(v), bool(np.isnan(v).any())) for k, v in out.items() if k.startswith(("conv", "fil"))})
+    print({k: (np.shape(v), bool(np.isnan(v).any())) for k, v in out.items() if k.startswith(("conv", "fil", "ngconv", "ngfil", "kconv"))})
 
 
 if __name__ == "__main__":

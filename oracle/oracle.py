@@ -328,9 +328,10 @@ def map2xvec(dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NX, xmap):
 
 
 # ---- ILS convolution (Measurement_0.lblconv :3335, lblconvg :3799, lblconv_fil :3549, lblconvg_fil :3992) ---------
-def _ils_window(ishape, vcen, fwhm, grad):
-    """Window [v1, v2] and the Gaussian sigma of one convolution point.  The two reference kernels differ for the
-    Hamming shape: lblconv sets v1 = v2 = vcen - 1.1*fwhm (:3391-3393), lblconvg vcen -+ fwhm (:3866-3868)."""
+def _ils_window(ishape, vcen, fwhm, grad, ngeom=False):
+    """Window [v1, v2] and the Gaussian sigma of one convolution point.  The reference kernels differ for the
+    Hamming shape: lblconv sets v1 = v2 = vcen - 1.1*fwhm (:3391-3393), lblconvg vcen -+ fwhm (:3866-3868), both
+    *_ngeom variants v1 = v2 = vcen - fwhm (:3501-3503, :3753-3755)."""
     sig = 0.0
     if ishape == 0:
         v1 = vcen - 0.5 * fwhm; v2 = v1 + fwhm
@@ -339,7 +340,9 @@ def _ils_window(ishape, vcen, fwhm, grad):
     elif ishape == 2:
         sig = 0.5 * fwhm / np.sqrt(np.log(2.0)); v1 = vcen - 3. * sig; v2 = vcen + 3. * sig
     elif ishape == 3:
-        if grad:
+        if ngeom:
+            v1 = vcen - fwhm; v2 = vcen - fwhm
+        elif grad:
             v1 = vcen - fwhm; v2 = vcen + fwhm
         else:
             v1 = vcen - 1.1 * fwhm; v2 = vcen - 1.1 * fwhm
@@ -378,31 +381,59 @@ def _ils_sum(f1, cols):
         return out / nor
 
 
-def lblconv(nwave, vwave, y, nconv, vconv, ishape, fwhm, dydx=None):
-    """Measurement_0.lblconv (dydx None) / lblconvg: yout (nconv) [, gradout (nconv, nx)]."""
-    vwave = np.asarray(vwave, float); y = np.asarray(y, float)
+def _ils_cols(y, dydx, ngeom):
+    """columns [gradients..., spectra...] of one call and how to split the result again"""
+    y = np.asarray(y, float)
+    ycols = y if ngeom else y[:, None]
+    ng = ycols.shape[1]
+    if dydx is None:
+        return ycols, ng, 0
+    d = np.asarray(dydx, float)
+    nx = d.shape[-1]
+    return np.column_stack([d.reshape(d.shape[0], ng * nx), ycols]), ng, nx
+
+
+def _ils_split(out, ng, nx, grad, ngeom):
+    nconv = out.shape[0]
+    yo = out[:, ng * nx:]; go = out[:, :ng * nx].reshape(nconv, ng, nx)
+    if not ngeom:
+        yo = yo[:, 0]; go = go[:, 0, :]
+    return (yo, go) if grad else yo
+
+
+def lblconv(nwave, vwave, y, nconv, vconv, ishape, fwhm, dydx=None, ngeom=False):
+    """Measurement_0.lblconv (dydx None) / lblconvg: yout (nconv) [, gradout (nconv, nx)]; ngeom=True: lblconv_ngeom
+    (:3444) / lblconvg_ngeom (:3685) with y (nwave, ngeom), dydx (nwave, ngeom, nx)."""
+    vwave = np.asarray(vwave, float)
     grad = dydx is not None
-    cols = np.column_stack([np.asarray(dydx, float), y]) if grad else y[:, None]
+    cols, ng, nx = _ils_cols(y, dydx, ngeom)
     out = np.zeros((nconv, cols.shape[1]))
     for j in range(nconv):
-        v1, v2, sig = _ils_window(int(ishape), vconv[j], fwhm, grad)
+        v1, v2, sig = _ils_window(int(ishape), vconv[j], fwhm, grad, ngeom)
         idx = np.where((vwave >= v1) & (vwave <= v2))[0]
         out[j] = _ils_sum(_ils_weight(int(ishape), vwave[idx], vconv[j], fwhm, sig), cols[idx])
-    return (out[:, -1], out[:, :-1]) if grad else out[:, 0]
+    return _ils_split(out, ng, nx, grad, ngeom)
 
 
-def lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil, dydx=None):
-    """Measurement_0.lblconv_fil / lblconvg_fil: tabulated filter per convolution point, np.interp weights."""
-    vwave = np.asarray(vwave, float); y = np.asarray(y, float)
+def lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil, dydx=None, ngeom=False, bracket=False):
+    """Measurement_0.lblconv_fil / lblconvg_fil (ngeom=True: lblconv_fil_ngeom :3614 / lblconvg_fil_ngeom :3912):
+    tabulated filter per convolution point, np.interp weights.  bracket=True: the FWHM < 0 branch of the k-table
+    methods Measurement_0.conv / convg (:2425-2461, :2655-2691), whose window runs from the last point below the
+    filter to the first above it."""
+    vwave = np.asarray(vwave, float)
     grad = dydx is not None
-    cols = np.column_stack([np.asarray(dydx, float), y]) if grad else y[:, None]
+    cols, ng, nx = _ils_cols(y, dydx, ngeom)
     out = np.zeros((nconv, cols.shape[1]))
     for j in range(nconv):
         n = int(nfil[j])
         xp = np.asarray(vfil[:n, j], float); yp = np.asarray(afil[:n, j], float)
-        idx = np.where((vwave >= xp[0]) & (vwave <= xp[-1]))[0]
+        if bracket:
+            lo = np.where(vwave < xp[0])[0]; hi = np.where(vwave > xp[-1])[0]
+            idx = np.arange(lo[-1], hi[0] + 1)            # IndexError when the filter is not inside the grid, like :2437
+        else:
+            idx = np.where((vwave >= xp[0]) & (vwave <= xp[-1]))[0]
         out[j] = _ils_sum(np.interp(vwave[idx], xp, yp), cols[idx])
-    return (out[:, -1], out[:, :-1]) if grad else out[:, 0]
+    return _ils_split(out, ng, nx, grad, ngeom)
 
 
 # ---- collision-induced absorption (ForwardModel_0.calc_tau_cia :4516-4760) -----------------------------------------

@@ -524,6 +524,46 @@ def test_lblconv_fil_golden_and_large_vs_oracle(eng, oracle, golden_dir):
         eng.lblconv(nw, vw[::-1].copy(), y, nc, vc, 1, 0.4)
 
 
+@pytest.mark.parametrize("ishape", range(5))
+def test_lblconv_ngeom_golden(eng, golden_dir, ishape):
+    """The *_ngeom kernels (several geometries on one grid) vs the reference, incl. their own Hamming window and the 0/0
+    results."""
+    from test_conv_oracle import close_nan
+    z = _load(golden_dir, "ils_conv")
+    nw, nc, fw = z["vwave"].size, z["vconv"].size, float(z["fwhm"])
+    close_nan(eng.lblconv_ngeom(nw, z["vwave"], z["y_ngeom"], nc, z["vconv"], ishape, fw), z[f"ngconv_{ishape}"], 1e-12)
+    yo, go = eng.lblconvg_ngeom(nw, z["vwave"], z["y_ngeom"], z["dydx_ngeom"], nc, z["vconv"], ishape, fw)
+    close_nan(yo, z[f"ngconvg_{ishape}_y"], 1e-12)
+    close_nan(go, z[f"ngconvg_{ishape}_g"], 1e-11)
+
+
+def test_lblconv_fil_ngeom_golden(eng, golden_dir):
+    from test_conv_oracle import close_nan
+    z = _load(golden_dir, "ils_conv")
+    nw, nc = z["vwave"].size, z["vconv"].size
+    close_nan(eng.lblconv_fil_ngeom(nw, z["vwave"], z["y_ngeom"], nc, z["vconv"], z["nfil"], z["vfil"], z["afil"]),
+              z["ngfil_y"], 1e-12)
+    yo, go = eng.lblconvg_fil_ngeom(nw, z["vwave"], z["y_ngeom"], z["dydx_ngeom"], nc, z["vconv"], z["nfil"], z["vfil"],
+                                    z["afil"])
+    close_nan(yo, z["ngfilg_y"], 1e-12)
+    close_nan(go, z["ngfilg_g"], 1e-11)
+
+
+def test_ktable_conv_filter_branch_golden(eng, golden_dir):
+    """Measurement_0.conv / convg, FWHM < 0 (k-table runs with a filter per convolution point) vs the reference."""
+    from test_conv_oracle import close_nan
+    z = _load(golden_dir, "ils_conv")
+    nc = z["vconv"].size
+    a = (nc, z["vconv"], z["nfil"], z["vfil"], z["afil_k"])
+    close_nan(eng.conv_fil(z["vwave"], z["y"], None, *a), z["kconv_fil"], 1e-12)
+    yo, go = eng.conv_fil(z["vwave"], z["y"], z["dydx"], *a)
+    close_nan(yo, z["kconvg_fil_y"], 1e-12)
+    close_nan(go, z["kconvg_fil_g"], 1e-11)
+    vf = z["vfil"].copy(); vf[0, 0] = z["vwave"][0] - 1.0            # a filter that sticks out of the grid: IndexError there
+    with pytest.raises(ValueError):
+        eng.conv_fil(z["vwave"], z["y"], None, nc, z["vconv"], z["nfil"], vf, z["afil_k"])
+
+
 def test_batch_layer_dedup_is_bit_identical(eng):
     """A numerical-Jacobian batch (every state differs from the first in two layers): layers identical to the first
     model's share its opacity rows -- same spectra and TAUGAS to the last bit, far fewer rows computed."""
