@@ -1469,6 +1469,125 @@ int ansfm_calc_tau_cia(ansfm_ctx *ctx, int W, const double *WAVEN, int NWC, cons
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* continuum: Rayleigh scattering (ForwardModel_0.calc_tau_rayleigh) and aerosols (calc_tau_dust) */
+/* ------------------------------------------------------------------------------------------ */
+int ansfm_calc_tau_rayleigh(ansfm_ctx *ctx, int mode, int ISPACE, int W, const double *WAVEC, int L, const double *TOTAM,
+                            const double *f4, double *TAURAY, double *dTAURAY)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || L <= 0 || !WAVEC || !TOTAM || !TAURAY || !dTAURAY || (ISPACE != 0 && ISPACE != 1) ||
+        (mode != 1 && mode != 2 && mode != 4 && mode != 12) || (mode == 4 && !f4))
+        FAIL(ANSFM_ERR_INVALID, "calc_tau_rayleigh: bad argument (mode = IRAY 1, 2, 4 or 12 for calc_tau_rayleighv)");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t D = sizeof(double), nt = (size_t)W * L;
+    const void *d[3] = {nullptr};
+    int rc;
+    if ((rc = h2d(ctx, ctx->hb[0], WAVEC, W * D, &d[0]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[1], TOTAM, L * D, &d[1]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[2], f4, mode == 4 ? (size_t)L * 4 * D : 0, &d[2]))) return rc;
+    HIPCHK(ctx->tmp_out.reserve(2 * nt * D));
+    RayParams p;
+    memset(&p, 0, sizeof p);
+    p.wavec = (const double *)d[0]; p.totam = (const double *)d[1]; p.f4 = (const double *)d[2];
+    p.tau = ctx->tmp_out.as<double>(); p.dtau = p.tau + nt;
+    p.W = W; p.L = L; p.mode = mode; p.ispace = ISPACE;
+    hipLaunchKernelGGL(k_tau_rayleigh, dim3(nblk((size_t)W, 128), (unsigned)L), dim3(128), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(TAURAY, p.tau, nt * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dTAURAY, p.dtau, nt * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+// not-a-knot cubic spline through (x, y[stride]) : per interval b, c, d of  y_a + t (b + t (c + t d)),  t = x - x_a
+static void notaknot_coeffs(int n, const double *x, const double *y, size_t stride, double *coef)
+{
+    std::vector<double> h(n - 1), s(n - 1), M(n, 0.0);
+    for (int i = 0; i < n - 1; ++i) { h[i] = x[i + 1] - x[i]; s[i] = (y[(size_t)(i + 1) * stride] - y[(size_t)i * stride]) / h[i]; }
+    // unknowns M_1..M_{n-2} (second derivatives); M_0 and M_{n-1} eliminated with the not-a-knot conditions
+    const int m = n - 2;
+    std::vector<double> lo(m, 0.0), di(m, 0.0), up(m, 0.0), r(m, 0.0);
+    for (int k = 0; k < m; ++k) {
+        const int i = k + 1;
+        lo[k] = h[i - 1]; di[k] = 2.0 * (h[i - 1] + h[i]); up[k] = h[i];
+        r[k] = 6.0 * (s[i] - s[i - 1]);
+    }
+    if (m == 1) {   // n == 3 is refused by the caller; kept total
+        M[1] = r[0] / di[0];
+    } else {
+        // M_0 = ((h0+h1) M_1 - h0 M_2) / h1 ;  M_{n-1} = ((h_{n-2}+h_{n-3}) M_{n-2} - h_{n-2} M_{n-3}) / h_{n-3}
+        const double h0 = h[0], h1 = h[1], hn = h[n - 2], hm = h[n - 3];
+        di[0] += lo[0] * (h0 + h1) / h1; up[0] -= lo[0] * h0 / h1; lo[0] = 0.0;
+        di[m - 1] += up[m - 1] * (hn + hm) / hm; lo[m - 1] -= up[m - 1] * hn / hm; up[m - 1] = 0.0;
+        for (int k = 1; k < m; ++k) {   // Thomas
+            const double f = lo[k] / di[k - 1];
+            di[k] -= f * up[k - 1];
+            r[k] -= f * r[k - 1];
+        }
+        M[m] = r[m - 1] / di[m - 1];
+        for (int k = m - 2; k >= 0; --k) M[k + 1] = (r[k] - up[k] * M[k + 2]) / di[k];
+        M[0] = ((h0 + h1) * M[1] - h0 * M[2]) / h1;
+        M[n - 1] = ((hn + hm) * M[n - 2] - hn * M[n - 3]) / hm;
+    }
+    for (int i = 0; i < n - 1; ++i) {
+        coef[(size_t)i * 3 + 0] = s[i] - h[i] * (2.0 * M[i] + M[i + 1]) / 6.0;
+        coef[(size_t)i * 3 + 1] = M[i] / 2.0;
+        coef[(size_t)i * 3 + 2] = (M[i + 1] - M[i]) / (6.0 * h[i]);
+    }
+}
+
+int ansfm_calc_tau_dust(ansfm_ctx *ctx, int W, const double *WAVEC, int NWS, const double *SWAVE, int NDUST,
+                        const double *KEXT, const double *KSCA, int L, const double *CONT, double *TAUDUST,
+                        double *TAUCLSCAT, double *dTAUDUSTdq, double *dTAUCLSCATdq)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || NWS < 2 || NDUST <= 0 || L <= 0 || !WAVEC || !SWAVE || !KEXT || !KSCA || !CONT || !TAUDUST || !TAUCLSCAT ||
+        !dTAUDUSTdq || !dTAUCLSCATdq)
+        FAIL(ANSFM_ERR_INVALID, "calc_tau_dust: bad argument");
+    if (NWS == 3) FAIL(ANSFM_ERR_UNSUPPORTED, "calc_tau_dust: three tabulated wavelengths (scipy's cubic interp1d refuses them too)");
+    for (int i = 1; i < NWS; ++i)
+        if (!(SWAVE[i] > SWAVE[i - 1])) FAIL(ANSFM_ERR_UNSORTED, "calc_tau_dust: Scatter.WAVE must be strictly ascending");
+    for (int w = 0; w < W; ++w)      // interp1d(bounds_error=True)
+        if (!(WAVEC[w] >= SWAVE[0] && WAVEC[w] <= SWAVE[NWS - 1]))
+            FAIL(ANSFM_ERR_INVALID, "calc_tau_dust: a calculation wavenumber is outside the range of the aerosol properties");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t D = sizeof(double), nt = (size_t)W * L * NDUST;
+    const int cubic = NWS > 2;
+    std::vector<double> coef;
+    if (cubic) {
+        coef.resize((size_t)2 * NDUST * (NWS - 1) * 3);
+        for (int i = 0; i < NDUST; ++i) {
+            notaknot_coeffs(NWS, SWAVE, KEXT + i, NDUST, coef.data() + (size_t)i * (NWS - 1) * 3);
+            notaknot_coeffs(NWS, SWAVE, KSCA + i, NDUST, coef.data() + ((size_t)NDUST + i) * (NWS - 1) * 3);
+        }
+    }
+    const void *d[6] = {nullptr};
+    int rc;
+    if ((rc = h2d(ctx, ctx->hb[0], WAVEC, W * D, &d[0]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[1], SWAVE, NWS * D, &d[1]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[2], KEXT, (size_t)NWS * NDUST * D, &d[2]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[3], KSCA, (size_t)NWS * NDUST * D, &d[3]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[4], CONT, (size_t)L * NDUST * D, &d[4]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[5], cubic ? coef.data() : nullptr, coef.size() * D, &d[5]))) return rc;
+    HIPCHK(ctx->tmp_out.reserve(4 * nt * D));
+    DustParams p;
+    memset(&p, 0, sizeof p);
+    p.wavec = (const double *)d[0]; p.swave = (const double *)d[1]; p.kext = (const double *)d[2]; p.ksca = (const double *)d[3];
+    p.cont = (const double *)d[4];
+    p.cext = (const double *)d[5]; p.csca = p.cext ? p.cext + (size_t)NDUST * (NWS - 1) * 3 : nullptr;
+    p.taudust = ctx->tmp_out.as<double>(); p.tauclscat = p.taudust + nt; p.dtaudust = p.tauclscat + nt; p.dtauclscat = p.dtaudust + nt;
+    p.W = W; p.NWS = NWS; p.NDUST = NDUST; p.L = L; p.cubic = cubic;
+    hipLaunchKernelGGL(k_tau_dust, dim3(nblk((size_t)W, 128), (unsigned)NDUST), dim3(128), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(TAUDUST, p.taudust, nt * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(TAUCLSCAT, p.tauclscat, nt * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dTAUDUSTdq, p.dtaudust, nt * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dTAUCLSCATdq, p.dtauclscat, nt * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* multiple scattering                                                                         */
 /* ------------------------------------------------------------------------------------------ */
 int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const double *phasarr, const double *radg,

@@ -92,4 +92,146 @@ __global__ __launch_bounds__(128) void k_tau_cia(CiaParams p)
         for (int s = 0; s < p.NVMR + 2; ++s) d[s] = d[s] * c.xfac;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Rayleigh scattering opacity of the layers: ForwardModel_0.calc_tau_rayleighj (:5525, IRAY 1, gas giants, Allen 1976),
+// calc_tau_rayleighv2 (:5647, IRAY 2, CO2, Ityaksov et al. 2008), calc_tau_rayleighls (:5712, IRAY 4, Jovian air after
+// Sromovsky: H2 / He / CH4 / NH3 weighted by the layer's composition) and the older calc_tau_rayleighv (:5598, not
+// selected by any IRAY).  tau[w][l] = k(w[, l]) * TOTAM[l], dtau[w][l] = k.  One thread per (wavenumber, layer); the
+// operation order of the reference's expressions is kept.
+// ------------------------------------------------------------------------------------------------------------------
+struct RayParams {
+    const double *wavec;        // [W] wavenumber (ISPACE 0) or wavelength in micron (ISPACE 1)
+    const double *totam;        // [L]
+    const double *f4;           // mode 4: [L][4] mixing ratios of H2, He, CH4, NH3 (0 where the gas is absent)
+    double *tau, *dtau;         // [W][L]
+    int W, L, mode, ispace;     // mode = IRAY (1, 2, 4); 12 = calc_tau_rayleighv
+};
+
+__global__ __launch_bounds__(128) void k_tau_rayleigh(RayParams p)
+{
+#pragma clang fp contract(off)      // n*n - 1 with n = 1 + 4e-4 cancels: a fused multiply-add would differ from NumPy by 1e-13
+    const int w = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (w >= p.W) return;
+    const double PI = 3.141592653589793;
+    const double v = p.wavec[w];
+    double k = 0.0;
+    if (p.mode == 1) {                                           // :5543-5577
+        const double AH2 = 13.58E-5, BH2 = 7.52E-3, AHe = 3.48E-5, BHe = 2.30E-3, fH2 = 0.864;
+        const double kb = 1.37971e-23, P0 = 1.01325e5, T0 = 273.15;
+        const double LAMBDA = (p.ispace == 0) ? 1. / v * 1.0e-2 : v * 1.0e-6;
+        double x = 1.0 / (LAMBDA * 1.0e6);
+        const double nH2 = AH2 * (1.0 + BH2 * x * x);
+        const double nHe = AHe * (1.0 + BHe * x * x);
+        const double nAir = fH2 * nH2 + (1 - fH2) * nHe;
+        const double temp = 32 * (PI * PI * PI) * (nAir * nAir);
+        const double N0 = P0 / (kb * T0);
+        x = N0 * LAMBDA * LAMBDA;
+        const double faniso = (6.0 + 3.0 * 0.0) / (6.0 - 7.0 * 0.0);
+        k = temp * faniso / (3. * (x * x));
+    } else if (p.mode == 12) {                                   // :5620-5632
+        const double LAMBDA = (p.ispace == 0) ? 1. / v * 1.0e4 : v;
+        const double l2 = LAMBDA * LAMBDA;
+        k = 8.8e-28 / (l2 * l2) * 1.0e-4;
+    } else if (p.mode == 2) {                                    // :5670-5695
+        const double LAMBDA = (p.ispace == 0) ? 1. / v * 1.0e4 : v;
+        const double dens = 2.5475605e+19;
+        const double lam = LAMBDA * 1.0e-4;
+        const double f_king = 1.14 + (25.3e-12) / (lam * lam);
+        const double nu2 = 1. / lam / lam;
+        const double term1 = 5799.3 / (16.618e9 - nu2) + 120.05 / (7.9609e9 - nu2) + 5.3334 / (5.6306e9 - nu2) +
+                             4.3244 / (4.6020e9 - nu2) + 1.218e-5 / (5.84745e6 - nu2);
+        const double n = 1.0 + 1.1427e3 * term1;
+        const double r = (n * n - 1) / (n * n + 2.0);
+        const double factor1 = r * r;
+        const double l2 = lam * lam;
+        k = (24. * (PI * PI * PI) / (l2 * l2) / (dens * dens)) * factor1 * f_king;
+        k = k * 1.0e-4;
+    } else {                                                     // mode 4, :5745-5824
+        const double *f = p.f4 + (size_t)l * 4;
+        const double fh2 = f[0], fhe = f[1], fch4 = f[2], fnh3 = f[3];
+        double fheh2 = 0.0, fch4h2 = 0.0;
+        if (fh2 > 0.0) { fheh2 = fhe / fh2; fch4h2 = fch4 / fh2; }
+        double comp[4];
+        comp[0] = (1.0 - fnh3) / (1.0 + fheh2 + fch4h2);
+        comp[1] = fheh2 * comp[0];
+        comp[2] = fch4h2 * comp[0];
+        comp[3] = fnh3;
+        const double losch = 2.687e19 * 1.0E+12;                 // loschpm3 as the reference forms it (:5786)
+        const double wl = (p.ispace == 0) ? 1. / v * 1.0e4 : v;
+        const double A[4] = {13.58e-5, 3.48e-5, 37.0e-5, 37.0e-5};
+        const double B[4] = {7.52e-3, 2.3e-3, 12.0e-3, 12.0e-3};
+        const double D[4] = {0.0221, 0.025, .0922, .0922};
+        double xc1 = 0.0, sumwt = 0.0;
+        const double wl2 = wl * wl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double nr = 1.0 + A[j] * (1.0 + B[j] / wl2);
+            const double t = nr * nr - 1.0;
+            xc1 = xc1 + (t * t) * comp[j] * (6.0 + 3.0 * D[j]) / (6.0 - 7.0 * D[j]);
+            sumwt = sumwt + comp[j];
+        }
+        const double fact = 8.0 * (PI * PI * PI) / (3.0 * (wl2 * wl2) * (losch * losch));
+        k = fact * xc1 * 1.0E-8 / sumwt * 1.0e-4;
+    }
+    const size_t o = (size_t)w * p.L + l;
+    p.tau[o] = k * p.totam[l];
+    p.dtau[o] = k;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Aerosol opacity of the layers: ForwardModel_0.calc_tau_dust (:4790-4867).  Per aerosol population the extinction and
+// scattering cross sections tabulated on Scatter.WAVE are interpolated to the calculation grid with scipy's
+// interp1d(kind='cubic') = the not-a-knot cubic spline (piecewise coefficients from the host, ansfm_calc_tau_dust), or
+// linearly when only two points are tabulated; where the spline leaves the physical range (ksca < 0 < kext, kext < 0 <
+// ksca, kext < ksca -- all three tested on the spline values, :4849-4851) the linear interpolant replaces it
+// (:4853-4859).  tau = k * 1e-4 * CONT[layer][population], dtau/dq = k * 1e-4.  One thread per (wavenumber, population).
+// ------------------------------------------------------------------------------------------------------------------
+struct DustParams {
+    const double *wavec;        // [W]
+    const double *swave;        // [NWS] ascending
+    const double *kext, *ksca;  // [NWS][NDUST] tabulated values
+    const double *cext, *csca;  // [NDUST][NWS-1][3] spline coefficients b, c, d per interval (cubic only)
+    const double *cont;         // [L][NDUST]
+    double *taudust, *tauclscat, *dtaudust, *dtauclscat;   // [W][L][NDUST]
+    int W, NWS, NDUST, L, cubic;
+};
+
+__global__ __launch_bounds__(128) void k_tau_dust(DustParams p)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (w >= p.W) return;
+    const double x = p.wavec[w];
+    const int n = p.NWS;
+    // spline interval: x in [x_a, x_a+1] (the last one closed); interp1d's: searchsorted(left) clipped to [1, n-1], minus 1
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (p.swave[mid] < x) lo = mid + 1; else hi = mid; }
+    int idx = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    const int a = idx - 1;
+    const double xa = p.swave[a], xb = p.swave[a + 1];
+    const double ea = p.kext[(size_t)a * p.NDUST + i], eb = p.kext[(size_t)(a + 1) * p.NDUST + i];
+    const double sa = p.ksca[(size_t)a * p.NDUST + i], sb = p.ksca[(size_t)(a + 1) * p.NDUST + i];
+    const double lin_e = ((eb - ea) / (xb - xa)) * (x - xa) + ea;
+    const double lin_s = ((sb - sa) / (xb - xa)) * (x - xa) + sa;
+    double kext = lin_e, ksca = lin_s;
+    if (p.cubic) {
+        const double t = x - xa;
+        const double *ce = p.cext + ((size_t)i * (n - 1) + a) * 3;
+        const double *cs = p.csca + ((size_t)i * (n - 1) + a) * 3;
+        const double se = ea + t * (ce[0] + t * (ce[1] + t * ce[2]));
+        const double ss = sa + t * (cs[0] + t * (cs[1] + t * cs[2]));
+        const bool inv_s = (ss < 0) && (se > 0), inv_e = (se < 0) && (ss > 0), inv_b = (se < ss);
+        kext = (inv_e || inv_b) ? lin_e : se;
+        ksca = (inv_s || inv_b) ? lin_s : ss;
+    }
+    const double de = kext * 1.0e-4, ds = ksca * 1.0e-4;
+    for (int j = 0; j < p.L; ++j) {
+        const double c = p.cont[(size_t)j * p.NDUST + i];
+        const size_t o = ((size_t)w * p.L + j) * p.NDUST + i;
+        p.taudust[o] = de * c;
+        p.tauclscat[o] = ds * c;
+        p.dtaudust[o] = de;
+        p.dtauclscat[o] = ds;
+    }
+}
+
 }  // namespace ansfm

@@ -418,6 +418,49 @@ class AnsfmEngine:
             dtau = None if dtau is None else dtau[isort, :, :]
         return (tau, dtau) if with_grad else tau
 
+    def calc_tau_rayleigh(self, IRAY, ISPACE, WAVEC, TOTAM, ID=None, ISO=None, VMR=None, variant=None):
+        """ForwardModel_0.calc_tau_rayleigh (:4869): IRAY 0 -> zeros, 1 -> calc_tau_rayleighj, 2 -> calc_tau_rayleighv2,
+        4 -> calc_tau_rayleighls (needs ID, ISO, VMR (NLAY, NVMR)); variant='v' -> calc_tau_rayleighv (:5598).
+        -> TAURAY (NWAVE, NLAY), dTAURAY (NWAVE, NLAY)."""
+        WAVEC = _np(WAVEC); TOTAM = _np(TOTAM)
+        W, L = WAVEC.size, TOTAM.size
+        IRAY = int(IRAY)
+        if variant is None and IRAY == 0:
+            return np.zeros((W, L)), np.zeros((W, L))
+        mode = 12 if variant == "v" else IRAY
+        if mode not in (1, 2, 4, 12):
+            raise ValueError("error in CIRSrad :: IRAY = " + str(IRAY) + " type has not been implemented yet")
+        f4 = None
+        if mode == 4:
+            ID = np.asarray(ID); ISO = np.asarray(ISO); VMR = _np(VMR)
+            f4 = np.zeros((L, 4))
+            for j in range(ID.size):                               # :5748-5767 (the last matching gas wins)
+                if ISO[j] in (0, 1):
+                    col = {39: 0, 40: 1, 6: 2, 11: 3}.get(int(ID[j]))
+                    if col is not None:
+                        f4[:, col] = VMR[:, j]
+            f4 = _np(f4)
+        tau = np.empty((W, L)); dtau = np.empty((W, L))
+        rc = self._lib.ansfm_calc_tau_rayleigh(self._ctx, mode, int(ISPACE), W, _ptr(WAVEC), L, _ptr(TOTAM), _ptr(f4), _ptr(tau),
+                                               _ptr(dtau))
+        self._check(rc, "calc_tau_rayleigh")
+        return tau, dtau
+
+    def calc_tau_dust(self, WAVEC, SWAVE, KEXT, KSCA, CONT):
+        """ForwardModel_0.calc_tau_dust (:4790): KEXT / KSCA (NWAVE_scatter, NDUST) on SWAVE, CONT (NLAY, NDUST) ->
+        TAUDUST, TAUCLSCAT, dTAUDUSTdq, dTAUCLSCATdq (NWAVE, NLAY, NDUST)."""
+        WAVEC = _np(WAVEC); SWAVE = _np(SWAVE); KEXT = _np(KEXT); KSCA = _np(KSCA); CONT = _np(CONT)
+        W, L, ND = WAVEC.size, CONT.shape[0], CONT.shape[1]
+        if KEXT.shape != (SWAVE.size, ND) or KSCA.shape != KEXT.shape:
+            raise ValueError("KEXT / KSCA must be (len(Scatter.WAVE), NDUST)")
+        out = [np.empty((W, L, ND)) for _ in range(4)]
+        if ND == 0:
+            return tuple(out)
+        rc = self._lib.ansfm_calc_tau_dust(self._ctx, W, _ptr(WAVEC), SWAVE.size, _ptr(SWAVE), ND, _ptr(KEXT), _ptr(KSCA), L,
+                                           _ptr(CONT), *[_ptr(o) for o in out])
+        self._check(rc, "calc_tau_dust")
+        return tuple(out)
+
     # ---- instrument line shape ---------------------------------------------------------------------------------
     def lblconv(self, nwave, vwave, y, nconv, vconv, ishape, fwhm):
         """Measurement_0.lblconv (:3335), one geometry: y (nwave) -> yout (nconv)."""

@@ -475,7 +475,7 @@ def install_gpu_convolution(device=0):
 
 def install_gpu_continuum(device=0):
     """Route ForwardModel_0.calc_tau_cia (ForwardModel_0.py:4516) -- per forward model ~2 scipy interp1d constructions per
-    (layer, CIA pair) on the host -- through the GPU.  The wavenumber-only parametrisations co2cia / n2n2cia / n2h2cia
+    (layer, CIA pair) on the host --, calc_tau_rayleigh (:4869) and calc_tau_dust (:4790) through the GPU.  The wavenumber-only parametrisations co2cia / n2n2cia / n2h2cia
     (CIA_0.py:631-880, embedded data tables) are still evaluated by the reference's own functions and passed as vectors."""
     import importlib
     fm = importlib.import_module("archnemesis.ForwardModel_0")
@@ -505,6 +505,45 @@ def install_gpu_continuum(device=0):
 
     cls._ansfm_reference_calc_tau_cia = ref
     cls.calc_tau_cia = calc_tau_cia
+
+    # Rayleigh scattering (:4869) and aerosols (:4790): same pattern, the reference's methods keep their signatures
+    ref_ray = getattr(cls, "_ansfm_reference_calc_tau_rayleigh", None) or cls.calc_tau_rayleigh
+    ref_dust = getattr(cls, "_ansfm_reference_calc_tau_dust", None) or cls.calc_tau_dust
+
+    def calc_tau_rayleigh(self, IRAY=None, ISPACE=None, WAVEC=None, ID=None, ISO=None, Layer=None, MakePlot=False):
+        if MakePlot:
+            _delegate("calc_tau_rayleigh(MakePlot=True)")
+            return ref_ray(self, IRAY, ISPACE, WAVEC, ID, ISO, Layer, MakePlot)
+        IRAY = int(self.ScatterX.IRAY if IRAY is None else IRAY)
+        ISPACE = int(self.MeasurementX.ISPACE if ISPACE is None else ISPACE)
+        WAVEC = self.SpectroscopyX.WAVE if WAVEC is None else WAVEC
+        ID = self.AtmosphereX.ID if ID is None else ID
+        ISO = self.AtmosphereX.ISO if ISO is None else ISO
+        L = self.LayerX if Layer is None else Layer
+        VMR = (np.asarray(L.PP).T / np.asarray(L.PRESS)).T if IRAY == 4 else None
+        return eng.calc_tau_rayleigh(IRAY, ISPACE, WAVEC, L.TOTAM, ID, ISO, VMR)
+
+    def calc_tau_dust(self, WAVEC=None, Scatter=None, Layer=None, MakePlot=False):
+        WAVEC = self.SpectroscopyX.WAVE if WAVEC is None else WAVEC
+        S = self.ScatterX if Scatter is None else Scatter
+        L = self.LayerX if Layer is None else Layer
+        WAVEC = np.asarray(WAVEC, dtype=np.float64)
+        if self.Scatter.NDUST > 0:                                      # the reference's own range test (:4819-4823)
+            if (WAVEC.min() < S.WAVE.min()) & (WAVEC.max() > S.WAVE.min()):
+                raise ValueError('error calc_tau_dust :: Spectral range for calculation is outside of range in which the Aerosol properties are defined')
+        for i in range(S.NDUST):                                        # side effect on Layer.CONT kept (:4833-4834)
+            if i in self.AtmosphereX.DUST_RENORMALISATION.keys():
+                L.CONT[:, i] = L.CONT[:, i] / L.CONT[:, i].sum() * 1e4 * self.AtmosphereX.DUST_RENORMALISATION[i]
+        if S.NDUST == 0:
+            z = np.zeros((len(WAVEC), L.NLAY, 0))
+            return z, z.copy(), z.copy(), z.copy()
+        return eng.calc_tau_dust(WAVEC, S.WAVE, np.asarray(S.KEXT)[:, :S.NDUST], np.asarray(S.KSCA)[:, :S.NDUST],
+                                 np.asarray(L.CONT)[:, :S.NDUST])
+
+    cls._ansfm_reference_calc_tau_rayleigh = ref_ray
+    cls._ansfm_reference_calc_tau_dust = ref_dust
+    cls.calc_tau_rayleigh = calc_tau_rayleigh
+    cls.calc_tau_dust = calc_tau_dust
     return calc_tau_cia
 
 

@@ -324,6 +324,23 @@ int ansfm_calc_tau_cia(ansfm_ctx *ctx, int W, const double *WAVEN, int NWC, cons
                        const double *xfac, int ico2, const double *k_co2, int in2, const double *k_n2n2, int ih2,
                        const double *k_n2h2, double *TAUCIA, double *dTAUCIA);
 
+/* ForwardModel_0.calc_tau_rayleigh (ForwardModel_0.py:4869): mode = IRAY -- 1 calc_tau_rayleighj (:5525, gas giants),
+ * 2 calc_tau_rayleighv2 (:5647, CO2), 4 calc_tau_rayleighls (:5712, Jovian air; f4[L][4] = mixing ratios of H2, He, CH4,
+ * NH3 per layer, 0 where absent) -- or 12 for calc_tau_rayleighv (:5598, not selected by any IRAY).  WAVEC[W] in the
+ * units of ISPACE, TOTAM[L] in m-2 -> TAURAY[W][L], dTAURAY[W][L] (= dTAURAY/dTOTAM). */
+int ansfm_calc_tau_rayleigh(ansfm_ctx *ctx, int mode, int ISPACE, int W, const double *WAVEC, int L,
+                            const double *TOTAM, const double *f4, double *TAURAY, double *dTAURAY);
+
+/* ForwardModel_0.calc_tau_dust (ForwardModel_0.py:4790): KEXT / KSCA[NWS][NDUST] tabulated on SWAVE[NWS] (Scatter.WAVE,
+ * strictly ascending) interpolated to WAVEC[W] like scipy interp1d(kind='cubic') (not-a-knot spline; linear when
+ * NWS == 2; NWS == 3 is refused as scipy refuses it), out-of-range values replaced by the linear interpolant
+ * (:4849-4859); CONT[L][NDUST] in particles m-2 (after any DUST_RENORMALISATION, which the caller applies).
+ * -> TAUDUST, TAUCLSCAT, dTAUDUSTdq, dTAUCLSCATdq [W][L][NDUST].  A WAVEC outside SWAVE is ANSFM_ERR_INVALID (the
+ * reference's interp1d raises ValueError). */
+int ansfm_calc_tau_dust(ansfm_ctx *ctx, int W, const double *WAVEC, int NWS, const double *SWAVE, int NDUST,
+                        const double *KEXT, const double *KSCA, int L, const double *CONT, double *TAUDUST,
+                        double *TAUCLSCAT, double *dTAUDUSTdq, double *dTAUCLSCATdq);
+
 /* Layer de-duplication inside a batch (n_models > 1) of the cirsrad_ck_thermal entry points.  The states of a
  * numerical Jacobian (ForwardModel_0.jacobian_nemesis :2234-2242) differ from the unperturbed one in two or three
  * layers; every layer (m, l) whose pressure, temperature and S amounts equal those of layer l of model 0 to the last

@@ -529,3 +529,83 @@ def calc_tau_cia(ISPACE, WAVEC, CIA_WAVEN, CIA_TEMP, CIA_FRAC, NPARA, K_CIA, IPA
     if isort is not None:
         tau = tau[isort, :]; dtau = dtau[isort, :, :]
     return tau, dtau
+
+
+# ---- Rayleigh scattering (ForwardModel_0.calc_tau_rayleighj :5525, rayleighv :5598, rayleighv2 :5647, rayleighls :5712)
+def calc_tau_rayleigh(mode, ISPACE, WAVEC, TOTAM, ID=None, ISO=None, VMR=None):
+    """mode = IRAY (1 gas giant, 2 CO2 (v2), 4 Jovian air) or "v" for the older CO2 formula.
+    -> TAURAY (NWAVE, NLAY), dTAURAY (NWAVE, NLAY)."""
+    WAVEC = np.asarray(WAVEC, float); TOTAM = np.asarray(TOTAM, float)
+    if mode == 1:
+        AH2 = 13.58E-5; BH2 = 7.52E-3; AHe = 3.48E-5; BHe = 2.30E-3; fH2 = 0.864
+        kb = 1.37971e-23; P0 = 1.01325e5; T0 = 273.15
+        LAMBDA = 1. / WAVEC * 1.0e-2 if ISPACE == 0 else WAVEC * 1.0e-6
+        x = 1.0 / (LAMBDA * 1.0e6)
+        nAir = fH2 * (AH2 * (1.0 + BH2 * x * x)) + (1 - fH2) * (AHe * (1.0 + BHe * x * x))
+        temp = 32 * (np.pi ** 3.) * nAir ** 2.
+        x = (P0 / (kb * T0)) * LAMBDA * LAMBDA
+        k = temp * 1.0 / (3. * (x ** 2))
+        k = np.repeat(k[:, None], TOTAM.size, axis=1)
+    elif mode == "v":
+        LAMBDA = 1. / WAVEC * 1.0e4 if ISPACE == 0 else WAVEC
+        k = np.repeat((8.8e-28 / LAMBDA ** 4. * 1.0e-4)[:, None], TOTAM.size, axis=1)
+    elif mode == 2:
+        LAMBDA = 1. / WAVEC * 1.0e4 if ISPACE == 0 else WAVEC
+        dens = 2.5475605e+19
+        lam = LAMBDA * 1.0e-4
+        f_king = 1.14 + (25.3e-12) / (lam * lam)
+        nu2 = 1. / lam / lam
+        term1 = (5799.3 / (16.618e9 - nu2) + 120.05 / (7.9609e9 - nu2) + 5.3334 / (5.6306e9 - nu2) + 4.3244 / (4.6020e9 - nu2)
+                 + 1.218e-5 / (5.84745e6 - nu2))
+        n = 1.0 + 1.1427e3 * term1
+        factor1 = ((n * n - 1) / (n * n + 2.0)) ** 2.
+        k = (24. * np.pi ** 3. / lam ** 4. / dens ** 2.) * factor1 * f_king * 1.0e-4
+        k = np.repeat(k[:, None], TOTAM.size, axis=1)
+    elif mode == 4:
+        ID = np.asarray(ID); ISO = np.asarray(ISO); VMR = np.asarray(VMR, float)
+        NLAY = VMR.shape[0]
+        f = {g: np.zeros(NLAY) for g in (39, 40, 6, 11)}
+        for j in range(ID.size):
+            if int(ID[j]) in f and ISO[j] in (0, 1):
+                f[int(ID[j])] = VMR[:, j].copy()
+        fh2, fhe, fch4, fnh3 = f[39], f[40], f[6], f[11]
+        fheh2 = np.zeros(NLAY); fch4h2 = np.zeros(NLAY)
+        ok = fh2 > 0.0
+        fheh2[ok] = fhe[ok] / fh2[ok]; fch4h2[ok] = fch4[ok] / fh2[ok]
+        comp = np.zeros((NLAY, 4))
+        comp[:, 0] = (1.0 - fnh3) / (1.0 + fheh2 + fch4h2)
+        comp[:, 1] = fheh2 * comp[:, 0]; comp[:, 2] = fch4h2 * comp[:, 0]; comp[:, 3] = fnh3
+        losch = 2.687e19 * 1.0E+12
+        wl = 1. / WAVEC * 1.0e4 if ISPACE == 0 else WAVEC
+        A = (13.58e-5, 3.48e-5, 37.0e-5, 37.0e-5); B = (7.52e-3, 2.3e-3, 12.0e-3, 12.0e-3); Dp = (0.0221, 0.025, .0922, .0922)
+        xc1 = np.zeros((NLAY, WAVEC.size)); sumwt = np.zeros(NLAY)
+        for j in range(4):
+            nr = 1.0 + A[j] * (1.0 + B[j] / wl ** 2.)
+            xc1 += np.outer(comp[:, j], (nr ** 2.0 - 1.0) ** 2.0) * (6.0 + 3.0 * Dp[j]) / (6.0 - 7.0 * Dp[j])
+            sumwt += comp[:, j]
+        fact = 8.0 * (np.pi ** 3.0) / (3.0 * (wl ** 4.0) * (losch ** 2.0))
+        k = np.transpose(fact * xc1 * 1.0E-8) / sumwt * 1.0e-4
+    else:
+        raise ValueError("mode")
+    return k * TOTAM, k.copy()
+
+
+# ---- aerosol opacity (ForwardModel_0.calc_tau_dust :4790-4867) -----------------------------------------------------
+def calc_tau_dust(WAVEC, SWAVE, KEXT, KSCA, CONT):
+    """-> TAUDUST, TAUCLSCAT, dTAUDUSTdq, dTAUCLSCATdq (NWAVE, NLAY, NDUST); scipy's interp1d does the interpolation, as in
+    the reference."""
+    from scipy import interpolate
+    WAVEC = np.asarray(WAVEC, float); SWAVE = np.asarray(SWAVE, float); CONT = np.asarray(CONT, float)
+    W, (L, ND) = WAVEC.size, CONT.shape
+    out = [np.zeros((W, L, ND)) for _ in range(4)]
+    for i in range(ND):
+        kind = "cubic" if SWAVE.size > 2 else "linear"
+        kext = interpolate.interp1d(SWAVE, KEXT[:, i], kind=kind)(WAVEC)
+        ksca = interpolate.interp1d(SWAVE, KSCA[:, i], kind=kind)(WAVEC)
+        m1 = (ksca < 0) & (kext > 0); m2 = (kext < 0) & (ksca > 0); m3 = kext < ksca
+        le = interpolate.interp1d(SWAVE, KEXT[:, i], fill_value="extrapolate")(WAVEC)
+        ls = interpolate.interp1d(SWAVE, KSCA[:, i], fill_value="extrapolate")(WAVEC)
+        ksca = np.where(m1 | m3, ls, ksca); kext = np.where(m2 | m3, le, kext)
+        out[0][:, :, i] = np.outer(kext * 1.0e-4, CONT[:, i]); out[1][:, :, i] = np.outer(ksca * 1.0e-4, CONT[:, i])
+        out[2][:, :, i] = (kext * 1.0e-4)[:, None]; out[3][:, :, i] = (ksca * 1.0e-4)[:, None]
+    return tuple(out)

@@ -68,6 +68,17 @@ class OracleEngineDouble:
         k.pop("with_grad", None)
         return self.orc.calc_tau_cia(*a, **k)
 
+    def calc_tau_rayleigh(self, IRAY, ISPACE, WAVEC, TOTAM, ID=None, ISO=None, VMR=None, variant=None):
+        self.ray_calls = getattr(self, "ray_calls", 0) + 1
+        if int(IRAY) == 0:
+            z = np.zeros((len(WAVEC), len(TOTAM)))
+            return z, z.copy()
+        return self.orc.calc_tau_rayleigh(int(IRAY), int(ISPACE), WAVEC, TOTAM, ID, ISO, VMR)
+
+    def calc_tau_dust(self, *a):
+        self.dust_calls = getattr(self, "dust_calls", 0) + 1
+        return self.orc.calc_tau_dust(*a)
+
     def map2pro(self, *a, **k):
         self.map_calls = getattr(self, "map_calls", 0) + 1
         return self.orc.map2pro(*a, **k)
@@ -210,13 +221,15 @@ def test_nemesisfmg_with_gradient_maps_routed_through_the_engine(c1_run, oracle,
     finally:
         fm0.map2pro, fm0.map2xvec = orig
         l0.layer_average, l0.layer_averageg = orig_l
-        if hasattr(fm0.ForwardModel_0, "_ansfm_reference_calc_tau_cia"):
-            fm0.ForwardModel_0.calc_tau_cia = fm0.ForwardModel_0._ansfm_reference_calc_tau_cia
-            del fm0.ForwardModel_0._ansfm_reference_calc_tau_cia
+        for name in ("calc_tau_cia", "calc_tau_rayleigh", "calc_tau_dust"):
+            if hasattr(fm0.ForwardModel_0, "_ansfm_reference_" + name):
+                setattr(fm0.ForwardModel_0, name, getattr(fm0.ForwardModel_0, "_ansfm_reference_" + name))
+                delattr(fm0.ForwardModel_0, "_ansfm_reference_" + name)
         for mod, name in ((fm0, "_ansfm_reference_maps"), (l0, "_ansfm_reference_layering")):
             if hasattr(mod, name):
                 delattr(mod, name)
     assert double.map_calls >= 2 and double.lay_calls >= 1 and double.cia_calls >= 1
+    assert double.ray_calls >= 1 and double.dust_calls >= 1
     z = np.load(os.path.join(golden_dir, "c1_cirsrad_grad.npz"))
     ref = z["dSPECONV"]
     scale = np.abs(ref).max(axis=(0, 1), keepdims=True) + 1e-300

@@ -564,6 +564,41 @@ def test_ktable_conv_filter_branch_golden(eng, golden_dir):
         eng.conv_fil(z["vwave"], z["y"], None, nc, z["vconv"], z["nfil"], vf, z["afil_k"])
 
 
+@pytest.mark.parametrize("ispace", [0, 1])
+@pytest.mark.parametrize("name,iray,variant", [("j", 1, None), ("v", 2, "v"), ("v2", 2, None), ("ls", 4, None)])
+def test_rayleigh_golden(eng, golden_dir, name, iray, variant, ispace):
+    """calc_tau_rayleighj / rayleighv / rayleighv2 / rayleighls vs the reference, wavenumber and wavelength grids."""
+    z = _load(golden_dir, "continuum_ray_dust")
+    w = z["wn"] if ispace == 0 else z["wl"]
+    t, d = eng.calc_tau_rayleigh(iray, ispace, w, z["TOTAM"], z["ID"], z["ISO"], z["VMR"], variant=variant)
+    np.testing.assert_allclose(t, z[f"ray_{name}_{ispace}_tau"], rtol=1e-13)
+    np.testing.assert_allclose(d, z[f"ray_{name}_{ispace}_dtau"], rtol=1e-13)
+    t0, d0 = eng.calc_tau_rayleigh(0, ispace, w, z["TOTAM"])
+    assert not t0.any() and not d0.any() and t0.shape == t.shape
+    with pytest.raises(ValueError):
+        eng.calc_tau_rayleigh(3, ispace, w, z["TOTAM"])               # N2-O2: not implemented in the reference either
+
+
+@pytest.mark.parametrize("pre,rows", [("dust", slice(None)), ("dust2", [0, -1])])
+def test_dust_golden(eng, oracle, golden_dir, pre, rows):
+    """calc_tau_dust vs the reference: not-a-knot spline of the host side + the linear fall-back; then a larger random
+    case against the oracle."""
+    z = _load(golden_dir, "continuum_ray_dust")
+    r = eng.calc_tau_dust(z["WAVEC_D"], z["SW"][rows], z["KEXT"][rows], z["KSCA"][rows], z["CONT"])
+    for n, a in zip(("TAUDUST", "TAUCLSCAT", "dTAUDUSTdq", "dTAUCLSCATdq"), r):
+        e = z[f"{pre}_{n}"]
+        assert np.all(np.abs(a - e) <= 1e-12 * np.abs(e).max(axis=(0, 1), keepdims=True)), n
+    if pre == "dust":
+        rng = np.random.default_rng(3)
+        SW = np.cumsum(rng.uniform(0.05, 0.4, 60)); W = np.sort(rng.uniform(SW[0], SW[-1], 5000)); W[0], W[-1] = SW[0], SW[-1]
+        KE = 10.0 ** rng.uniform(-10, -8, (60, 4)); KS = KE * rng.uniform(0.2, 1.0, KE.shape)
+        CONT = 10.0 ** rng.uniform(2, 8, (40, 4))
+        for a, e in zip(eng.calc_tau_dust(W, SW, KE, KS, CONT), oracle.calc_tau_dust(W, SW, KE, KS, CONT)):
+            assert np.all(np.abs(a - e) <= 1e-12 * np.abs(e).max(axis=(0, 1), keepdims=True))
+        with pytest.raises(ValueError):
+            eng.calc_tau_dust(np.array([SW[0] - 0.1, SW[1]]), SW, KE, KS, CONT)       # interp1d(bounds_error=True)
+
+
 def test_batch_layer_dedup_is_bit_identical(eng):
     """A numerical-Jacobian batch (every state differs from the first in two layers): layers identical to the first
     model's share its opacity rows -- same spectra and TAUGAS to the last bit, far fewer rows computed."""
