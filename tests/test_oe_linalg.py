@@ -37,6 +37,28 @@ def test_gain_matrix_and_errors(NY, NX, scalar):
     np.testing.assert_allclose(SM2, (rDD * SEf[0, 0]) @ rDD.T, rtol=0, atol=1e-10 * np.abs(rSM).max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["scalar", "diag", "full"])
+def test_phiret_and_next_xn(kind):
+    """cost function (:573-610, the three SE cases) and the state update (:655-677) vs the NumPy expressions"""
+    from archnemesis_dist_amd import oe_linalg as oe
+    NY, NX = 400, 60
+    KK, SA, SE = _case(NY, NX, 77, kind == "scalar")
+    rng = np.random.default_rng(5)
+    if kind == "full":
+        B = rng.normal(size=(NY, NY)) * 0.01
+        SE = SE + B @ B.T
+    Y = rng.normal(size=NY); YN = Y + rng.normal(size=NY) * 0.1
+    XA = rng.normal(size=NX); XN = XA + rng.normal(size=NX) * 0.2
+    PHI, CHISQ = oe.calc_phiret(Y, YN, XN, XA, SE, SA)
+    b = YN - Y; d = XN - XA
+    meas = b @ b / SE[0, 0] if kind == "scalar" else b @ np.linalg.solve(SE, b)
+    np.testing.assert_allclose(CHISQ, meas / NY, rtol=1e-11)
+    np.testing.assert_allclose(PHI, meas + d @ np.linalg.solve(SA, d), rtol=1e-11)
+    DD, AA = _numpy_gain(KK, SA, SE if kind != "scalar" else np.eye(NY) * SE[0, 0])
+    np.testing.assert_allclose(oe.calc_next_xn(XA, XN, Y, YN, DD, AA), XA + DD @ (Y - YN) - AA @ (XA - XN), rtol=1e-11, atol=1e-13)
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
