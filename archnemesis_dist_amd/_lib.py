@@ -25,7 +25,8 @@ EXPORTS = [
     "ansfm_cirsrad_ck_thermal_dev", "ansfm_get_taugas", "ansfm_last_kernel_ms",
     "ansfm_k_overlapg", "ansfm_cirsradg_ck_thermal", "ansfm_cirsradg_ck_thermal_dev", "ansfm_scloud11wave_core", "ansfm_upload_lbltable", "ansfm_calc_klbl", "ansfm_add_line_set_monochromatic_absorption", "ansfm_layer_average",
     "ansfm_map2pro", "ansfm_map2xvec", "ansfm_layer_averageg", "ansfm_lblconv", "ansfm_lblconv_fil", "ansfm_lblconv_ngeom", "ansfm_lblconv_fil_ngeom", "ansfm_conv_fil", "ansfm_calc_tau_rayleigh", "ansfm_calc_tau_dust", "ansfm_set_layer_dedup", "ansfm_last_layer_rows",
-    "ansfm_ktable_file_header", "ansfm_upload_ktable_files", "ansfm_ktable_grids", "ansfm_calc_tau_cia",
+    "ansfm_ktable_file_header", "ansfm_upload_ktable_files", "ansfm_ktable_grids", "ansfm_lbltable_file_header",
+    "ansfm_upload_lbltable_files", "ansfm_calc_tau_cia",
 ]
 
 _lib = None
@@ -125,6 +126,8 @@ def load():
     lib.ansfm_ktable_file_header.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ansfm_upload_ktable_files.argtypes = [vp, ci, C.POINTER(C.c_char_p), cd, cd]
     lib.ansfm_ktable_grids.argtypes = [vp, vp, vp, vp, vp]
+    lib.ansfm_lbltable_file_header.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp]
+    lib.ansfm_upload_lbltable_files.argtypes = [vp, ci, C.POINTER(C.c_char_p), cd, cd]
     lib.ansfm_set_layer_dedup.argtypes = [vp, ci]
     lib.ansfm_last_layer_rows.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.ansfm_lblconv.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, ci, cd, vp, vp]
@@ -163,3 +166,18 @@ def read_ktable_header(path):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     lib.ansfm_ktable_file_header(os.fsencode(path), dims, ids, hdr, p(wave), p(g_ord), p(del_g), p(press), p(temp))
     return nwave, wave, float(hdr[2]), npress, ntemp, ng, int(ids[0]), int(ids[1]), g_ord, del_g, press, temp
+
+
+def read_lbltable_header(path):
+    """Spectroscopy_0.read_ltahead (:2451) through the native reader (no GPU needed):
+    nwave, vmin, delv, npress, ntemp, gasID, isoID, presslevels, templevels  (+ the wavenumber grid as a 10th item)."""
+    import numpy as np
+    lib = load()
+    dims = (C.c_int64 * 3)(); ids = (C.c_int32 * 2)(); hdr = (C.c_double * 2)()
+    if lib.ansfm_lbltable_file_header(os.fsencode(path), dims, ids, hdr, None, None, None) != ANSFM_OK:
+        raise ValueError("not a readable .lta table (or one with NT < 0): %s" % path)
+    nwave, npress, ntemp = (int(d) for d in dims)
+    wave = np.empty(nwave); press = np.empty(npress, np.float32); temp = np.empty(ntemp, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.ansfm_lbltable_file_header(os.fsencode(path), dims, ids, hdr, p(wave), p(press), p(temp))
+    return nwave, float(hdr[0]), float(hdr[1]), npress, ntemp, int(ids[0]), int(ids[1]), press, temp, wave

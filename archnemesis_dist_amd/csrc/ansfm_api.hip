@@ -275,7 +275,55 @@ static bool kta_read_header(const char *path, KtaHeader &h, std::string &err)
     fclose(f);
     return ok;
 }
+
+// Spectroscopy_0.read_ltahead (:2451): irec0, nwave, vmin, delv, npress, ntemp, gasID, isoID, P, T -- no g-ordinates
+// (NG = 1), the wavenumbers always np.linspace(vmin, vmin + delv (nwave-1), nwave) (:2692-2693).
+static bool lta_read_header(const char *path, KtaHeader &h, std::string &err)
+{
+    std::string fn(path);
+    if (fn.size() < 4 || fn.compare(fn.size() - 4, 4, ".lta") != 0) fn += ".lta";
+    FILE *f = fopen(fn.c_str(), "rb");
+    if (!f) { err = "cannot open " + fn; return false; }
+    auto rd = [&](void *dst, size_t sz, size_t n) { return fread(dst, sz, n, f) == n; };
+    int32_t i2[2]; float f2[2]; int32_t j4[4];
+    bool ok = rd(i2, 4, 2) && rd(f2, 4, 2) && rd(j4, 4, 4);
+    if (ok) {
+        h.irec0 = i2[0]; h.nwave = i2[1];
+        h.vmin = round7((double)f2[0]); h.delv = round7((double)f2[1]); h.fwhm = 0.0;
+        h.npress = j4[0]; h.ntemp = j4[1]; h.ng = 1; h.gasID = j4[2]; h.isoID = j4[3];
+        ok = h.nwave > 0 && h.npress > 0 && h.ntemp > 0 && h.irec0 > 0;
+        if (!ok) err = "not an LBL-table header, or NT < 0 (one temperature grid per pressure level: not streamed): " + fn;
+    } else
+        err = "truncated header: " + fn;
+    if (ok) {
+        h.g_ord.assign(1, 0.0f); h.del_g.assign(1, 1.0f); h.press.resize(h.npress); h.temp.resize(h.ntemp);
+        ok = rd(h.press.data(), 4, h.npress) && rd(h.temp.data(), 4, h.ntemp);
+        h.wave.resize(h.nwave);
+        const double vmax = h.vmin + h.delv * (h.nwave - 1);
+        const double step = h.nwave > 1 ? (vmax - h.vmin) / (h.nwave - 1) : 0.0;
+        for (int i = 0; i < h.nwave; ++i) h.wave[i] = i * step + h.vmin;
+        if (h.nwave > 1) h.wave[h.nwave - 1] = vmax;
+        if (!ok) err = "truncated header arrays: " + fn;
+    }
+    fclose(f);
+    return ok;
+}
 }  // namespace
+
+int ansfm_lbltable_file_header(const char *path, int64_t dims[3], int32_t ids[2], double hdr[2], double *wave, float *press,
+                               float *temp)
+{
+    if (!path) return ANSFM_ERR_INVALID;
+    KtaHeader h; std::string err;
+    if (!lta_read_header(path, h, err)) return ANSFM_ERR_INVALID;
+    if (dims) { dims[0] = h.nwave; dims[1] = h.npress; dims[2] = h.ntemp; }
+    if (ids) { ids[0] = h.gasID; ids[1] = h.isoID; }
+    if (hdr) { hdr[0] = h.vmin; hdr[1] = h.delv; }
+    if (wave) memcpy(wave, h.wave.data(), h.wave.size() * sizeof(double));
+    if (press) memcpy(press, h.press.data(), h.npress * sizeof(float));
+    if (temp) memcpy(temp, h.temp.data(), h.ntemp * sizeof(float));
+    return ANSFM_OK;
+}
 
 int ansfm_ktable_file_header(const char *path, int64_t dims[4], int32_t ids[2], double hdr[3], double *wave, float *g_ord,
                              float *del_g, float *press, float *temp)
@@ -294,7 +342,7 @@ int ansfm_ktable_file_header(const char *path, int64_t dims[4], int32_t ids[2], 
     return ANSFM_OK;
 }
 
-int ansfm_upload_ktable_files(ansfm_ctx *ctx, int S, const char *const *paths, double wavemin, double wavemax)
+static int upload_table_files(ansfm_ctx *ctx, int S, const char *const *paths, double wavemin, double wavemax, bool lta)
 {
     CHECK_CTX(ctx);
     if (S <= 0 || !paths) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: bad argument");
@@ -302,7 +350,8 @@ int ansfm_upload_ktable_files(ansfm_ctx *ctx, int S, const char *const *paths, d
     std::vector<KtaHeader> hs(S);
     for (int s = 0; s < S; ++s) {
         std::string err;
-        if (!paths[s] || !kta_read_header(paths[s], hs[s], err)) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: " + err);
+        if (!paths[s] || !(lta ? lta_read_header(paths[s], hs[s], err) : kta_read_header(paths[s], hs[s], err)))
+            FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: " + err);
         if (hs[s].nwave != hs[0].nwave) FAIL(ANSFM_ERR_INVALID, "error :: Number of wavenumbers in all .kta files must be the same");
         if (hs[s].npress != hs[0].npress) FAIL(ANSFM_ERR_INVALID, "error :: Number of pressure levels in all .kta files must be the same");
         if (hs[s].ntemp != hs[0].ntemp) FAIL(ANSFM_ERR_INVALID, "error :: Number of temperature levels in all .kta files must be the same");
@@ -313,6 +362,7 @@ int ansfm_upload_ktable_files(ansfm_ctx *ctx, int S, const char *const *paths, d
     const KtaHeader &hl = hs[S - 1];
     const int G = hl.ng, NP = hl.npress, NT = hl.ntemp;
     if (G > ANSFM_MAX_NG || NP < 2 || NT < 2) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: need 1<=G<=32, NP>=2, NT>=2");
+    if (lta && NP > 256) FAIL(ANSFM_ERR_UNSUPPORTED, "upload_lbltable_files: NP <= 256");
     const std::vector<double> &wv = hl.wave;
     long iwl = (long)(std::upper_bound(wv.begin(), wv.end(), wavemin) - wv.begin()) - 1;
     if (iwl < 0) iwl = 0;
@@ -346,7 +396,8 @@ int ansfm_upload_ktable_files(ansfm_ctx *ctx, int S, const char *const *paths, d
         const long b = (long)(std::upper_bound(ws.begin(), ws.end(), whi) - ws.begin());
         if (b - a != W) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: the tables do not share one wavenumber grid");
         std::string fn(paths[s]);
-        if (fn.size() < 4 || fn.compare(fn.size() - 4, 4, ".kta") != 0) fn += ".kta";
+        const char *ext = lta ? ".lta" : ".kta";
+        if (fn.size() < 4 || fn.compare(fn.size() - 4, 4, ext) != 0) fn += ext;
         FILE *f = fopen(fn.c_str(), "rb");
         if (!f) FAIL(ANSFM_ERR_INVALID, "upload_ktable_files: cannot open " + fn);
         const long long off = ((long long)per_wave * a + (hs[s].irec0 - 1)) * 4;     // :2836-2838
@@ -367,9 +418,21 @@ int ansfm_upload_ktable_files(ansfm_ctx *ctx, int S, const char *const *paths, d
     ctx->monotone = (flag & 1) ? 0 : 1;
     ctx->h_delg = DELG; ctx->h_wave = WAVE; ctx->h_press = PRESS; ctx->h_temp = TEMP;
     ctx->have_table = true;
-    ctx->is_lbl = 0; ctx->temp2d = 0;
-    ctx->grid_f32 = 1; ctx->delg_f32 = 1;      // PRESS / TEMP / DELG come out of the file as float32 arrays (:2544-2559)
+    ctx->is_lbl = lta ? 1 : 0; ctx->temp2d = 0;
+    if (lta) ctx->monotone = 1;
+    ctx->grid_f32 = 1; ctx->delg_f32 = lta ? 0 : 1;   // PRESS / TEMP / DELG come out of the file as float32 arrays (:2544-2559)
     return ANSFM_OK;
+}
+
+int ansfm_upload_ktable_files(ansfm_ctx *ctx, int S, const char *const *paths, double wavemin, double wavemax)
+{
+    return upload_table_files(ctx, S, paths, wavemin, wavemax, false);
+}
+
+// Spectroscopy_0.read_lbltable (:2626) for every gas of an ILBL = 2 run: float32 k * 1e20 [wave][press][temp]
+int ansfm_upload_lbltable_files(ansfm_ctx *ctx, int S, const char *const *paths, double wavemin, double wavemax)
+{
+    return upload_table_files(ctx, S, paths, wavemin, wavemax, true);
 }
 
 int ansfm_ktable_grids(const ansfm_ctx *ctx, double *WAVE, double *PRESS, double *TEMP, double *DELG)

@@ -115,6 +115,20 @@ class AnsfmEngine:
         self._check(self._lib.ansfm_ktable_grids(self._ctx, _ptr(WAVE), _ptr(PRESS), _ptr(TEMP), _ptr(DELG)), "ktable_grids")
         return WAVE, PRESS.astype(np.float32), TEMP.astype(np.float32), DELG.astype(np.float32)
 
+    def upload_lbltable_files(self, paths, wavemin=0.0, wavemax=1.0e10):
+        """Spectroscopy_0.read_tables (:1448) for binary .lta LBL tables (ILBL = 2), straight from the files into HBM
+        (read_lbltable's Python loop over (wavenumber, pressure) never runs).  Returns WAVE, PRESS, TEMP."""
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        rc = self._lib.ansfm_upload_lbltable_files(self._ctx, len(paths), arr, float(wavemin), float(wavemax))
+        self._check(rc, "upload_lbltable_files")
+        self.dims, _ = self.ktable_info()
+        self.grid_f32 = True
+        W, G, NP, NT, S = self.dims
+        WAVE, PRESS, TEMP, DELG = np.empty(W), np.empty(NP), np.empty(NT), np.empty(G)
+        self._check(self._lib.ansfm_ktable_grids(self._ctx, _ptr(WAVE), _ptr(PRESS), _ptr(TEMP), _ptr(DELG)), "ktable_grids")
+        self.WAVE, self.DELG = WAVE, np.array([1.0])
+        return WAVE, PRESS.astype(np.float32), TEMP.astype(np.float32)
+
     def upload_lbltable(self, K, PRESS, TEMP, WAVE):
         """LBL table (ILBL = 2): K (W,NP,|NT|,S) float64 host array; TEMP (|NT|,) or (NP,|NT|) (NT < 0 form)."""
         self.set_f32_semantics(_is_f32(PRESS) or _is_f32(TEMP), False)

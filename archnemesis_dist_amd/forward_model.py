@@ -63,7 +63,8 @@ class KtaTableOnDevice:
     really needs the numbers on the host (a CPU path of the reference) gets them through __array__, read by the
     reference's own read_ktable -- slowly, once."""
 
-    def __init__(self, paths, wavemin, wavemax, shape, reader):
+    def __init__(self, paths, wavemin, wavemax, shape, reader, ext=".kta", kindex=12):
+        self.ext, self._kindex = ext, kindex      # ".lta": read_lbltable returns k as its 9th item
         self.paths = [str(p) for p in paths]
         self.wavemin, self.wavemax = float(wavemin), float(wavemax)
         self.shape = tuple(int(x) for x in shape)
@@ -73,7 +74,7 @@ class KtaTableOnDevice:
         self._host = None
         st = []
         for p in self.paths:
-            q = p if p.endswith(".kta") else p + ".kta"
+            q = p if p.endswith(ext) else p + ext
             s = os.stat(q)
             st.append((q, s.st_size, s.st_mtime_ns))
         self.fingerprint = hashlib.blake2b(repr((st, self.wavemin, self.wavemax, self.shape)).encode(), digest_size=16).hexdigest()
@@ -82,7 +83,7 @@ class KtaTableOnDevice:
         if self._host is None:
             k = np.zeros(self.shape)
             for i, p in enumerate(self.paths):
-                k[..., i] = self._reader(p, self.wavemin, self.wavemax)[12]
+                k[..., i] = self._reader(p, self.wavemin, self.wavemax)[self._kindex]
             self._host = k
         return self._host if dtype is None else self._host.astype(dtype, copy=False)
 
@@ -198,8 +199,9 @@ class CIRSradGPU:
         S = self.SpectroscopyX
         fp = _table_fingerprint(S)
         if getattr(eng, "_table_fp", None) != fp:
-            if isinstance(S.K, KtaTableOnDevice):   # .kta files -> HBM without a host array (install_gpu_table_reader)
-                WAVE = eng.upload_ktable_files(S.K.paths, S.K.wavemin, S.K.wavemax)[0]
+            if isinstance(S.K, KtaTableOnDevice):   # .kta / .lta files -> HBM without a host array (install_gpu_table_reader)
+                up = eng.upload_lbltable_files if S.K.ext == ".lta" else eng.upload_ktable_files
+                WAVE = up(S.K.paths, S.K.wavemin, S.K.wavemax)[0]
                 if WAVE.shape != np.shape(S.WAVE) or not np.array_equal(WAVE, np.asarray(S.WAVE, dtype=np.float64)):
                     raise ValueError("the .kta files no longer give the wavenumber grid Spectroscopy.WAVE holds")
             elif int(S.ILBL) == ILBL_LBL_TABLES:      # K (NWAVE,NP,|NT|,NGAS); TEMP (NP,|NT|) when NT < 0
@@ -548,7 +550,8 @@ def install_gpu_continuum(device=0):
 
 
 def install_gpu_table_reader(device=0):
-    """Spectroscopy_0.read_tables (Spectroscopy_0.py:1448) for binary k-tables without the host array: the header logic
+    """Spectroscopy_0.read_tables (Spectroscopy_0.py:1448) for binary k-tables (.kta) and LBL tables (.lta, ILBL = 2;
+    read_lbltable :2626 loops over (wavenumber, pressure) in Python) without the host array: the header logic
     (read_header, the searchsorted cut of WAVE to [wavemin, wavemax], :1482-1494) is the reference's, but instead of
     unpacking every table with the Python loops of read_ktable (:2846-2850) into a float64 (NWAVE,NG,NP,NT,NGAS) array,
     Spectroscopy.K becomes a KtaTableOnDevice description and the GPU CIRSrad streams the files into HBM
@@ -560,10 +563,13 @@ def install_gpu_table_reader(device=0):
     ref = getattr(cls, "_ansfm_reference_read_tables", None) or cls.read_tables
 
     def read_tables(self, wavemin=0., wavemax=1.0e10, wavedelta=1.0):
-        binary = (int(self.ILBL) == ILBL_K_TABLES and self.LOCATION is not None and not getattr(self, "ONLINE", False)
-                  and len(self.LOCATION) > 0 and all(str(p).endswith("kta") for p in self.LOCATION))
+        ext = {ILBL_K_TABLES: "kta", ILBL_LBL_TABLES: "lta"}.get(int(self.ILBL))
+        binary = (ext is not None and self.LOCATION is not None and not getattr(self, "ONLINE", False)
+                  and len(self.LOCATION) > 0 and all(str(p).endswith(ext) for p in self.LOCATION))
+        if binary and ext == "lta" and self.NT is not None and int(self.NT) < 0:
+            binary = False                           # one temperature grid per pressure level: not streamed
         if not binary:
-            _delegate("read_tables for tables that are not binary .kta files")
+            _delegate("read_tables for tables that are not binary .kta / .lta files")
             return ref(self, wavemin, wavemax, wavedelta)
         if self.WAVE is None:
             self.read_header()
@@ -576,8 +582,15 @@ def install_gpu_table_reader(device=0):
         wave1 = self.WAVE[iwl:iwh + 1]
         self.NWAVE = len(wave1)
         self.WAVE = wave1
-        self.K = KtaTableOnDevice(self.LOCATION, self.WAVE.min(), self.WAVE.max(),
-                                  (self.NWAVE, self.NG, self.NP, self.NT, self.NGAS), sp.read_ktable)
+        if ext == "lta":
+            if int(self.NT) < 0:                      # header only known now (read_header ran above)
+                _delegate("read_tables for .lta tables with one temperature grid per pressure level")
+                return ref(self, wavemin, wavemax, wavedelta)
+            self.K = KtaTableOnDevice(self.LOCATION, self.WAVE.min(), self.WAVE.max(),
+                                      (self.NWAVE, self.NP, self.NT, self.NGAS), sp.read_lbltable, ".lta", 8)
+        else:
+            self.K = KtaTableOnDevice(self.LOCATION, self.WAVE.min(), self.WAVE.max(),
+                                      (self.NWAVE, self.NG, self.NP, self.NT, self.NGAS), sp.read_ktable)
 
     cls._ansfm_reference_read_tables = ref
     cls.read_tables = read_tables

@@ -104,6 +104,15 @@ int ansfm_ktable_file_header(const char *path, int64_t dims[4], int32_t ids[2], 
                              float *g_ord, float *del_g, float *press, float *temp);
 int ansfm_upload_ktable_files(ansfm_ctx *ctx, int S, const char *const *paths, double wavemin, double wavemax);
 int ansfm_ktable_grids(const ansfm_ctx *ctx, double *WAVE, double *PRESS, double *TEMP, double *DELG);
+/* The same for binary LBL tables: Spectroscopy_0.read_ltahead (:2451) / read_lbltable (:2626) -- header irec0, nwave,
+ * vmin, delv, npress, ntemp, gasID, isoID, P, T, then k * 1e20 as float32 [wave][press][temp]; the reference unpacks
+ * them with a Python loop over (wavenumber, pressure), minutes for a 10^6-point table.  dims = {nwave, npress, ntemp},
+ * hdr = {vmin, delv}.  Tables with one temperature grid per pressure level (ntemp < 0) are not streamed
+ * (ANSFM_ERR_INVALID; read them with the reference and use ansfm_upload_lbltable).  After the upload the context is in
+ * the LBL-table state of ansfm_upload_lbltable; ansfm_ktable_grids returns WAVE / PRESS / TEMP (DELG = {1}). */
+int ansfm_lbltable_file_header(const char *path, int64_t dims[3], int32_t ids[2], double hdr[2], double *wave,
+                               float *press, float *temp);
+int ansfm_upload_lbltable_files(ansfm_ctx *ctx, int S, const char *const *paths, double wavemin, double wavemax);
 
 /* ---- array-level seams (host pointers), one per numba/NumPy kernel of the reference ------- */
 

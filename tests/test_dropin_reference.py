@@ -332,3 +332,27 @@ def test_measurement_lblconv_methods_routed_through_the_engine(c1_run, oracle, m
     ncalls = len(double.conv_calls)
     np.testing.assert_array_equal(Meas.conv(wave, y[:, 0], IGEOM=0), rconv(Meas, wave, y[:, 0], IGEOM=0))
     assert len(double.conv_calls) == ncalls
+
+
+def test_read_tables_keeps_lbl_tables_in_their_files(c1_run, golden_dir, monkeypatch):
+    """install_gpu_table_reader with ILBL = 2: Spectroscopy.read_tables on binary .lta tables leaves K a file
+    description (the engine streams the files); the numbers it stands for are the reference's read_tables result."""
+    ans = c1_run
+    import importlib
+    import archnemesis_dist_amd.forward_model as fmod
+    sp = importlib.import_module("archnemesis.Spectroscopy_0")
+    monkeypatch.setattr(sp.Spectroscopy_0, "read_tables", sp.Spectroscopy_0.read_tables)
+    monkeypatch.delattr(sp.Spectroscopy_0, "_ansfm_reference_read_tables", raising=False)
+    paths = [os.path.join(golden_dir, "kta", f"lbl_gas{i}.lta") for i in range(2)]
+
+    def make():
+        S = ans.Spectroscopy_0(ILBL=2)
+        S.NGAS = 2; S.ID = np.array([2, 5]); S.ISO = np.array([1, 0]); S.LOCATION = list(paths)
+        S.read_header()
+        return S
+    Sref = make(); Sref.read_tables(wavemin=2000.9, wavemax=2003.6)
+    fmod.install_gpu_table_reader()
+    S = make(); S.read_tables(wavemin=2000.9, wavemax=2003.6)
+    assert isinstance(S.K, fmod.KtaTableOnDevice) and S.K.ext == ".lta"
+    assert S.K.shape == Sref.K.shape and np.array_equal(S.WAVE, Sref.WAVE)
+    assert np.array_equal(np.asarray(S.K), Sref.K)
