@@ -212,18 +212,30 @@ def main():
     ov = float(np.mean(ov_ms)) * 1e-3
     abytes = algorithmic_bytes(W, G, S, L, NP, NT, P, 1)
     traffic = None
+    valu = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             key = f"W{W}_G{G}_S{S}_L{L}"
             traffic = tj.get(key, {}).get("ck_overlap_hbm_bytes_per_launch")
+            valu = tj.get(key, {}).get("valu_insts_per_launch")
         except Exception:
             traffic = None
     roof = {"bound": "hbm", "kernel": "k_ck_overlap", "achieved": abytes / ov / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": abytes / ov / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": abytes, "kernel_ms": ov * 1e3, "rt_kernel_ms": float(np.mean(rt_ms)),
-            "note": "second bound (fp64 VALU of the per-lane G-way merge, kernel at ~71% of it) dominates; see DESIGN.md 4.1"}
+            "note": "second bound (fp64 VALU of the per-lane G-way merge) dominates; see second_bound and DESIGN.md 4.1"}
+    if valu:
+        # the kernel's own limit: wave64 VALU instructions issued (SQ_INSTS_VALU of the committed PMC pass, per launch)
+        # against what the chip can issue -- one wave64 fp64 instruction per SIMD every 4 clocks
+        props = torch.cuda.get_device_properties(dev)
+        n_simd = props.multi_processor_count * 4
+        clk_hz = 2.4e9                                                    # MI355X peak engine clock (MI355X_MICROARCH.md)
+        peak = n_simd * clk_hz / 4.0
+        roof["second_bound"] = {"bound": "valu_issue", "insts_per_launch": valu, "achieved": valu / ov / 1e9,
+                                "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": valu / ov / peak,
+                                "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json (rocprofv3 --pmc pass) / live kernel time"}
 
     # ---- CPU baseline: the oracle (port) on a bounded sample, rank 0 only ---------------------------------
     cpu = None

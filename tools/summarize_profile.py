@@ -46,6 +46,7 @@ def main():
         traffic = {"W10000_G20_S8_L100": {
             "ck_overlap_hbm_bytes_per_launch": 2 * fetch + write,
             "fetch_bytes_raw": fetch, "fetch_bytes_x2_gfx950_correction": 2 * fetch, "write_bytes": write,
+            "valu_insts_per_launch": s.get("SQ_INSTS_VALU"), "lds_insts_per_launch": s.get("SQ_INSTS_LDS"),
             "profile": tag,
             "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile.sh), average per "
                     "k_ck_overlap launch; FETCH doubled per MI355X_MICROARCH.md HBM section, factor confirmed for "
