@@ -7,6 +7,7 @@
 #include "ansfm_map_kernels.hip.h"
 #include "ansfm_conv_kernels.hip.h"
 #include "ansfm_cont_kernels.hip.h"
+#include "ansfm_kdist.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -1646,6 +1647,65 @@ int ansfm_calc_tau_dust(ansfm_ctx *ctx, int W, const double *WAVEC, int NWS, con
     HIPCHK(hipMemcpyAsync(TAUCLSCAT, p.tauclscat, nt * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(dTAUDUSTdq, p.dtaudust, nt * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(dTAUCLSCATdq, p.dtauclscat, nt * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* k-table generator: k-distribution of an LBL spectrum in bins (Spectroscopy_0.calc_ktable_chunk) */
+/* ------------------------------------------------------------------------------------------ */
+int ansfm_kdist_bins(ansfm_ctx *ctx, int ncalc, const double *wavecalc, const double *kabs, int nbin, const double *vbinmin,
+                     const double *vbinmax, const double *wcen, int nfilmax, const int32_t *nfil, const double *dfil,
+                     const double *afil, int NG, const double *g_ord, double *kout)
+{
+    CHECK_CTX(ctx);
+    if (ncalc < 2 || nbin <= 0 || NG <= 0 || !wavecalc || !kabs || !vbinmin || !vbinmax || !g_ord || !kout ||
+        (nfil && (!dfil || !afil || !wcen || nfilmax < 1)))
+        FAIL(ANSFM_ERR_INVALID, "kdist_bins: bad argument");
+    for (int i = 1; i < ncalc; ++i)
+        if (!(wavecalc[i] > wavecalc[i - 1])) FAIL(ANSFM_ERR_UNSORTED, "kdist_bins: the line-by-line grid must be ascending");
+    // mask = (wavecalc >= vbinmin) & (wavecalc <= vbinmax)   (:3633)
+    std::vector<int32_t> i0(nbin);
+    std::vector<int64_t> off(nbin + 1, 0);
+    for (int b = 0; b < nbin; ++b) {
+        const long a = (long)(std::lower_bound(wavecalc, wavecalc + ncalc, vbinmin[b]) - wavecalc);
+        const long e = (long)(std::upper_bound(wavecalc, wavecalc + ncalc, vbinmax[b]) - wavecalc);
+        if (e <= a) FAIL(ANSFM_ERR_INVALID, "kdist_bins: a bin holds no line-by-line point (np.interp would raise on the empty sample)");
+        if (nfil && (nfil[b] < 1 || nfil[b] > nfilmax)) FAIL(ANSFM_ERR_INVALID, "kdist_bins: 1 <= nfil[bin] <= rows of the filter arrays");
+        i0[b] = (int32_t)a;
+        off[b + 1] = off[b] + (e - a);
+    }
+    const int64_t total = off[nbin];
+    if (total > 0x7fffffffLL) FAIL(ANSFM_ERR_UNSUPPORTED, "kdist_bins: more than 2^31 points in one call; split the bins");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t D = sizeof(double);
+    const void *d[10] = {nullptr};
+    int rc;
+    if ((rc = h2d(ctx, ctx->hb[0], wavecalc, ncalc * D, &d[0]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[1], kabs, ncalc * D, &d[1]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[2], i0.data(), nbin * sizeof(int32_t), &d[2]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[3], off.data(), (nbin + 1) * sizeof(int64_t), &d[3]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[4], g_ord, NG * D, &d[4]))) return rc;
+    if (nfil) {
+        if ((rc = h2d(ctx, ctx->hb[5], wcen, nbin * D, &d[5]))) return rc;
+        if ((rc = h2d(ctx, ctx->hb[6], nfil, nbin * sizeof(int32_t), &d[6]))) return rc;
+        if ((rc = h2d(ctx, ctx->hb[7], dfil, (size_t)nfilmax * nbin * D, &d[7]))) return rc;
+        if ((rc = h2d(ctx, ctx->hb[8], afil, (size_t)nfilmax * nbin * D, &d[8]))) return rc;
+    }
+    HIPCHK(ctx->tmp_in.reserve((size_t)total * D));
+    HIPCHK(ctx->tmp_in2.reserve((size_t)total * D));
+    HIPCHK(ctx->tmp_out.reserve((size_t)nbin * NG * D));
+    KdistParams p;
+    memset(&p, 0, sizeof p);
+    p.wavecalc = (const double *)d[0]; p.kabs = (const double *)d[1]; p.i0 = (const int32_t *)d[2]; p.off = (const int64_t *)d[3];
+    p.g_ord = (const double *)d[4]; p.wcen = (const double *)d[5]; p.nfil = (const int32_t *)d[6];
+    p.dfil = (const double *)d[7]; p.afil = (const double *)d[8];
+    p.keys = ctx->tmp_in.as<double>(); p.vals = ctx->tmp_in2.as<double>(); p.kout = ctx->tmp_out.as<double>();
+    p.dv = wavecalc[1] - wavecalc[0];                                     // delvarray (:3647)
+    p.nbin = nbin; p.NG = NG;
+    const int herr = ansfm_kdist_run((void *)ctx->stream, p, total);
+    if (herr != 0) FAIL(ANSFM_ERR_HIP, std::string("kdist_bins: ") + hipGetErrorString((hipError_t)herr));
+    HIPCHK(hipMemcpyAsync(kout, p.kout, (size_t)nbin * NG * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ANSFM_OK;
 }

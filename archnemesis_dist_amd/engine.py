@@ -475,6 +475,26 @@ class AnsfmEngine:
         self._check(rc, "calc_tau_dust")
         return tuple(out)
 
+    def kdist_bins(self, wavecalc, kabs, vbinmin, vbinmax, g_ord, fil=None):
+        """Numerical core of Spectroscopy_0.calc_ktable_chunk (:3620-3652): k-distribution of the line-by-line spectrum
+        kabs on the uniform grid wavecalc inside each bin [vbinmin, vbinmax], read at the g-ordinates.  fil = (bin
+        centres, nfil (nbin), dfil (NF, nbin) = VFIL - VCONV, afil (NF, nbin)) weights the points with the instrument
+        function, None = equal weights.  -> (nbin, NG)."""
+        wavecalc = _np(wavecalc); kabs = _np(kabs); vbinmin = _np(vbinmin); vbinmax = _np(vbinmax); g_ord = _np(g_ord)
+        nbin, NG = vbinmin.size, g_ord.size
+        out = np.empty((nbin, NG))
+        if fil is None:
+            args = (None, 0, None, None, None)
+        else:
+            wcen, nfil, dfil, afil = _np(fil[0]), _np(fil[1], np.int32), _np(fil[2]), _np(fil[3])
+            if dfil.shape != afil.shape or dfil.shape[1] != nbin or nfil.shape != (nbin,) or wcen.shape != (nbin,):
+                raise ValueError("fil = (centres (nbin), nfil (nbin), dfil (NF, nbin), afil (NF, nbin))")
+            args = (_ptr(wcen), dfil.shape[0], _ptr(nfil), _ptr(dfil), _ptr(afil))
+        rc = self._lib.ansfm_kdist_bins(self._ctx, wavecalc.size, _ptr(wavecalc), _ptr(kabs), nbin, _ptr(vbinmin), _ptr(vbinmax),
+                                        *args, NG, _ptr(g_ord), _ptr(out))
+        self._check(rc, "kdist_bins")
+        return out
+
     # ---- instrument line shape ---------------------------------------------------------------------------------
     def lblconv(self, nwave, vwave, y, nconv, vconv, ishape, fwhm):
         """Measurement_0.lblconv (:3335), one geometry: y (nwave) -> yout (nconv)."""

@@ -114,6 +114,18 @@ int ansfm_lbltable_file_header(const char *path, int64_t dims[3], int32_t ids[2]
                                float *press, float *temp);
 int ansfm_upload_lbltable_files(ansfm_ctx *ctx, int S, const char *const *paths, double wavemin, double wavemax);
 
+/* The k-table GENERATOR's numerical core, Spectroscopy_0.calc_ktable_chunk (Spectroscopy_0.py:3620-3652): from a
+ * line-by-line spectrum kabs[ncalc] on the uniform grid wavecalc[ncalc], for each of nbin bins [vbinmin, vbinmax] the
+ * points inside are sorted by k, weighted by the instrument function (np.interp of afil over dfil = VFIL - VCONV at the
+ * distance from the bin centre wcen; nfil == NULL: weight 1), g = cumsum(w dv) / sum(w dv), and k is read at the
+ * g-ordinates: kout[nbin][NG] = np.interp(g_ord, g_sorted, k_sorted).  dfil / afil are [nfilmax][nbin] with nfil[bin]
+ * valid rows.  A bin without points is ANSFM_ERR_INVALID (np.interp raises there).  The sort is one segmented radix
+ * sort over all bins (rocPRIM). */
+int ansfm_kdist_bins(ansfm_ctx *ctx, int ncalc, const double *wavecalc, const double *kabs, int nbin,
+                     const double *vbinmin, const double *vbinmax, const double *wcen, int nfilmax,
+                     const int32_t *nfil, const double *dfil, const double *afil, int NG, const double *g_ord,
+                     double *kout);
+
 /* ---- array-level seams (host pointers), one per numba/NumPy kernel of the reference ------- */
 
 /* Spectroscopy_0.calc_k (Spectroscopy_0.py:2298) / calc_kg (:2147), WAVECALC=None.

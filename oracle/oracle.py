@@ -609,3 +609,24 @@ def calc_tau_dust(WAVEC, SWAVE, KEXT, KSCA, CONT):
         out[0][:, :, i] = np.outer(kext * 1.0e-4, CONT[:, i]); out[1][:, :, i] = np.outer(ksca * 1.0e-4, CONT[:, i])
         out[2][:, :, i] = (kext * 1.0e-4)[:, None]; out[3][:, :, i] = (ksca * 1.0e-4)[:, None]
     return tuple(out)
+
+
+# ---- k-table generator: k-distribution of an LBL spectrum in bins (Spectroscopy_0.calc_ktable_chunk :3620-3652) -----
+def kdist_bins(wavecalc, kabs, vbinmin, vbinmax, g_ord, fil=None):
+    """fil = (centres, nfil, dfil (NF, nbin), afil (NF, nbin)) or None.  -> (nbin, NG)."""
+    wavecalc = np.asarray(wavecalc, float); kabs = np.asarray(kabs, float)
+    out = np.zeros((len(vbinmin), len(g_ord)))
+    for b in range(len(vbinmin)):
+        mask = (wavecalc >= vbinmin[b]) & (wavecalc <= vbinmax[b])
+        idx = np.argsort(kabs[mask], kind="stable")
+        wavesel = wavecalc[mask]
+        k_sorted = kabs[mask][idx]
+        if fil is not None:
+            n = int(fil[1][b])
+            ils = np.interp(wavesel[idx] - fil[0][b], fil[2][:n, b], fil[3][:n, b])
+        else:
+            ils = np.ones_like(wavesel)
+        dv = np.zeros_like(k_sorted) + (wavecalc[1] - wavecalc[0])
+        g_sorted = np.cumsum(ils * dv) / np.sum(ils * dv)
+        out[b] = np.interp(g_ord, g_sorted, k_sorted)
+    return out
