@@ -25,3 +25,18 @@ for r in csv.DictReader(open(f)):
 for k,cs in acc.items(): print(k, {c: sum(v)/len(v) for c,v in cs.items()})
 PY
 fi
+# optional VALU / LDS issue counters of the same section (own pass): bash tools/prof_extra.sh lbl_c5 <tag> valu
+if [ "$3" = "valu" ]; then
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_valu -- python3 tools/bench_extra.py $SEC > $OUT/pmc_valu.log 2>&1 || exit 1
+  python3 - <<PY
+import csv,glob,json
+from collections import defaultdict
+f=glob.glob("$OUT/pmc_valu/**/*counter_collection.csv",recursive=True)[0]
+acc=defaultdict(lambda: defaultdict(list))
+for r in csv.DictReader(open(f)):
+    if "ansfm" in r["Kernel_Name"]: acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out={k: {c: sum(v)/len(v) for c,v in cs.items()} for k,cs in acc.items()}
+json.dump(out, open("$OUT/pmc_valu_summary.json","w"), indent=1)
+for k,v in out.items(): print(k, v)
+PY
+fi
