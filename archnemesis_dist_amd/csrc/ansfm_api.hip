@@ -1342,7 +1342,7 @@ int ansfm_map2xvec(ansfm_ctx *ctx, int W, int NPAR, int NPRO, int P, int NX, con
 static int ils_conv_impl(ansfm_ctx *ctx, int nwave, const double *vwave, int ny, const double *y, int nx, const double *dydx,
                          int nconv, const double *vconv, int ishape, double fwhm, int hamming_rule, int nfilmax,
                          const int32_t *nfil, const double *vfil, const double *afil, double *yout, double *gradout,
-                         bool bracket = false)
+                         bool bracket = false, bool integrate = false)
 {
     CHECK_CTX(ctx);
     const bool filter = nfil != nullptr;
@@ -1381,7 +1381,7 @@ static int ils_conv_impl(ansfm_ctx *ctx, int nwave, const double *vwave, int ny,
     p.nfil = (const int32_t *)d[4]; p.vfil = (const double *)d[5]; p.afil = (const double *)d[6];
     p.yout = ctx->tmp_out.as<double>(); p.gradout = p.yout + (size_t)nconv * ny;
     p.nwave = nwave; p.nx = nx; p.ny = ny; p.nconv = nconv; p.ishape = ishape; p.hamming_rule = hamming_rule;
-    p.filter = filter ? (bracket ? 2 : 1) : 0;
+    p.filter = filter ? (integrate ? 3 : bracket ? 2 : 1) : 0;
     p.fwhm = fwhm;
     hipLaunchKernelGGL(k_ils_conv, dim3((unsigned)nconv, (unsigned)((nx + ny + 127) / 128)), dim3(128), 0, ctx->stream, p);
     HIPCHK(hipGetLastError());
@@ -1423,6 +1423,15 @@ int ansfm_conv_fil(ansfm_ctx *ctx, int nwave, const double *vwave, const double 
     if (ctx && !nfil) FAIL(ANSFM_ERR_INVALID, "conv_fil: bad argument");
     return ils_conv_impl(ctx, nwave, vwave, 1, y, nx, dydx, nconv, vconv, 0, 0.0, 0, nfilmax, nfil, vfil, afil, yout, gradout,
                          true);
+}
+
+int ansfm_integrate_filter(ansfm_ctx *ctx, int nwave, const double *vwave, int ngeom, const double *y, int nx,
+                           const double *dydx, int nconv, const double *vconv, int nfilmax, const int32_t *nfil,
+                           const double *vfil, const double *afil, double *yout, double *gradout)
+{
+    if (ctx && (!nfil || ngeom <= 0)) FAIL(ANSFM_ERR_INVALID, "integrate_filter: bad argument");
+    return ils_conv_impl(ctx, nwave, vwave, ngeom, y, ngeom * nx, dydx, nconv, vconv, 0, 0.0, 0, nfilmax, nfil, vfil, afil,
+                         yout, gradout, false, true);
 }
 
 int ansfm_lblconv_fil_ngeom(ansfm_ctx *ctx, int nwave, const double *vwave, int ngeom, const double *y, int nx,

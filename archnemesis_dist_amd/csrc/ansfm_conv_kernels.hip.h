@@ -22,6 +22,7 @@ struct ConvParams {
     const double *vfil, *afil;           // filter mode: [nfilmax][nconv]
     double *yout, *gradout;              // [nconv][ny], [nconv][nx]
     int nwave, nx, ny, nconv, ishape, hamming_rule, filter;   // filter 2: Measurement_0.conv / convg window (bracketing points)
+                                                               // filter 3: integrate_filter* -- np.trapz of filter x spectrum, no normalisation
     double fwhm;
 };
 
@@ -84,6 +85,11 @@ __global__ __launch_bounds__(128) void k_ils_conv(ConvParams p)
                 const double x0 = xp[(size_t)a * p.nconv], x1 = xp[(size_t)(a + 1) * p.nconv];
                 const double y0 = yp[(size_t)a * p.nconv], y1 = yp[(size_t)(a + 1) * p.nconv];
                 f = (v >= v2) ? yp[(size_t)(nf - 1) * p.nconv] : (v <= v1) ? yp[0] : ((y1 - y0) / (x1 - x0)) * (v - x0) + y0;
+                if (p.filter == 3) {       // trapezoid node weight: f_i (dv_left + dv_right) / 2 inside the window (:4124)
+                    const double dl = (i > i0x) ? v - p.vwave[i - 1] : 0.0;
+                    const double dr = (i + 1 < i1) ? p.vwave[i + 1] - v : 0.0;
+                    f = f * (0.5 * (dl + dr));
+                }
             } else
                 f = conv_shape(p.ishape, v, vcen, p.fwhm, sig);
         }
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(128) void k_ils_conv(ConvParams p)
             const int n = min(128, i1 - base);
             for (int k = 0; k < n; ++k) {
                 const double fk = fw[k];
-                if (fk > 0.0) {                            // :3433
+                if (fk > 0.0 || p.filter == 3) {           // :3433 (the integrals take every point)
                     const double val = (c < p.nx) ? p.dydx[(size_t)(base + k) * p.nx + c]
                                                   : p.y[(size_t)(base + k) * p.ny + (c - p.nx)];
                     acc = acc + fk * val;
@@ -103,8 +109,9 @@ __global__ __launch_bounds__(128) void k_ils_conv(ConvParams p)
             }
         }
     }
-    if (c < p.nx) p.gradout[(size_t)j * p.nx + c] = acc / nor;
-    else if (c < ncol) p.yout[(size_t)j * p.ny + (c - p.nx)] = acc / nor;
+    const double res = (p.filter == 3) ? acc : acc / nor;
+    if (c < p.nx) p.gradout[(size_t)j * p.nx + c] = res;
+    else if (c < ncol) p.yout[(size_t)j * p.ny + (c - p.nx)] = res;
 }
 
 }  // namespace ansfm

@@ -534,7 +534,13 @@ class AnsfmEngine:
         r = self._lblconv(vwave, y, dydx, nconv, vconv, None, None, (nfil, vfil, afil), bracket=True)
         return r if dydx is not None else r[0]
 
-    def _lblconv(self, vwave, y, dydx, nconv, vconv, ishape, fwhm, fil=None, ngeom=False, bracket=False):
+    def integrate_filter(self, nwave, vwave, y, nconv, vconv, nfil, vfil, afil, dydx=None):
+        """Measurement_0.integrate_filter (:4079) / integrate_filterg (:4188; dydx given) and, for y (nwave, ngeom) [dydx
+        (nwave, ngeom, nx)], integrate_filter_ngeom (:4131) / integrate_filterg_ngeom (:4251)."""
+        r = self._lblconv(vwave, y, dydx, nconv, vconv, None, None, (nfil, vfil, afil), ngeom=(np.ndim(y) == 2), integrate=True)
+        return r if dydx is not None else r[0]
+
+    def _lblconv(self, vwave, y, dydx, nconv, vconv, ishape, fwhm, fil=None, ngeom=False, bracket=False, integrate=False):
         vwave = _np(vwave); y = _np(y); vconv = _np(np.asarray(vconv)[:nconv])
         nd = 2 if ngeom else 1
         if y.ndim != nd or (dydx is not None and np.ndim(dydx) != nd + 1):
@@ -548,6 +554,12 @@ class AnsfmEngine:
         if fil is not None:
             nfil = _np(np.asarray(fil[0])[:nconv], np.int32)
             vfil = _np(np.asarray(fil[1])[:, :nconv]); afil = _np(np.asarray(fil[2])[:, :nconv])
+        if integrate:
+            rc = self._lib.ansfm_integrate_filter(self._ctx, vwave.size, _ptr(vwave), ng, _ptr(y), nx, _ptr(dydx), int(nconv),
+                                                  _ptr(vconv), vfil.shape[0], _ptr(nfil), _ptr(vfil), _ptr(afil), _ptr(yout),
+                                                  _ptr(gout))
+            self._check(rc, "integrate_filter")
+            return (yout, gout) if ngeom else (yout[:, 0], gout[:, 0, :])
         if ngeom:
             if fil is None:
                 rc = self._lib.ansfm_lblconv_ngeom(self._ctx, vwave.size, _ptr(vwave), ng, _ptr(y), nx, _ptr(dydx), int(nconv),

@@ -469,6 +469,23 @@ def install_gpu_convolution(device=0):
                             self.AFIL)
 
     cls.conv, cls.convg = conv, convg
+    # filter integrals (:4079-4300): np.trapz of filter x spectrum per convolution point
+    if not hasattr(m0, "_ansfm_reference_intf"):
+        m0._ansfm_reference_intf = (m0.integrate_filter, m0.integrate_filter_ngeom, m0.integrate_filterg, m0.integrate_filterg_ngeom)
+    rint = m0._ansfm_reference_intf
+
+    def _intf(k, nd, with_grad):
+        def f(nwave, vwave, y, *rest):
+            dydx = rest[0] if with_grad else None
+            nconv, vconv, nfil, vfil, afil = rest[1:] if with_grad else rest
+            if np.ndim(y) != nd or (with_grad and np.ndim(dydx) != nd + 1) or not _ascending(vwave):
+                _delegate("integrate_filter* on an unsorted grid")
+                return rint[k](nwave, vwave, y, *rest)
+            return eng.integrate_filter(nwave, vwave, y, nconv, vconv, nfil, vfil, afil, dydx=dydx)
+        return f
+
+    m0.integrate_filter, m0.integrate_filter_ngeom = _intf(0, 1, False), _intf(1, 2, False)
+    m0.integrate_filterg, m0.integrate_filterg_ngeom = _intf(2, 1, True), _intf(3, 2, True)
     m0.lblconv, m0.lblconvg, m0.lblconv_fil, m0.lblconvg_fil = lblconv, lblconvg, lblconv_fil, lblconvg_fil
     m0.lblconv_ngeom, m0.lblconvg_ngeom = lblconv_ngeom, lblconvg_ngeom
     m0.lblconv_fil_ngeom, m0.lblconvg_fil_ngeom = lblconv_fil_ngeom, lblconvg_fil_ngeom

@@ -319,6 +319,13 @@ int ansfm_lblconv_fil_ngeom(ansfm_ctx *ctx, int nwave, const double *vwave, int 
                             const double *dydx, int nconv, const double *vconv, int nfilmax, const int32_t *nfil,
                             const double *vfil, const double *afil, double *yout, double *gradout);
 
+/* integrate_filter (:4079) / integrate_filterg (:4188) and their *_ngeom variants (:4131, :4251): np.trapz of
+ * (filter x spectrum) over the calculation points inside each filter, no normalisation.  y[nwave][ngeom],
+ * dydx[nwave][ngeom][nx] (ngeom = 1 for the single-geometry functions) -> yout[nconv][ngeom], gradout[nconv][ngeom][nx]. */
+int ansfm_integrate_filter(ansfm_ctx *ctx, int nwave, const double *vwave, int ngeom, const double *y, int nx,
+                           const double *dydx, int nconv, const double *vconv, int nfilmax, const int32_t *nfil,
+                           const double *vfil, const double *afil, double *yout, double *gradout);
+
 /* Measurement_0.conv (:2288) / convg (:2467), k-table runs, FWHM < 0 branch (:2425-2461, :2655-2691): the filter
  * average of lblconv_fil, but over the window from the last calculation point BELOW vfil[0][j] to the first ABOVE
  * vfil[nfil[j]-1][j] (both must exist: the reference raises IndexError otherwise -> ANSFM_ERR_INVALID), np.interp

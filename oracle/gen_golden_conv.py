@@ -74,6 +74,13 @@ def main():
         out["kconv_0"] = Meas.conv(vwave, y, IGEOM=0)
         yo, go = Meas.convg(vwave, y, dydx, IGEOM=0)
         out["kconvg_0_y"] = yo; out["kconvg_0_g"] = go
+        # filter integrals (no normalisation): integrate_filter / integrate_filterg and the *_ngeom variants
+        out["intf"] = M0.integrate_filter(nwave, vwave, y, nconv, vconv, nfil, vfil, afil)
+        yo, go = M0.integrate_filterg(nwave, vwave, y, dydx, nconv, vconv, nfil, vfil, afil)
+        out["intfg_y"] = yo; out["intfg_g"] = go
+        out["ngintf"] = M0.integrate_filter_ngeom(nwave, vwave, y2, nconv, vconv, nfil, vfil, afil)
+        yo, go = M0.integrate_filterg_ngeom(nwave, vwave, y2, dydx3, nconv, vconv, nfil, vfil, afil)
+        out["ngintfg_y"] = yo; out["ngintfg_g"] = go
     np.savez_compressed(os.path.join(OUT, "ils_conv.npz"), **out)
     print({k: (np.shape(v), bool(np.isnan(v).any())) for k, v in out.items() if k.startswith(("conv", "fil", "ngconv", "ngfil", "kconv"))})
 

@@ -436,6 +436,23 @@ def lblconv_fil(nwave, vwave, y, nconv, vconv, nfil, vfil, afil, dydx=None, ngeo
     return _ils_split(out, ng, nx, grad, ngeom)
 
 
+def integrate_filter(nwave, vwave, y, nconv, vconv, nfil, vfil, afil, dydx=None):
+    """Measurement_0.integrate_filter (:4079) / integrate_filterg (:4188) and, for y (nwave, ngeom), their *_ngeom
+    variants (:4131, :4251): np.trapz of filter x spectrum inside each filter."""
+    vwave = np.asarray(vwave, float)
+    ngeom = np.ndim(y) == 2
+    grad = dydx is not None
+    cols, ng, nx = _ils_cols(y, dydx, ngeom)
+    out = np.zeros((nconv, cols.shape[1]))
+    for j in range(nconv):
+        n = int(nfil[j])
+        idx = np.where((vwave >= vfil[0, j]) & (vwave <= vfil[n - 1, j]))[0]
+        f = np.interp(vwave[idx], vfil[:n, j], afil[:n, j])
+        trapz = getattr(np, "trapezoid", None) or np.trapz
+        out[j] = trapz(cols[idx] * f[:, None], vwave[idx], axis=0)
+    return _ils_split(out, ng, nx, grad, ngeom)
+
+
 # ---- collision-induced absorption (ForwardModel_0.calc_tau_cia :4516-4760) -----------------------------------------
 def calc_tau_cia(ISPACE, WAVEC, CIA_WAVEN, CIA_TEMP, CIA_FRAC, NPARA, K_CIA, IPAIRG1, IPAIRG2, INORMALT, INORMAL, INORMALD,
                  ID, ISO, PP, PRESS, TEMP, FRAC, TOTAM, DELH, k_co2=None, k_n2n2=None, k_n2h2=None):

@@ -61,3 +61,18 @@ def test_ktable_conv_filter_branch(oracle, golden_dir):
     close_nan(yo, z["kconvg_fil_y"], 1e-13)
     close_nan(go, z["kconvg_fil_g"], 1e-13)
     assert np.max(np.abs(z["kconv_fil"] / oracle.lblconv_fil(*a) - 1)) > 1e-6      # the bracketing points do carry weight
+
+
+def test_integrate_filter_family(oracle, golden_dir):
+    """integrate_filter / integrate_filterg and the *_ngeom variants (:4079-4300): np.trapz of filter x spectrum"""
+    z = np.load(os.path.join(golden_dir, "ils_conv.npz"))
+    nw, nc = z["vwave"].size, z["vconv"].size
+    f = (nc, z["vconv"], z["nfil"], z["vfil"], z["afil"])
+    np.testing.assert_allclose(oracle.integrate_filter(nw, z["vwave"], z["y"], *f), z["intf"], rtol=1e-13)
+    yo, go = oracle.integrate_filter(nw, z["vwave"], z["y"], *f, dydx=z["dydx"])
+    np.testing.assert_allclose(yo, z["intfg_y"], rtol=1e-13)
+    np.testing.assert_allclose(go, z["intfg_g"], rtol=0, atol=1e-13 * np.abs(z["intfg_g"]).max())
+    np.testing.assert_allclose(oracle.integrate_filter(nw, z["vwave"], z["y_ngeom"], *f), z["ngintf"], rtol=1e-13)
+    yo, go = oracle.integrate_filter(nw, z["vwave"], z["y_ngeom"], *f, dydx=z["dydx_ngeom"])
+    np.testing.assert_allclose(yo, z["ngintfg_y"], rtol=1e-13)
+    np.testing.assert_allclose(go, z["ngintfg_g"], rtol=0, atol=1e-13 * np.abs(z["ngintfg_g"]).max())

@@ -280,8 +280,10 @@ def test_measurement_lblconv_methods_routed_through_the_engine(c1_run, oracle, m
     monkeypatch.setattr(fmod, "get_engine", lambda device=0: double)
     for n, f in ref.items():                       # undo the module patch after the test
         monkeypatch.setattr(m0, n, f)
-    for n in ("lblconv_fil", "lblconvg_fil", "lblconv_fil_ngeom", "lblconvg_fil_ngeom"):
+    for n in ("lblconv_fil", "lblconvg_fil", "lblconv_fil_ngeom", "lblconvg_fil_ngeom", "integrate_filter",
+              "integrate_filter_ngeom", "integrate_filterg", "integrate_filterg_ngeom"):
         monkeypatch.setattr(m0, n, getattr(m0, n))
+    monkeypatch.delattr(m0, "_ansfm_reference_intf", raising=False)
     monkeypatch.delattr(m0, "_ansfm_reference_conv", raising=False)
     rconv, rconvg = m0.Measurement_0.conv, m0.Measurement_0.convg
     monkeypatch.setattr(m0.Measurement_0, "conv", rconv)

@@ -599,6 +599,21 @@ def test_dust_golden(eng, oracle, golden_dir, pre, rows):
             eng.calc_tau_dust(np.array([SW[0] - 0.1, SW[1]]), SW, KE, KS, CONT)       # interp1d(bounds_error=True)
 
 
+def test_integrate_filter_family_golden(eng, golden_dir):
+    """integrate_filter / integrate_filterg / *_ngeom vs the reference (trapezoid weights formed per node on the GPU)."""
+    z = _load(golden_dir, "ils_conv")
+    nw, nc = z["vwave"].size, z["vconv"].size
+    f = (nc, z["vconv"], z["nfil"], z["vfil"], z["afil"])
+    np.testing.assert_allclose(eng.integrate_filter(nw, z["vwave"], z["y"], *f), z["intf"], rtol=1e-12)
+    yo, go = eng.integrate_filter(nw, z["vwave"], z["y"], *f, dydx=z["dydx"])
+    np.testing.assert_allclose(yo, z["intfg_y"], rtol=1e-12)
+    np.testing.assert_allclose(go, z["intfg_g"], rtol=0, atol=1e-12 * np.abs(z["intfg_g"]).max())
+    np.testing.assert_allclose(eng.integrate_filter(nw, z["vwave"], z["y_ngeom"], *f), z["ngintf"], rtol=1e-12)
+    yo, go = eng.integrate_filter(nw, z["vwave"], z["y_ngeom"], *f, dydx=z["dydx_ngeom"])
+    np.testing.assert_allclose(yo, z["ngintfg_y"], rtol=1e-12)
+    np.testing.assert_allclose(go, z["ngintfg_g"], rtol=0, atol=1e-12 * np.abs(z["ngintfg_g"]).max())
+
+
 def test_batch_layer_dedup_is_bit_identical(eng):
     """A numerical-Jacobian batch (every state differs from the first in two layers): layers identical to the first
     model's share its opacity rows -- same spectra and TAUGAS to the last bit, far fewer rows computed."""
