@@ -488,7 +488,7 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
             else { acc += del_g_host[g]; p.g_ord[g + 1] = acc; }
         }
         p.g_ord[G] = 1.0;
-        p.g_ord[G + 1] = __builtin_inf();
+        p.g_ord[G + 1] = __builtin_nan("");        // never crossed: merge_walk compares with an ordered >=
     }
     const size_t lds = (size_t)(2 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) + kMaxG * sizeof(float) +
                        (sorted ? 0 : (size_t)2 * G * kWave);
@@ -558,7 +558,7 @@ static int check_unsorted(ansfm_ctx *ctx)
     int flag = 0, rc = read_unsorted(ctx, &flag);
     if (rc) return rc;
     if (flag)
-        FAIL(ANSFM_ERR_UNSORTED, "k-distribution not non-decreasing in g: the gradient merge has no generic (unsorted) path");
+        FAIL(ANSFM_ERR_UNSORTED, "k-distribution not non-decreasing in g although the table was flagged monotone at upload");
     return ANSFM_OK;
 }
 
@@ -959,13 +959,16 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
             else { acc += del_g_host[g]; p.g_ord[g + 1] = acc; }
         }
         p.g_ord[G] = 1.0;
-        p.g_ord[G + 1] = __builtin_inf();
+        p.g_ord[G + 1] = __builtin_nan("");        // never crossed: merge_walk compares with an ordered >=
     }
     pg.dkin = dkin;
     pg.dk = dk;
     const int NP1 = S + 1;
     if (NP1 > 21) FAIL(ANSFM_ERR_UNSUPPORTED, "gradient path supports at most 20 spectroscopic gases");
-    const size_t lds = (size_t)(2 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) + kMaxG * sizeof(float);
+    // fast path: every k(g) non-decreasing (tables: checked at upload; array-level seam: in the kernel, rerun otherwise)
+    const bool sorted = !ctx->force_generic && (from_k || ctx->monotone);
+    const size_t lds = (size_t)(2 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) + kMaxG * sizeof(float) +
+                       (sorted ? 0 : (size_t)2 * G * kWave);
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
@@ -983,10 +986,13 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     HIPCHK(hipMemsetAsync(p.tile_counter, 0, 8 * sizeof(unsigned int), ctx->stream));
 #define LAUNCH_OVG(D, FK)                                                                                           \
     do {                                                                                                            \
-        if (ctx->delg_f32)                                                                                          \
-            hipLaunchKernelGGL((k_ck_overlapg<D, FK, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);  \
-        else                                                                                                        \
-            hipLaunchKernelGGL((k_ck_overlapg<D, FK, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg); \
+        if (ctx->delg_f32) {                                                                                        \
+            if (sorted) hipLaunchKernelGGL((k_ck_overlapg<D, FK, true, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);   \
+            else hipLaunchKernelGGL((k_ck_overlapg<D, FK, true, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);         \
+        } else {                                                                                                    \
+            if (sorted) hipLaunchKernelGGL((k_ck_overlapg<D, FK, false, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);  \
+            else hipLaunchKernelGGL((k_ck_overlapg<D, FK, false, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);        \
+        }                                                                                                           \
     } while (0)
 #define LAUNCH_OVG_D(FK)                                              \
     switch (merge_list_len(G)) {                                      \
@@ -1018,8 +1024,6 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
         !SCALE || !EMTEMP || !TSURF || !SPECOUT || !dSPECOUT || !dTSURF || !igas_map_host || NPAR <= 0 ||
         NPAR > kMaxPar || NVMR < 0 || NVMR >= NPAR || (ISPACE != 0 && ISPACE != 1))
         FAIL(ANSFM_ERR_INVALID, "cirsradg: bad argument (NPAR <= 64)");
-    if (!ctx->monotone)
-        FAIL(ANSFM_ERR_UNSORTED, "k-table is not non-negative and non-decreasing in g: generic merge path not built");
     HIPCHK(hipSetDevice(ctx->device));
     const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, S = ctx->S, NP1 = S + 1;
     HIPCHK(ctx->li.reserve((size_t)n_models * L * sizeof(LayerInterp)));
@@ -1184,9 +1188,17 @@ int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *d
     HIPCHK(hipGetLastError());
     HIPCHK(ctx->misc.reserve((size_t)L * G * Wpad * sizeof(double)));
     HIPCHK(ctx->dkbuf.reserve((size_t)L * NP1 * G * Wpad * sizeof(double)));
-    rc = launch_overlapg(ctx, true, ctx->tmp_in.as<double>(), ctx->tmp_in2.as<double>(), W, Wpad, G, S, L, 1, nullptr,
-                         (const double *)dam, (const double *)ddg, del_g, ctx->misc.as<double>(), ctx->dkbuf.as<double>());
-    if (rc) return rc;
+    for (int pass = 0; pass < 2; ++pass) {
+        ctx->force_generic = pass;       // pass 1 only if the fast merge met an unsorted k-distribution
+        HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+        rc = launch_overlapg(ctx, true, ctx->tmp_in.as<double>(), ctx->tmp_in2.as<double>(), W, Wpad, G, S, L, 1, nullptr,
+                             (const double *)dam, (const double *)ddg, del_g, ctx->misc.as<double>(), ctx->dkbuf.as<double>());
+        ctx->force_generic = 0;
+        if (rc) return rc;
+        int flag = 0;
+        if ((rc = read_unsorted(ctx, &flag))) return rc;
+        if (!flag) break;
+    }
     const size_t nout = (size_t)W * G * L, ndk = nout * NP1;
     HIPCHK(ctx->tmp_out.reserve(nout * sizeof(double)));
     HIPCHK(ctx->tmp_out2.reserve(ndk * sizeof(double)));

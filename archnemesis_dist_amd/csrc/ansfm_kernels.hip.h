@@ -233,7 +233,7 @@ struct OverlapParams {
     unsigned int *tile_counter;  // [8] dynamic tile queues, one per XCD (zeroed before every launch)
     int W, Wpad, G, NT, S, L, n_models;
     int delg_f32;             // DELG is a float32 array: del_g[i]*del_g[j] is a float32 product
-    double g_ord[kMaxG + 2];  // [0, cumsum(del_g)] (float32 cumsum when delg_f32), g_ord[G]=1, +inf
+    double g_ord[kMaxG + 2];  // [0, cumsum(del_g)] (float32 cumsum when delg_f32), g_ord[G]=1, NaN
 };
 
 // Table reads of one gas for one (64-wavenumber, layer) tile.  The loads of kLoadBatch g-ordinates (4 corner
@@ -396,7 +396,9 @@ __device__ __forceinline__ bool merge_walk(const MergeElem &e, WalkState &ws, do
     const double gdn = ws.gd + w;
     const double cw = cv * w;
     double kn = ws.kacc + cw, sn = ws.sum1 + w;
-    const bool cross = !(gdn < ws.gnext);
+    // ordered >= : GORD[G+1] is NaN, so nothing crosses after the last bin whatever gdn is (garbage weights of a call
+    // that is going to be rerun on the generic path, NaN / inf input) -- ig, and with it every record index, stays <= G
+    const bool cross = (gdn >= ws.gnext);
     if (cross) {                                // this element straddles the bin boundary
         double *rp = rec + (size_t)ws.ig * 6 * kWave + lane;
         rp[0] = ws.kacc; rp[kWave] = ws.sum1; rp[2 * kWave] = cw; rp[3 * kWave] = w;
@@ -405,7 +407,7 @@ __device__ __forceinline__ bool merge_walk(const MergeElem &e, WalkState &ws, do
             rp[5 * kWave] = __longlong_as_double((long long)(e.ci | ((e.np - 1) << 5)));
         kn = 0.0; sn = 0.0;
         ws.ig += 1;
-        ws.gnext = GORD[ws.ig + 1];             // GORD[G+1] = +inf: nothing crosses after the last bin
+        ws.gnext = GORD[ws.ig + 1];             // GORD[G+1] = NaN: nothing crosses after the last bin
     }
     ws.kacc = kn; ws.sum1 = sn;
     ws.gd = gdn;
@@ -560,6 +562,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         if constexpr (!SORTED) sort_column(A, PA, G, lane);
         for (int s = 1; s < p.S; ++s) {
             load_gas<FROM_K>(p, q, m, l, s, nu, B, lane, unsorted);
+            if constexpr (SORTED)                       // the call is rerun on the generic path: no point in merging
+                if (__builtin_amdgcn_ballot_w64(unsorted) != 0) break;
             const double blast = B[(G - 1) * kWave + lane];
             if constexpr (!SORTED) sort_column(B, PB, G, lane);
             if constexpr (SORTED) alast = A[(G - 1) * kWave + lane];
@@ -747,15 +751,23 @@ __device__ __forceinline__ void stage_slice(double *dst_lds, const double *__res
     }
 }
 
+// generic path: LDS position g holds the value of the ORIGINAL g-ordinate P[g] (the column was sorted per lane)
+__device__ __forceinline__ void stage_slice_perm(double *dst_lds, const double *__restrict__ src, const unsigned char *P,
+                                                 int G, int lane)
+{
+    for (int g = 0; g < G; ++g) dst_lds[g * kWave + lane] = src[(size_t)P[g * kWave + lane] * kWave + lane];
+}
+
 // Replay of the recorded order for one gathered vector: SL[row] (slots of the earlier gases, row part of the
 // temperature slot) or, COL, SL[col] (the new gas's slot, column part of the temperature slot).
 // Store-free and branch-free: the running sum is written every step to the LDS row of
 // the lane's current bin, so each row ends up holding the sum before the element that closed the bin; global
 // stores inside this loop would sit in front of the code-word loads in the (in-order) vmcnt queue.
 // OUTL has G+1 rows (row G collects what follows the last bin).  Returns the sum after the last boundary.
-template <bool COL, bool W32>
+template <bool COL, bool W32, bool SORTED = true>
 __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigned long long *__restrict__ perm,
-                                              const double *SL, double *OUTL, const double *DG)
+                                              const double *SL, double *OUTL, const double *DG,
+                                              const unsigned char *PA = nullptr, const unsigned char *PB = nullptr)
 {
     double acc = 0.0;
     int bo = lane;                                  // b * 64 + lane
@@ -766,7 +778,8 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
         for (int k = 0; k < 4; ++k) {
             const unsigned code = (unsigned)(word >> (16 * k)) & 0xFFFFu;
             const int row = code & 31, col = (code >> 5) & 31;
-            wr[k] = pair_weight<W32>(DG, row, col);
+            if constexpr (SORTED) wr[k] = pair_weight<W32>(DG, row, col);
+            else wr[k] = pair_weight<W32>(DG, PA[row * kWave + lane], PB[col * kWave + lane]);
             g[k] = SL[(COL ? col : row) * kWave + lane];
         }
 #pragma unroll
@@ -848,7 +861,11 @@ __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const doub
     }
 }
 
-template <int NR, bool FROM_K, bool W32>
+// SORTED = false: generic path (k not non-decreasing in g), as in k_ck_overlap: A and B are sorted per lane, PA / PB give
+// the original g-ordinate of each sorted position.  The gradient rows in the global scratch stay in ORIGINAL order while
+// a spectrum is unmerged (rows and columns are staged through PA / PB for the replay) and are in bin order -- the
+// identity -- after a merge.
+template <int NR, bool FROM_K, bool W32, bool SORTED = true>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_ck_overlapg(OverlapGParams pg)
 {
     const OverlapParams &p = pg.o;
@@ -860,6 +877,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     double *B = A + G * kWave;                   // G+1 rows
     double *DG = B + (G + 1) * kWave;
     double *GORD = DG + kMaxG;
+    unsigned char *PA = reinterpret_cast<unsigned char *>(GORD + kMaxG + 2) + kMaxG * sizeof(float);   // SORTED = false only
+    unsigned char *PB = PA + G * kWave;
     if (lane < G) {
         DG[lane] = p.del_g[lane];
         const_cast<float *>(delg_f32_table(DG))[lane] = (float)p.del_g[lane];
@@ -892,6 +911,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         int cur = 0;
         // gas 0: a = k0*amount0 ; D[0] = k0 (d/d amount0), D[1] = dkdT0*amount0 (d/dT), rest 0
         load_gas_g<FROM_K>(pg, q, m, l, 0, nu, A, Dbuf[0], Dbuf[0] + GW, lane, unsorted);
+        double alast = A[(G - 1) * kWave + lane];       // last g-ordinate in the ORIGINAL order
+        if constexpr (!SORTED) sort_column(A, PA, G, lane);
         for (int pp = 2; pp < NP1; ++pp)
             for (int g = 0; g < G; ++g) Dbuf[0][(size_t)pp * GW + g * kWave + lane] = 0.0;
 
@@ -899,9 +920,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
             const int igas = s - 1;
             const int n = igas + 3;  // rankg's `n`
             load_gas_g<FROM_K>(pg, q, m, l, s, nu, B, KRB, DTB, lane, unsorted);
+            if constexpr (SORTED)                       // the call is rerun on the generic path: no point in merging
+                if (__builtin_amdgcn_ballot_w64(unsorted) != 0) break;
             double *Dold = Dbuf[cur], *Dnew = Dbuf[cur ^ 1];
-            const double alast = A[(G - 1) * kWave + lane];
             const double blast = B[(G - 1) * kWave + lane];
+            if constexpr (!SORTED) sort_column(B, PB, G, lane);
+            if constexpr (SORTED) alast = A[(G - 1) * kWave + lane];
             bool takeB, keepA;
             if (s == 1) { takeB = (alast <= 0.0); keepA = !takeB && (blast <= 0.0); }
             else { keepA = (blast <= 0.0); takeB = !keepA && (alast <= 0.0); }
@@ -922,31 +946,36 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                         }
                         Dnew[o] = v;
                     }
-                if (takeB)
+                if (takeB) {
                     for (int g = 0; g < G; ++g) A[g * kWave + lane] = B[g * kWave + lane];
+                    if constexpr (!SORTED) {
+                        for (int g = 0; g < G; ++g) PA[g * kWave + lane] = PB[g * kWave + lane];
+                        alast = blast;
+                    }
+                }
             } else {
                 // ---- the forward merge, recording the order -------------------------------------------------
                 B[G * kWave + lane] = HUGE_KEY;
                 double R[NR];
                 merge_init<NR>(R, G, lane, A, B[lane], HUGE_KEY);
                 MergeElem e0, e1;
-                merge_fetch<W32>(R[0], lane, A, B, DG, e0);
+                merge_fetch<W32, SORTED>(R[0], lane, A, B, DG, e0, PA, PB);
                 WalkState ws{0.0, 0.0, 0.0, GORD[1], 0};
                 unsigned long long *pw = perm + lane;
                 int it = 0;
                 for (; it + 3 < nloop; it += 4) {
-                    const unsigned long long c0 = merge_step<NR, W32, true>(R, e0, e1, ws, lane, A, B, DG, GORD, rec);
-                    const unsigned long long c1 = merge_step<NR, W32, true>(R, e1, e0, ws, lane, A, B, DG, GORD, rec);
-                    const unsigned long long c2 = merge_step<NR, W32, true>(R, e0, e1, ws, lane, A, B, DG, GORD, rec);
-                    const unsigned long long c3 = merge_step<NR, W32, true>(R, e1, e0, ws, lane, A, B, DG, GORD, rec);
+                    const unsigned long long c0 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    const unsigned long long c1 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    const unsigned long long c2 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    const unsigned long long c3 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
                     *pw = c0 | (c1 << 16) | (c2 << 32) | (c3 << 48);
                     pw += kWave;
                 }
                 if (it < nloop) {   // G*G not a multiple of 4: a partial last word
                     unsigned long long word = 0;
                     for (int k = 0; it < nloop; ++it, ++k) {
-                        const unsigned long long c = (k & 1) ? merge_step<NR, W32, true>(R, e1, e0, ws, lane, A, B, DG, GORD, rec)
-                                                             : merge_step<NR, W32, true>(R, e0, e1, ws, lane, A, B, DG, GORD, rec);
+                        const unsigned long long c = (k & 1) ? merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB)
+                                                             : merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
                         word |= c << (16 * k);
                     }
                     *pw = word;
@@ -990,34 +1019,48 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                     }
                 }
                 // ---- replay, one gathered vector per pass: the vector in A, bin sums in B (G+1 rows) ---------
+                auto stage_row = [&](const double *src) {
+                    if constexpr (SORTED) stage_slice(A, src, G, lane); else stage_slice_perm(A, src, PA, G, lane);
+                };
+                auto stage_col = [&](const double *src) {
+                    if constexpr (SORTED) stage_slice(A, src, G, lane); else stage_slice_perm(A, src, PB, G, lane);
+                };
                 {   // temperature slot: D_old[igas+1][row] + dkdT_new[col]*amount, as a row pass plus a column pass
                     double *DT = Dnew + (size_t)(igas + 2) * GW;
-                    stage_slice(A, Dold + (size_t)(igas + 1) * GW, G, lane);
-                    double tail = grad_replay<false, W32>(nloop, lane, perm, A, B, DG);
+                    stage_row(Dold + (size_t)(igas + 1) * GW);
+                    double tail = grad_replay<false, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
                     grad_resolve<false, false>(G, lane, ig, rec, A, B, tail, DT);
-                    stage_slice(A, DTB, G, lane);
-                    tail = grad_replay<true, W32>(nloop, lane, perm, A, B, DG);
+                    stage_col(DTB);
+                    tail = grad_replay<true, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
                     grad_resolve<true, true>(G, lane, ig, rec, A, B, tail, DT);
                 }
                 {   // the new gas's slot: k_new[col]
-                    stage_slice(A, KRB, G, lane);
-                    const double tail = grad_replay<true, W32>(nloop, lane, perm, A, B, DG);
+                    stage_col(KRB);
+                    const double tail = grad_replay<true, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
                     grad_resolve<true, false>(G, lane, ig, rec, A, B, tail, Dnew + (size_t)(igas + 1) * GW);
                 }
                 for (int pp = 0; pp <= igas; ++pp) {   // earlier gases: D_old[pp][row]
-                    stage_slice(A, Dold + (size_t)pp * GW, G, lane);
-                    const double tail = grad_replay<false, W32>(nloop, lane, perm, A, B, DG);
+                    stage_row(Dold + (size_t)pp * GW);
+                    const double tail = grad_replay<false, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
                     grad_resolve<false, false>(G, lane, ig, rec, A, B, tail, Dnew + (size_t)pp * GW);
                 }
                 for (int pp = n; pp < NP1; ++pp)
                     for (int g = 0; g < G; ++g) Dnew[(size_t)pp * GW + g * kWave + lane] = 0.0;
                 stage_slice(A, ASAVE, G, lane);
+                if constexpr (!SORTED) {   // the merged spectrum is ascending with the plain del_g weights
+                    for (int g = 0; g < G; ++g) PA[g * kWave + lane] = (unsigned char)g;
+                    alast = A[(G - 1) * kWave + lane];
+                }
             }
             cur ^= 1;
         }
-        if (unsorted) atomicOr(p.err_flag, 1);
         double *out = p.tau + (((size_t)m * p.L + l) * G) * p.Wpad + nu;
-        for (int g = 0; g < G; ++g) out[(size_t)g * p.Wpad] = A[g * kWave + lane];
+        if constexpr (SORTED) {
+            if (unsorted) atomicOr(p.err_flag, 1);
+            for (int g = 0; g < G; ++g) out[(size_t)g * p.Wpad] = A[g * kWave + lane];
+        } else {
+            for (int g = 0; g < G; ++g) out[(size_t)PA[g * kWave + lane] * p.Wpad] = A[g * kWave + lane];
+        }
         double *dout = pg.dk + (((size_t)m * p.L + l) * NP1) * G * p.Wpad + nu;
         const double *Dc = Dbuf[cur];
         for (int pp = 0; pp < NP1; ++pp)

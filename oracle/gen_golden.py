@@ -131,8 +131,10 @@ def case_ko_unsorted(ans, name, seed, W, G, L, S):
     k[:, -1, 2, 0] = 0.0          # first gas "empty" in layer 2: the second gas is taken as is (unsorted output)
     k[:, -1, 3, 1:] = 0.0         # only gas 0 left in layer 3: output = its unsorted k * amount
     tau = fm.k_overlap(del_g, k, amount)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), DELG=del_g, k=k, amount=amount, tau=tau)
-    print(name, tau.shape)
+    dkdT = k * rng.uniform(-0.02, 0.02, k.shape)            # drawn after everything above: tau is unchanged
+    taug, dk = fm.k_overlapg(del_g, k, dkdT, amount)        # the same with gradients (k_overlapg :5842, rankg :5959)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), DELG=del_g, k=k, amount=amount, tau=tau, dkdT=dkdT, taug=taug, dk=dk)
+    print(name, tau.shape, dk.shape, np.abs(taug - tau).max())
 
 
 def case_thermal(ans, name, seed, W, G, Li, NPAR, NVMR):

@@ -57,6 +57,35 @@ def test_k_overlap_unsorted_golden(eng, golden_dir):
     np.testing.assert_allclose(tau, z["tau"], rtol=1e-12, atol=0)
 
 
+def test_k_overlapg_unsorted_golden(eng, golden_dir):
+    """The same unsorted k-distributions with gradients: k_overlapg / rankg of the reference (golden).  The gradient merge's
+    generic path sorts each gas per lane and stages the gradient rows through the same permutations."""
+    z = _load(golden_dir, "ko_unsorted_g8_s4")
+    taug, dk = eng.k_overlapg(z["DELG"], z["k"], z["dkdT"], z["amount"])
+    np.testing.assert_allclose(taug, z["taug"], rtol=1e-12, atol=0)
+    scale = np.abs(z["dk"]).max(axis=1, keepdims=True) + 1e-300
+    assert np.max(np.abs(dk - z["dk"]) / scale) < 1e-10
+
+
+@pytest.mark.parametrize("G,S,f32", [(20, 8, True), (10, 3, False), (7, 1, False), (16, 5, False)])
+def test_k_overlapg_unsorted_vs_oracle(eng, oracle, G, S, f32):
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(G * 100 + S + 1)
+    W, L = 130, 6
+    _, delg = syn.gauss_legendre_01(G, f32)
+    k = 10.0 ** rng.uniform(-25, -20, (W, G, L, S))             # no exact ties: rankg's gradient rows follow argsort's order
+    k[:, -1, 2, S // 2] = 0.0                                   # a gas skipped in one layer (last ordinate only)
+    if S > 1:
+        k[:, -1, 4, 0] = 0.0                                    # first gas empty: the second is taken as is
+    dkdT = k * rng.uniform(-0.02, 0.02, k.shape)
+    amount = 10.0 ** rng.uniform(19, 22, (S, L))
+    tau, dk = eng.k_overlapg(delg, k, dkdT, amount)
+    rt, rdk = oracle.k_overlapg(delg, k, dkdT, amount)
+    np.testing.assert_allclose(tau, rt, rtol=1e-11, atol=0)
+    scale = np.abs(rdk).max(axis=1, keepdims=True) + 1e-300
+    assert np.max(np.abs(dk - rdk) / scale) < 1e-10
+
+
 @pytest.mark.parametrize("G,S,f32", [(20, 8, True), (10, 3, False), (7, 1, False)])
 def test_k_overlap_unsorted_vs_oracle(eng, oracle, G, S, f32):
     from archnemesis_dist_amd import synthetic as syn
@@ -89,9 +118,15 @@ def test_cirsrad_unsorted_table_vs_oracle(eng, oracle):
     ref = oracle.cirsrad_ck_thermal(0, K, PRESS, TEMP, WAVE, delg, atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0],
                                     None, NLAYIN, LAYINC, SCALE, EMTEMP, -1.0)
     np.testing.assert_allclose(np.squeeze(spec), np.squeeze(ref), rtol=1e-10)
-    with pytest.raises(ValueError):      # the gradient merge has no generic path
-        eng.cirsradg_ck_thermal(0, atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0], None, None, S, S + 2,
-                                np.arange(S, dtype=np.int32), NLAYIN, LAYINC, SCALE, EMTEMP, -1.0)
+    # the analytic-gradient forward model on the same table: generic path of the gradient merge
+    NPAR = S + 2
+    args = (0, atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0], None, None, S, NPAR, np.arange(S, dtype=np.int32),
+            NLAYIN, LAYINC, SCALE, EMTEMP, -1.0)
+    sg, dsg, dts = eng.cirsradg_ck_thermal(*args)
+    rs, rds, rdt = oracle.cirsradg_ck_thermal(0, K, PRESS, TEMP, WAVE, delg, *args[1:])
+    np.testing.assert_allclose(np.squeeze(sg), np.squeeze(ref), rtol=1e-10)
+    sc = np.abs(rds).max(axis=(0, 2, 3), keepdims=True) + 1e-300
+    assert np.max(np.abs(np.asarray(dsg).reshape(rds.shape) - rds) / sc) < 1e-9
 
 
 def test_thermal_emission_golden(eng, golden_dir):
