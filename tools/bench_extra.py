@@ -34,7 +34,45 @@ def main():
         bench_layer(eng, out)
     if only in (None, "maps"):
         bench_maps(eng, out, rng)
+    if only in (None, "next"):
+        bench_next(eng, out, rng)
     print(json.dumps(out, indent=1))
+
+
+def bench_next(eng, out, rng):
+    """the "next" rows: ILS convolution of an LBL spectrum with gradients, continuum opacities at C2, the
+    k-table generator's binning -- host arrays in / out, beside the NumPy oracle where it finishes in seconds"""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    # ILS: 1e6-point spectrum + 100 gradient columns, 1000 convolution points, Gaussian FWHM 0.4 cm-1 (~800 points a window)
+    nw, nx, nc = 1000000, 100, 1000
+    vw = 2000.0 + 1e-3 * np.arange(nw)
+    y = rng.uniform(1, 2, nw); dy = rng.normal(size=(nw, nx))
+    vc = np.linspace(2001.0, 2999.0, nc)
+    t = timeit(lambda: eng.lblconvg(nw, vw, y, dy, nc, vc, 2, 0.4), 2)
+    sub = slice(0, 20)
+    t0 = time.perf_counter(); orc.lblconv(nw, vw, y, 20, vc[sub], 2, 0.4, dydx=dy); to = (time.perf_counter() - t0) * nc / 20
+    out["lblconvg_1e6x100grad_1000conv"] = {"gpu_wall_s_host_arrays": t, "numpy_oracle_s_extrapolated_from_20_points": to}
+    # continuum at C2: CIA table 2 pairs, Rayleigh (Jovian air), 2 aerosol populations
+    W, L = 10000, 100
+    wn = 200.0 + 0.1 * np.arange(W)
+    TOTAM = 10.0 ** rng.uniform(24, 28, L)
+    ID = np.array([39, 40, 6, 11]); ISO = np.zeros(4, int); VMR = np.tile([0.86, 0.13, 2e-3, 1e-4], (L, 1))
+    tr = timeit(lambda: eng.calc_tau_rayleigh(4, 0, wn, TOTAM, ID, ISO, VMR))
+    SW = np.linspace(150.0, 1300.0, 40); KE = 10.0 ** rng.uniform(-10, -8, (40, 2)); KS = KE * 0.6
+    CONT = 10.0 ** rng.uniform(3, 8, (L, 2))
+    td = timeit(lambda: eng.calc_tau_dust(wn, SW, KE, KS, CONT))
+    t0 = time.perf_counter(); orc.calc_tau_dust(wn, SW, KE, KS, CONT); tdo = time.perf_counter() - t0
+    out["continuum_C2"] = {"rayleigh_ls_gpu_s": tr, "dust_2pop_gpu_s": td, "dust_scipy_oracle_s": tdo}
+    # k-table generator: 200 bins of ~2.5e4 line-by-line points (overlapping ILS windows), 20 g-ordinates
+    n = 2000000
+    w = np.linspace(1000.0, 1100.0, n)
+    k = 10.0 ** (-24 + 3 * np.sin(w * 11.0) ** 2 + rng.normal(0, 0.3, n))
+    cen = np.linspace(1001.0, 1099.0, 200); half = np.full(200, 0.625)
+    x, _ = np.polynomial.legendre.leggauss(20); g = 0.5 * (x + 1)
+    tk = timeit(lambda: eng.kdist_bins(w, k, cen - half, cen + half, g), 2)
+    t0 = time.perf_counter(); orc.kdist_bins(w, k, cen - half, cen + half, g); tko = time.perf_counter() - t0
+    out["kdist_200bins_2.5e4pts"] = {"gpu_wall_s_host_arrays": tk, "numpy_oracle_s": tko}
 
 
 def bench_maps(eng, out, rng):
