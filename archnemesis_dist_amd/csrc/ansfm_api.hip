@@ -100,7 +100,7 @@ static inline unsigned nblk(size_t n, int b) { return (unsigned)((n + b - 1) / b
 // length of the register-resident row-head list of the merge kernels: smallest instantiated size >= G
 static int merge_list_len(int G)
 {
-    static const int sizes[] = {4, 8, 10, 16, 20, 24, 32};
+    static const int sizes[] = {8, 10, 16, 20, 32};
     for (int v : sizes) if (v >= G) return v;
     return 32;
 }
@@ -515,12 +515,10 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     } while (0)
 #define LAUNCH_OVN(FK)                                                \
     switch (merge_list_len(G)) {                                      \
-        case 4: LAUNCH_OV(4, FK); break;                              \
         case 8: LAUNCH_OV(8, FK); break;                              \
         case 10: LAUNCH_OV(10, FK); break;                            \
         case 16: LAUNCH_OV(16, FK); break;                            \
         case 20: LAUNCH_OV(20, FK); break;                            \
-        case 24: LAUNCH_OV(24, FK); break;                            \
         default: LAUNCH_OV(32, FK); break;                            \
     }
     if (from_k) { LAUNCH_OVN(true); } else { LAUNCH_OVN(false); }
@@ -996,12 +994,10 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     } while (0)
 #define LAUNCH_OVG_D(FK)                                              \
     switch (merge_list_len(G)) {                                      \
-        case 4: LAUNCH_OVG(4, FK); break;                             \
         case 8: LAUNCH_OVG(8, FK); break;                             \
         case 10: LAUNCH_OVG(10, FK); break;                           \
         case 16: LAUNCH_OVG(16, FK); break;                           \
         case 20: LAUNCH_OVG(20, FK); break;                           \
-        case 24: LAUNCH_OVG(24, FK); break;                           \
         default: LAUNCH_OVG(32, FK); break;                           \
     }
     if (from_k) { LAUNCH_OVG_D(true); } else { LAUNCH_OVG_D(false); }
