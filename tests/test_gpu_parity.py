@@ -100,6 +100,33 @@ def test_k_overlap_unsorted_vs_oracle(eng, oracle, G, S, f32):
     np.testing.assert_allclose(tau, ref, rtol=1e-11, atol=0)
 
 
+def test_nan_and_inf_input_stays_in_its_cells(eng, oracle):
+    """NaN / inf absorption coefficients poison only the (wavenumber, layer) cells they are in: the merge kernels never
+    index by data beyond what the bin sentinel bounds (a NaN key can displace list entries), so the other cells equal
+    the clean run bit for bit."""
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(99)
+    W, G, L, S = 70, 10, 5, 4
+    _, delg = syn.gauss_legendre_01(G, True)
+    k = np.sort(10.0 ** rng.uniform(-25, -20, (W, G, L, S)), axis=1)
+    amount = 10.0 ** rng.uniform(19, 22, (S, L))
+    dkdT = k * 0.01
+    clean = eng.k_overlap(delg, k, amount)
+    cleang, cleandk = eng.k_overlapg(delg, k, dkdT, amount)
+    bad = k.copy()
+    bad[3, 4, 1, 2] = np.nan; bad[10, G - 1, 2, 0] = np.inf; bad[20, 0, 3, 1] = -np.inf; bad[33, :, 4, 3] = np.nan
+    cells = [(3, 1), (10, 2), (20, 3), (33, 4)]
+    mask = np.ones((W, L), bool)
+    for w, l in cells:
+        mask[w, l] = False
+    with np.errstate(all="ignore"):
+        tau = eng.k_overlap(delg, bad, amount)
+        taug, dk = eng.k_overlapg(delg, bad, dkdT, amount)
+    assert np.array_equal(tau.transpose(0, 2, 1)[mask], clean.transpose(0, 2, 1)[mask])
+    assert np.array_equal(taug.transpose(0, 2, 1)[mask], cleang.transpose(0, 2, 1)[mask])
+    assert np.array_equal(dk.transpose(0, 2, 1, 3)[mask], cleandk.transpose(0, 2, 1, 3)[mask])
+
+
 def test_cirsrad_unsorted_table_vs_oracle(eng, oracle):
     """A k-table that is not monotone in g goes down the generic path for the whole forward model."""
     from archnemesis_dist_amd import synthetic as syn
