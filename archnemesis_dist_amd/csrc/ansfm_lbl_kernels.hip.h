@@ -96,13 +96,13 @@ struct LblParams {
     const double *bparams;  // [3M][N]
     const double *mmf;      // [M]
     const double *t_calc, *p_calc, *q_ratio;  // [L]
-    double *store;          // [L][5][N]: strength, alpha_d, gamma_l, shift, line_approx_const
+    double *store;          // [L][5][N]: strength, alpha_d, gamma_l, shift, wing numerator (iso * strength * line_approx_const * cmax^2)
     double *out;            // [L][nw]  (added to)
     int nw, N, M, L, lineshape_id;
     double t_ref, p_ref, iso_abundance, iso_mass, s_floor, wn_calc_window, wn_approx_window, max_shift;
 };
 
-// per (layer, line): store[0..3] exactly as the reference fills them (:306-341) + the wing constant (:261)
+// per (layer, line): store[0..3] exactly as the reference fills them (:306-341) + the wing term's numerator (:261, :270)
 __global__ void k_lbl_line_params(LblParams p)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,7 +128,9 @@ __global__ void k_lbl_line_params(LblParams p)
     st[p.N + i] = alpha_d;
     st[2 * (size_t)p.N + i] = g;
     st[3 * (size_t)p.N + i] = sh;
-    st[4 * (size_t)p.N + i] = lbl_lineshape(p.lineshape_id, p.wn_calc_window, alpha_d, g);
+    // row 4: the whole numerator of the wing term (:270), same association as the reference's expression
+    st[4 * (size_t)p.N + i] = p.iso_abundance * strength * lbl_lineshape(p.lineshape_id, p.wn_calc_window, alpha_d, g) *
+                              (p.wn_calc_window * p.wn_calc_window);
 }
 
 __global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
         if (cmin <= wn_delta && wn_delta < cmax)
             acc += p.iso_abundance * strength * lbl_lineshape(p.lineshape_id, wn_delta, st[p.N + i], st[2 * (size_t)p.N + i]);
         else
-            acc += p.iso_abundance * strength * st[4 * (size_t)p.N + i] * (cmax * cmax) / (wn_delta * wn_delta);
+            acc += fast_div(st[4 * (size_t)p.N + i], wn_delta * wn_delta);   // <= 1 ulp
     }
     if (j < p.nw) p.out[(size_t)l * p.nw + j] = acc;
 }
