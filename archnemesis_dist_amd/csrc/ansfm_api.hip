@@ -1941,7 +1941,7 @@ int ansfm_add_line_set_monochromatic_absorption(
     if ((rc = h2d(ctx, ctx->hb[5], q_ratio, (size_t)L * D, &d_q))) return rc;
     if ((rc = h2d(ctx, ctx->hb[6], out, (size_t)L * nw * D, &d_out))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));   // h is a local buffer
-    HIPCHK(ctx->misc.reserve((size_t)L * 5 * N * D));
+    HIPCHK(ctx->misc.reserve((size_t)L * kLblRows * N * D));
     LblParams p;
     memset(&p, 0, sizeof p);
     const double *dl = (const double *)d_lines;
@@ -1961,14 +1961,14 @@ int ansfm_add_line_set_monochromatic_absorption(
     HIPCHK(hipMemcpyAsync(out, p.out, (size_t)L * nw * D, hipMemcpyDeviceToHost, ctx->stream));
     std::vector<double> hst;
     if (store) {
-        hst.resize((size_t)L * 5 * N);
+        hst.resize((size_t)L * kLblRows * N);
         HIPCHK(hipMemcpyAsync(hst.data(), p.store, hst.size() * D, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (store)   // store[L][4][N] in the caller's line order
         for (int l = 0; l < L; ++l)
             for (int r = 0; r < 4; ++r)
-                for (int i = 0; i < N; ++i) store[((size_t)l * 4 + r) * N + ord[i]] = hst[((size_t)l * 5 + r) * N + i];
+                for (int i = 0; i < N; ++i) store[((size_t)l * 4 + r) * N + ord[i]] = hst[((size_t)l * kLblRows + r) * N + i];
     return ANSFM_OK;
 }
 

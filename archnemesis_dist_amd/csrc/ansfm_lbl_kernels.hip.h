@@ -21,6 +21,18 @@ namespace ansfm {
 __device__ const double kLblE0[28] = {5.242885663363464e-22, 4.4777324417183015e-19, 2.319522830243569e-16, 7.287724095819692e-14, 1.3887943864964021e-11, 1.6052280551856116e-09, 1.1253517471925912e-07, 4.785117392129009e-06, 0.00012340980408667956, 0.0019304541362277093, 0.01831563888873418, 0.10539922456186433, 0.36787944117144233, 0.7788007830714049, 1.0, 0.7788007830714049, 0.36787944117144233, 0.10539922456186433, 0.01831563888873418, 0.0019304541362277093, 0.00012340980408667956, 4.785117392129009e-06, 1.1253517471925912e-07, 1.6052280551856116e-09, 1.3887943864964021e-11, 7.287724095819692e-14, 2.319522830243569e-16, 4.4777324417183015e-19};
 __device__ const double kLblE1[28] = {1.6310139226701858e-20, 1.0848552640429378e-17, 4.37661850287085e-15, 1.0709232382508077e-12, 1.5893910094516368e-10, 1.4307241918567688e-08, 7.811489408304491e-07, 2.586810022265412e-05, 0.0005195746821548384, 0.006329715427485747, 0.04677062238395898, 0.2096113871510978, 0.569782824730923, 0.9394130628134758, 0.9394130628134758, 0.569782824730923, 0.2096113871510978, 0.04677062238395898, 0.006329715427485747, 0.0005195746821548384, 2.586810022265412e-05, 7.811489408304491e-07, 1.4307241918567688e-08, 1.5893910094516368e-10, 1.0709232382508077e-12, 4.37661850287085e-15, 1.0848552640429378e-17, 1.6310139226701858e-20};
 
+constexpr int kLblRows = 8;   // rows of the per-(layer, line) store, see LblParams::store
+
+// n / d by v_rcp_f64 + two Newton steps + a residual correction (<= 1 ulp): the profile's divisions need no more
+__device__ __forceinline__ double lbl_div(double n, double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return fma(fma(-d, q, n), r, q);
+}
+
 __device__ __forceinline__ double lbl_rew(double x, double y)
 {
     const double PI = 3.141592653589793;
@@ -33,12 +45,12 @@ __device__ __forceinline__ double lbl_rew(double x, double y)
         const int n = r2 >= 1e6 ? 2 : r2 >= 1e4 ? 3 : r2 >= 1600.0 ? 4 : r2 >= 400.0 ? 6 : r2 >= 144.0 ? 8 : 12;
         double rr = 0.0, ri = 0.0;
         for (int k = n; k > 0; --k) {
-            const double dr = x - rr, di = y - ri, inv = (k * 0.5) / (dr * dr + di * di);
+            const double dr = x - rr, di = y - ri, inv = lbl_div(k * 0.5, dr * dr + di * di);
             rr = dr * inv;
             ri = -(di * inv);
         }
         const double dr = x - rr, di = y - ri;
-        return di / (1.7724538509055159 * (dr * dr + di * di));
+        return lbl_div(di, 1.7724538509055159 * (dr * dr + di * di));
     }
     const double h = 0.5;
     const double fr = x / h - floor(x / h);
@@ -51,7 +63,7 @@ __device__ __forceinline__ double lbl_rew(double x, double y)
         const double t1 = (k - 14) * h + shift, t2 = (k - 13) * h + shift;
         const double e1 = use_mid ? kLblE1[k] : kLblE0[k], e2 = use_mid ? kLblE1[k + 1] : kLblE0[k + 1];
         const double d1 = (x - t1) * (x - t1) + yy, d2 = (x - t2) * (x - t2) + yy;
-        s += (e1 * d2 + e2 * d1) / (d1 * d2);
+        s += lbl_div(e1 * d2 + e2 * d1, d1 * d2);
     }
     s *= y;
     s *= h / PI;
@@ -96,7 +108,9 @@ struct LblParams {
     const double *bparams;  // [3M][N]
     const double *mmf;      // [M]
     const double *t_calc, *p_calc, *q_ratio;  // [L]
-    double *store;          // [L][5][N]: strength, alpha_d, gamma_l, shift, wing numerator (iso * strength * line_approx_const * cmax^2)
+    double *store;          // [L][kLblRows][N]: strength, alpha_d, gamma_l, shift, wing numerator (iso * strength *
+                            // line_approx_const * cmax^2), then the Voigt constants of the line: 1/(sigma sqrt 2), y = gamma/(sigma
+                            // sqrt 2), 1/(sigma sqrt(2 pi))   (row 5 = 0: the line takes the general lineshape function)
     double *out;            // [L][nw]  (added to)
     int nw, N, M, L, lineshape_id;
     double t_ref, p_ref, iso_abundance, iso_mass, s_floor, wn_calc_window, wn_approx_window, max_shift;
@@ -123,7 +137,7 @@ __global__ void k_lbl_line_params(LblParams p)
         g += (pow(t_ratio, p.bparams[(size_t)(3 * j + 1) * p.N + i])) * p.bparams[(size_t)(3 * j) * p.N + i] * p.mmf[j] * p_ratio;
         sh += (p_ratio * p.bparams[(size_t)(3 * j + 2) * p.N + i]) * p.mmf[j];
     }
-    double *st = p.store + (size_t)l * 5 * p.N;
+    double *st = p.store + (size_t)l * kLblRows * p.N;
     st[i] = strength;
     st[p.N + i] = alpha_d;
     st[2 * (size_t)p.N + i] = g;
@@ -131,6 +145,21 @@ __global__ void k_lbl_line_params(LblParams p)
     // row 4: the whole numerator of the wing term (:270), same association as the reference's expression
     st[4 * (size_t)p.N + i] = p.iso_abundance * strength * lbl_lineshape(p.lineshape_id, p.wn_calc_window, alpha_d, g) *
                               (p.wn_calc_window * p.wn_calc_window);
+    // Voigt: scipy's voigt_profile(x, sigma, gamma) = Re w((x + i gamma) / (sigma sqrt 2)) / (sigma sqrt(2 pi)) -- the
+    // three per-line factors once per (layer, line) instead of three divisions per grid point
+    double xs = 0.0, yv = 0.0, nrm = 0.0;
+    if (p.lineshape_id == 0) {
+        const double sigma = alpha_d / sqrt(2.0 * log(2.0));
+        if (sigma > 0.0 && g > 0.0) {
+            const double isq2 = 0.70710678118654752440;
+            xs = isq2 / sigma;
+            yv = g / sigma * isq2;
+            nrm = 1.0 / sigma / sqrt(2.0 * 3.141592653589793);
+        }
+    }
+    st[5 * (size_t)p.N + i] = xs;
+    st[6 * (size_t)p.N + i] = yv;
+    st[7 * (size_t)p.N + i] = nrm;
 }
 
 __global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
@@ -150,7 +179,7 @@ __global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
     b = p.N;
     while (a < b) { int mid = (a + b) >> 1; if (p.nu[mid] <= hi_wn) a = mid + 1; else b = mid; }
     const int ihi = a;
-    const double *st = p.store + (size_t)l * 5 * p.N;
+    const double *st = p.store + (size_t)l * kLblRows * p.N;
     const double cmin = -1 * p.wn_calc_window, cmax = p.wn_calc_window;
     const double amin = -1 * p.wn_approx_window, amax = p.wn_approx_window;
     double acc = (j < p.nw) ? p.out[(size_t)l * p.nw + j] : 0.0;
@@ -159,8 +188,12 @@ __global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
         if (strength < p.s_floor) continue;                                     // :258
         const double wn_delta = wn - (p.nu[i] + st[3 * (size_t)p.N + i]);       // :264
         if (wn_delta >= amax || wn_delta < amin) continue;                      // :266-269
-        if (cmin <= wn_delta && wn_delta < cmax)
-            acc += p.iso_abundance * strength * lbl_lineshape(p.lineshape_id, wn_delta, st[p.N + i], st[2 * (size_t)p.N + i]);
+        if (cmin <= wn_delta && wn_delta < cmax) {
+            const double xs = st[5 * (size_t)p.N + i];
+            const double shape = (xs != 0.0) ? lbl_rew(wn_delta * xs, st[6 * (size_t)p.N + i]) * st[7 * (size_t)p.N + i]
+                                             : lbl_lineshape(p.lineshape_id, wn_delta, st[p.N + i], st[2 * (size_t)p.N + i]);
+            acc += p.iso_abundance * strength * shape;
+        }
         else
             acc += fast_div(st[4 * (size_t)p.N + i], wn_delta * wn_delta);   // <= 1 ulp
     }
