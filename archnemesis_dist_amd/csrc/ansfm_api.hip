@@ -466,6 +466,7 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     // fast path: every k(g) non-decreasing (checked at upload for tables, in the kernel otherwise); generic path:
     // per-lane sort of each gas first (k_ck_overlap<..., SORTED = false>)
     const bool sorted = !ctx->force_generic && (from_k || ctx->monotone);
+    ctx->force_generic = 0;            // one-shot request of the rerun wrappers: never survives an error return
     OverlapParams p;
     memset(&p, 0, sizeof p);
     p.lnK = ctx->lnK.as<double>();
@@ -965,6 +966,7 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     if (NP1 > 21) FAIL(ANSFM_ERR_UNSUPPORTED, "gradient path supports at most 20 spectroscopic gases");
     // fast path: every k(g) non-decreasing (tables: checked at upload; array-level seam: in the kernel, rerun otherwise)
     const bool sorted = !ctx->force_generic && (from_k || ctx->monotone);
+    ctx->force_generic = 0;            // one-shot request of the rerun wrappers: never survives an error return
     const size_t lds = (size_t)(2 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) + kMaxG * sizeof(float) +
                        (sorted ? 0 : (size_t)2 * G * kWave);
     int per_cu = (int)((160 * 1024) / lds);

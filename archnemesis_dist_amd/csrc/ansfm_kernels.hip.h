@@ -738,15 +738,17 @@ __device__ __forceinline__ void load_gas_g(const OverlapGParams &pg, const Layer
     }
 }
 
-// global [G][64] -> LDS [G][64], loads batched (one round trip per kLoadBatch rows)
+// global [G][64] -> LDS [G][64], loads batched: one memory round trip per kStageBatch rows (every replay pass starts
+// with one of these and the wave has at most one sibling to hide it behind)
+constexpr int kStageBatch = 20;
 __device__ __forceinline__ void stage_slice(double *dst_lds, const double *__restrict__ src, int G, int lane)
 {
-    for (int g0 = 0; g0 < G; g0 += kLoadBatch) {
-        double r[kLoadBatch];
+    for (int g0 = 0; g0 < G; g0 += kStageBatch) {
+        double r[kStageBatch];
 #pragma unroll
-        for (int k = 0; k < kLoadBatch; ++k) r[k] = src[((g0 + k < G) ? g0 + k : G - 1) * kWave + lane];
+        for (int k = 0; k < kStageBatch; ++k) r[k] = src[((g0 + k < G) ? g0 + k : G - 1) * kWave + lane];
 #pragma unroll
-        for (int k = 0; k < kLoadBatch; ++k)
+        for (int k = 0; k < kStageBatch; ++k)
             if (g0 + k < G) dst_lds[(g0 + k) * kWave + lane] = r[k];
     }
 }
@@ -831,7 +833,7 @@ __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const doub
                                              double *__restrict__ OUT)
 {
     double carry = 0.0;
-    constexpr int kRB = 5;
+    constexpr int kRB = 10;     // two memory round trips per pass for G = 20
     for (int b0 = 0; b0 < G; b0 += kRB) {
         double rfr[kRB], rri[kRB], rw[kRB], rcd[kRB], rold[kRB];
 #pragma unroll
