@@ -40,3 +40,18 @@ json.dump(out, open("$OUT/pmc_valu_summary.json","w"), indent=1)
 for k,v in out.items(): print(k, v)
 PY
 fi
+# wave-state counters (own pass): bash tools/prof_extra.sh grad <tag> wait
+if [ "$3" = "wait" ]; then
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $OUT/pmc_wait -- python3 tools/bench_extra.py $SEC > $OUT/pmc_wait.log 2>&1 || exit 1
+  python3 - <<PY
+import csv,glob,json
+from collections import defaultdict
+f=glob.glob("$OUT/pmc_wait/**/*counter_collection.csv",recursive=True)[0]
+acc=defaultdict(lambda: defaultdict(list))
+for r in csv.DictReader(open(f)):
+    if "ansfm" in r["Kernel_Name"]: acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out={k: {c: sum(v)/len(v) for c,v in cs.items()} for k,cs in acc.items()}
+json.dump(out, open("$OUT/pmc_wait_summary.json","w"), indent=1)
+for k,v in out.items(): print(k, v)
+PY
+fi
