@@ -612,3 +612,19 @@ def install_gpu_table_reader(device=0):
     cls._ansfm_reference_read_tables = ref
     cls.read_tables = read_tables
     return read_tables
+
+
+def install_all(device=0, oe_linalg=True, ktable_generator=True):
+    """Every replacement this package has for the imported reference, in one call; returns the
+    names installed.  `make_gpu_forward_model` stays explicit: it returns a class."""
+    done = []
+    for f in (install_gpu_gradient_maps, install_gpu_scattering_core, install_gpu_line_kernel, install_gpu_layering,
+              install_gpu_convolution, install_gpu_continuum, install_gpu_table_reader):
+        f(device); done.append(f.__name__)
+    if oe_linalg:
+        from .oe_linalg import install_gpu_oe_linalg
+        install_gpu_oe_linalg(device); done.append("install_gpu_oe_linalg")
+    if ktable_generator:
+        from .ktable_gen import install_gpu_ktable_generator
+        install_gpu_ktable_generator(device); done.append("install_gpu_ktable_generator")
+    return done
