@@ -1093,8 +1093,14 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     {
         dim3 grid((unsigned)(Wpad / kWave), (unsigned)P, (unsigned)n_models);
-        const size_t lds = (size_t)(NP1 + 2) * kGY * kWave * sizeof(double);
-        hipLaunchKernelGGL(k_thermal_rtg, grid, dim3(kWave, kGY), lds, ctx->stream, q);
+        // reduction buffer [NP1+2][GY][64] doubles: the largest GY that leaves room for one block per CU
+        const size_t per_gy = (size_t)(NP1 + 2) * kWave * sizeof(double);
+        if (16 * per_gy <= 128 * 1024)
+            hipLaunchKernelGGL(k_thermal_rtg<16>, grid, dim3(kWave, 16), 16 * per_gy, ctx->stream, q);
+        else if (8 * per_gy <= 128 * 1024)
+            hipLaunchKernelGGL(k_thermal_rtg<8>, grid, dim3(kWave, 8), 8 * per_gy, ctx->stream, q);
+        else
+            hipLaunchKernelGGL(k_thermal_rtg<4>, grid, dim3(kWave, 4), 4 * per_gy, ctx->stream, q);
         HIPCHK(hipGetLastError());
     }
     for (int m = 0; m < n_models; ++m) {

@@ -1312,8 +1312,8 @@ __global__ void k_lbl_tau(const double *__restrict__ lnK, int Wpad, int NTa, int
 // ground / solar terms, unit factor and g-quadrature.   "thermal_rt"
 // Block = 64 wavenumbers x GY g-groups; thread (lane, gy) integrates g = gy, gy+GY, ...
 // ------------------------------------------------------------------------------------------------
-constexpr int kGY = 4;
-constexpr int kGPer = kMaxG / kGY;  // 8
+constexpr int kGY = 8;       // g-groups per block of the forward RT kernel (157 wavenumber tiles at C2: more waves per tile)
+constexpr int kGPer = kMaxG / kGY;  // 4
 
 struct RtParams {
     const double *tau;      // [n][L][G][Wpad], or [unique layers][G][Wpad] addressed through tau_slot
@@ -1501,10 +1501,14 @@ __device__ __forceinline__ void planckg_dev(int ispace, double y, double T, doub
     dBdT = e * ap / (b * b);   // ForwardModel_0.py:6274-6281
 }
 
-__global__ __launch_bounds__(kWave *kGY) void k_thermal_rtg(RtGParams q)
+// GY = g-groups (waves) per wavenumber tile: the kernel streams (S+1) gradient rows per layer and C2 has only 157 tiles,
+// so the launch picks the largest GY whose reduction buffer fits in LDS (16 up to S = 12).
+template <int GY>
+__global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
 {
+    constexpr int kGPerG = kMaxG / GY;
     const RtParams &p = q.r;
-    extern __shared__ double red[];  // [NP1+2][kGY][kWave]
+    extern __shared__ double red[];  // [NP1+2][GY][kWave]
     const int lane = threadIdx.x, gy = threadIdx.y;
     const int nu = blockIdx.x * kWave + lane;
     const int nuc = nu < p.W ? nu : p.W - 1;
@@ -1517,9 +1521,9 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rtg(RtGParams q)
     const size_t GWp = (size_t)G * p.Wpad;
     double *tws = q.trold_ws + (((size_t)m * p.P + ip) * (p.LIMAX + 1)) * GWp + nu;
 
-    double trold[kGPer], spec[kGPer];
+    double trold[kGPerG], spec[kGPerG];
 #pragma unroll
-    for (int k = 0; k < kGPer; ++k) { trold[k] = 1.0; spec[k] = 0.0; }
+    for (int k = 0; k < kGPerG; ++k) { trold[k] = 1.0; spec[k] = 0.0; }
     // ---- pass 1: forward, product form tr = trold*exp(-tau_j) (:6446-6452) -----------------------------
     for (int j = 0; j < nl; ++j) {
         const int lay = p.layinc[(size_t)j * p.P + ip];
@@ -1530,8 +1534,8 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rtg(RtGParams q)
         planckg_dev(p.ispace, y, T, bb, dB);
         const double *trow = p.tau + (((size_t)m * p.L + lay) * G) * p.Wpad + nu;
 #pragma unroll
-        for (int k = 0; k < kGPer; ++k) {
-            const int g = gy + k * kGY;
+        for (int k = 0; k < kGPerG; ++k) {
+            const int g = gy + k * GY;
             if (g < G) {
                 tws[(size_t)j * GWp + (size_t)g * p.Wpad] = trold[k];
                 const double t = (trow[(size_t)g * p.Wpad] + tc) * sc;
@@ -1557,12 +1561,12 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rtg(RtGParams q)
         }
     }
     const double xf = p.xfac ? p.xfac[nuc] : 1.0;
-    double R[kGPer];
+    double R[kGPerG];
     {
         double accs = 0.0, acct = 0.0;
 #pragma unroll
-        for (int k = 0; k < kGPer; ++k) {
-            const int g = gy + k * kGY;
+        for (int k = 0; k < kGPerG; ++k) {
+            const int g = gy + k * GY;
             R[k] = 0.0;
             if (g < G) {
                 double sgl = spec[k];
@@ -1572,22 +1576,22 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rtg(RtGParams q)
                 R[k] = ground ? trold[k] * radground : 0.0;
             }
         }
-        red[(0 * kGY + gy) * kWave + lane] = accs;
-        red[(1 * kGY + gy) * kWave + lane] = acct;
+        red[(0 * GY + gy) * kWave + lane] = accs;
+        red[(1 * GY + gy) * kWave + lane] = acct;
         __syncthreads();
         if (gy == 0 && nu < p.W) {
             double a = 0.0, b = 0.0;
 #pragma unroll
-            for (int k = 0; k < kGY; ++k) { a += red[(0 * kGY + k) * kWave + lane]; b += red[(1 * kGY + k) * kWave + lane]; }
+            for (int k = 0; k < GY; ++k) { a += red[(0 * GY + k) * kWave + lane]; b += red[(1 * GY + k) * kWave + lane]; }
             p.out[((size_t)m * p.W + nu) * p.P + ip] = a;
             q.dtsurf[((size_t)m * p.W + nu) * p.P + ip] = b;
         }
         __syncthreads();
     }
     // ---- pass 2: backward sweep ------------------------------------------------------------------------
-    double trnext[kGPer];  // tr_m = trold_{m+1}
+    double trnext[kGPerG];  // tr_m = trold_{m+1}
 #pragma unroll
-    for (int k = 0; k < kGPer; ++k) trnext[k] = trold[k];
+    for (int k = 0; k < kGPerG; ++k) trnext[k] = trold[k];
     double *dsp = q.dspec + (((size_t)m * p.P + ip) * q.NPAR) * (size_t)p.LIMAX * p.Wpad + nu;
     for (int mm = nl - 1; mm >= 0; --mm) {
         const int lay = p.layinc[(size_t)mm * p.P + ip];
@@ -1599,10 +1603,10 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rtg(RtGParams q)
         double X = 0.0, Z = 0.0;
         double *rb = red;
         (void)NR;
-        double cg[kGPer];
+        double cg[kGPerG];
 #pragma unroll
-        for (int k = 0; k < kGPer; ++k) {
-            const int g = gy + k * kGY;
+        for (int k = 0; k < kGPerG; ++k) {
+            const int g = gy + k * GY;
             cg[k] = 0.0;
             if (g < G) {
                 const double to = tws[(size_t)mm * GWp + (size_t)g * p.Wpad];
@@ -1620,25 +1624,25 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rtg(RtGParams q)
         for (int sidx = 0; sidx < NP1; ++sidx) {
             double ysum = 0.0;
 #pragma unroll
-            for (int k = 0; k < kGPer; ++k) {
-                const int g = gy + k * kGY;
+            for (int k = 0; k < kGPerG; ++k) {
+                const int g = gy + k * GY;
                 if (g < G) ysum += cg[k] * dkl[((size_t)sidx * G + g) * p.Wpad];
             }
-            rb[((2 + sidx) * kGY + gy) * kWave + lane] = ysum;
+            rb[((2 + sidx) * GY + gy) * kWave + lane] = ysum;
         }
-        rb[(0 * kGY + gy) * kWave + lane] = X;
-        rb[(1 * kGY + gy) * kWave + lane] = Z;
+        rb[(0 * GY + gy) * kWave + lane] = X;
+        rb[(1 * GY + gy) * kWave + lane] = Z;
         __syncthreads();
         double Xs = 0.0, Zs = 0.0;
 #pragma unroll
-        for (int k = 0; k < kGY; ++k) { Xs += rb[(0 * kGY + k) * kWave + lane]; Zs += rb[(1 * kGY + k) * kWave + lane]; }
-        for (int kpar = gy; kpar < q.NPAR; kpar += kGY) {
+        for (int k = 0; k < GY; ++k) { Xs += rb[(0 * GY + k) * kWave + lane]; Zs += rb[(1 * GY + k) * kWave + lane]; }
+        for (int kpar = gy; kpar < q.NPAR; kpar += GY) {
             const int slot = q.slot_of_param[kpar];
             double v = 0.0;
             if (slot >= 0) {
                 double ys = 0.0;
 #pragma unroll
-                for (int k = 0; k < kGY; ++k) ys += rb[((2 + slot) * kGY + k) * kWave + lane];
+                for (int k = 0; k < GY; ++k) ys += rb[((2 + slot) * GY + k) * kWave + lane];
                 v = ys * ((slot == NP1 - 1) ? 1.0 : 1.0e-4);      // :3870 / :3872
             }
             if (q.dcont) v += q.dcont[(((size_t)m * q.NPAR + kpar) * p.L + lay) * p.Wpad + nu] * Xs;
