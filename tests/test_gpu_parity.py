@@ -299,6 +299,53 @@ def test_cirsradg_vs_oracle(eng, oracle, W, G, S, L, f32):
         assert np.max(np.abs(dspec[m] - rd) / scale) < 1e-9, m
 
 
+def test_analytic_jacobian_agrees_with_finite_differences(eng):
+    """The two Jacobian routes of the path against each other (KK vs finite differences to 1e-4): central
+    differences of the forward CIRSrad in the gas amounts, the layer temperatures and the surface temperature vs the
+    analytic dSPECOUT / dTSURF of CIRSrad(return_grad=True).  Amount slots are d/dAMOUNT in m-2 (:3868-3870): 1e-4 x the
+    derivative in the engine's cm-2 columns."""
+    from archnemesis_dist_amd import synthetic as syn
+    W, G, S, L, NP, NT = 128, 10, 3, 8, 8, 6
+    _, delg = syn.gauss_legendre_01(G, as_float32=False)
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S, seed=21)
+    WAVE = 400.0 + 1.5 * np.arange(W)
+    atm = syn.synth_atmosphere(L, S, seed=5)
+    lp, lt, am = atm["lay_press_pa"][0], atm["lay_temp"][0].copy(), atm["amount"][0].copy()
+    am *= 40.0                                                    # optical depths of order 1: every term matters
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L, emiss_ang=30.0)
+    TSURF, EMIS = 300.0, np.linspace(0.85, 1.0, W)
+    eng.upload_ktable(K, PRESS, TEMP, WAVE, delg)
+    NVMR, NPAR = S, S + 2
+    igas = np.arange(S, dtype=np.int32)
+
+    def forward(amount, temp, tsurf=TSURF):
+        emt = temp[LAYINC[:, 0]][:, None]
+        return np.squeeze(eng.cirsrad_ck_thermal(0, lp, temp, amount, None, NLAYIN, LAYINC, SCALE, emt, tsurf, EMISSIVITY=EMIS))
+
+    spec, dspec, dts = eng.cirsradg_ck_thermal(0, lp, lt, am, None, None, NVMR, NPAR, igas, NLAYIN, LAYINC, SCALE,
+                                               lt[LAYINC[:, 0]][:, None], TSURF, EMISSIVITY=EMIS)
+    dspec = np.asarray(dspec).reshape(W, NPAR, L, 1)[..., 0]       # (W, NPAR, path position)
+    pos = {int(l): j for j, l in enumerate(LAYINC[:, 0])}          # path position of each layer (nadir: every layer once)
+    top = np.abs(dspec).max()
+    worst = 0.0
+    for l in (0, 3, L - 1):
+        for g in range(S):
+            h = 1e-4 * am[g, l]
+            ap, an = am.copy(), am.copy(); ap[g, l] += h; an[g, l] -= h
+            fd = (forward(ap, lt) - forward(an, lt)) / (2 * h) * 1.0e-4
+            ana = dspec[:, g, pos[l]]
+            worst = max(worst, np.max(np.abs(fd - ana)) / np.abs(ana).max())
+        h = 1e-4 * lt[l]
+        tp, tn = lt.copy(), lt.copy(); tp[l] += h; tn[l] -= h
+        fd = (forward(am, tp) - forward(am, tn)) / (2 * h)
+        ana = dspec[:, NVMR, pos[l]]
+        worst = max(worst, np.max(np.abs(fd - ana)) / np.abs(ana).max())
+    h = 1e-3
+    fd = (forward(am, lt, TSURF + h) - forward(am, lt, TSURF - h)) / (2 * h)
+    worst = max(worst, np.max(np.abs(fd - np.squeeze(dts))) / np.abs(dts).max())
+    assert top > 0 and worst < 1e-5, worst
+
+
 @pytest.mark.parametrize("name", ["ms_nmu5_hg_ray", "ms_nmu5_tab_lambert", "ms_nmu16_tab_ray", "ms_nmu5_lookup",
                                   "ms_nmu5_lookup_lambert", "ms_nmu16_lookup_lambert"])
 def test_scloud11wave_core_golden(eng, golden_dir, name):
