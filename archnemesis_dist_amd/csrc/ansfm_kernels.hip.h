@@ -215,11 +215,11 @@ __global__ void k_calc_k_seam(const double *__restrict__ lnK, int W, int Wpad, i
 // 512-byte coalesced row.  The reference sorts the G*G sums tau_i + k_j*amount (argsort) and
 // walks the sorted list once to re-bin it (rank, ForwardModel_0.py:6117-6173).  Both inputs are
 // already sorted in g, so the sorted sequence is produced by a G-way streaming merge of the rows
-// (a_i + b_0..b_{G-1}) with a loser tree, and rank's walk consumes it on the fly: nothing of size
-// G*G is ever stored.  Per-lane state (a[G], b[G], tree nodes) lives in LDS as [index][lane], so a
-// lane-dependent index never causes a bank conflict (bank depends on the lane only).
+// (a_i + b_0..b_{G-1}) -- the row heads held as a sorted list in registers, see merge_step -- and rank's walk
+// consumes it on the fly: nothing of size G*G is ever stored.  The per-lane arrays a[G], b[G+1] live in LDS as
+// [index][lane], so a lane-dependent index never causes a bank conflict (bank depends on the lane only).
 //
-// LDS per wave: G*64*(8+8+8) bytes (+ shared del_g / g_ord tables)  -> 30.5 KiB at G=20.
+// LDS per wave: (2G+1)*64*8 bytes (+ shared del_g / g_ord tables)  -> 21.1 KiB at G=20, 7 waves per CU.
 // ------------------------------------------------------------------------------------------------
 struct OverlapParams {
     const double *lnK;        // [NP][NT][S][G][Wpad]            (FROM_K: unused)
@@ -298,25 +298,6 @@ __device__ __forceinline__ void load_gas(const OverlapParams &p, const LayerInte
     }
 }
 
-// Tree keys: the element value a_i + b_j with the low 10 mantissa bits replaced by (j<<5 | i).
-// Keys compare like the values except among values closer than 2^-42 relative (treated as ties,
-// which rank() orders arbitrarily anyway); the exact value is recomputed from a_i + b_j when the
-// element is consumed, so sums are the reference's.  One tree level = v_min_f64 + v_max_f64.
-__device__ __forceinline__ double pack_key(double v, int row, int col)
-{
-    unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    b = (b & ~0x3FFULL) | (unsigned long long)((col << 5) | row);
-    return __longlong_as_double((long long)b);
-}
-__device__ __forceinline__ double sentinel_key(int row)
-{   // finite, above every real optical depth; never NaN (an inf with payload bits would be)
-    return __longlong_as_double((long long)(0x7FE0000000000000ULL | (unsigned long long)row));
-}
-__device__ __forceinline__ void minmax_f64(double a, double b, double &lo, double &hi)
-{
-    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
-    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
-}
 __device__ __forceinline__ double fast_div(double n, double d)
 {   // n/d with v_rcp_f64 + 2 Newton steps + residual correction (<= ~1 ulp; frac of rank())
     double r = __builtin_amdgcn_rcp(d);
@@ -371,7 +352,10 @@ __device__ __forceinline__ void merge_fetch(double key, int lane, const double *
     else e.w = pair_weight<W32>(DG, PA[ci * kWave + lane], PB[cp * kWave + lane]);
 }
 
-// keys: value with the low 11 mantissa bits = (col << 5) | row   (col <= 32, row <= 31)
+// List keys: the element value a_i + b_j with the low 11 mantissa bits replaced by (col << 5) | row  (col <= 32,
+// row <= 31).  Keys compare like the values except among values closer than 2^-41 relative (treated as ties, which
+// rank() orders arbitrarily anyway); the exact value is recomputed from a_i + b_j when the element is consumed, so the
+// sums are the reference's.
 __device__ __forceinline__ double pack_key11(double v, int row, int col)
 {
     unsigned long long b = (unsigned long long)__double_as_longlong(v);
