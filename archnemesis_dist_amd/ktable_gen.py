@@ -11,72 +11,62 @@ import numpy as np
 from .forward_model import get_engine
 
 
+def _bin_half_widths(bins, grid, meas):
+    """half width of every output bin: half the table spacing, or the reach of the bin's filter beyond its centre"""
+    if meas is None:
+        return np.full(len(bins), 0.5 * (grid[1] - grid[0]))
+    return np.array([np.max(meas.VFIL[:meas.NFIL[b], b] - meas.VCONV[b, 0]) for b in bins])
+
+
+def _filter_tables(bins, meas):
+    """(nfil, offsets, amplitudes) of the per-bin instrument functions, offsets measured from the bin centre"""
+    count = np.array([meas.NFIL[b] for b in bins], dtype=np.int32)
+    off = np.zeros((int(count.max()), len(bins)))
+    amp = np.zeros_like(off)
+    for col, b in enumerate(bins):
+        n = count[col]
+        off[:n, col] = meas.VFIL[:n, b] - meas.VCONV[b, 0]
+        amp[:n, col] = meas.AFIL[:n, b]
+    return count, off, amp
+
+
 def calc_ktable_chunk(iwaves, Spectroscopy, Spectroscopy_LBL, self_frac, Measurement, device=0, engine=None):
-    """Drop-in for Spectroscopy_0.calc_ktable_chunk: -> k_coefficients (len(iwaves), NG, NP, NT)."""
-    eng = engine if engine is not None else get_engine(device)
-    iwaves = np.asarray(iwaves)
-    iwavemin, iwavemax = iwaves[0], iwaves[-1]
-    nwave = len(iwaves)
-    WAVE = np.asarray(Spectroscopy.WAVE, dtype=np.float64)
+    """Drop-in for Spectroscopy_0.calc_ktable_chunk (:3558): k-coefficients (len(iwaves), NG, NP, NT) of one chunk of
+    output bins.  The host keeps what the reference does per (p, T) -- line-by-line grid step = a fifth of the narrowest
+    Voigt half width (:3600-3607), spectrum from `calc_klbl_online` (:3613) -- and hands the per-bin sort / cumulative
+    distribution / g-quantile step (:3620-3652) for ALL bins of the chunk to the engine in one call."""
+    eng = get_engine(device) if engine is None else engine
+    bins = np.asarray(iwaves)
+    table, lbl = Spectroscopy, Spectroscopy_LBL
+    centres = np.asarray(table.WAVE, dtype=np.float64)[bins]
+    half = _bin_half_widths(bins, np.asarray(table.WAVE, dtype=np.float64), Measurement)
+    lo, hi = centres - half, centres + half
+    span_lo, span_hi = lo[0], hi[-1]                                   # the chunk: first bin's lower to last bin's upper edge
+    in_wavelength = int(lbl.ISPACE) == 1
+    wn_lo, wn_hi = (1.0e4 / span_hi, 1.0e4 / span_lo) if in_wavelength else (span_lo, span_hi)
 
-    def half_width(iw):                                           # :3566-3568, :3627-3629
-        return (Measurement.VFIL[0:Measurement.NFIL[iw], iw] - Measurement.VCONV[iw, 0]).max()
+    lines, margin = lbl.LINE_DATA[0], 2.0 * lbl.LINE_DATA_PARAMS[0].wn_approx_window
+    lines.set_params(vmin=wn_lo - margin, vmax=wn_hi + margin, wave_unit=0).fetch_linedata()
+    lines.fetch_partition_fn()
+    out = np.zeros((bins.size, table.NG, table.NP, table.NT))
+    if len(lines.combined_line_data.NU) == 0:                          # no lines in range: the table stays zero (:3595)
+        return out
 
-    if Measurement is not None:
-        vchunkmin = WAVE[iwavemin] - half_width(iwavemin)
-        vchunkmax = WAVE[iwavemax] + half_width(iwavemax)
-        vbinmin = np.array([WAVE[iw] - half_width(iw) for iw in iwaves])
-        vbinmax = np.array([WAVE[iw] + half_width(iw) for iw in iwaves])
-    else:
-        delwave = WAVE[1] - WAVE[0]
-        vchunkmin = WAVE[iwavemin] - delwave / 2.
-        vchunkmax = WAVE[iwavemax] + delwave / 2.
-        vbinmin = WAVE[iwaves] - delwave / 2.
-        vbinmax = WAVE[iwaves] + delwave / 2.
-    vchunkmean = np.mean(WAVE[iwaves])
-
-    linedata = Spectroscopy_LBL.LINE_DATA[0]
-    lineparams = Spectroscopy_LBL.LINE_DATA_PARAMS[0]
-    ispace = int(Spectroscopy_LBL.ISPACE)
-    if ispace == 1:
-        wnchunkmin = 1. / vchunkmax * 1.0e4
-        wnchunkmax = 1. / vchunkmin * 1.0e4
-    else:
-        wnchunkmin, wnchunkmax = vchunkmin, vchunkmax
-    linedata.set_params(vmin=wnchunkmin - lineparams.wn_approx_window * 2., vmax=wnchunkmax + lineparams.wn_approx_window * 2.,
-                        wave_unit=0).fetch_linedata()
-    linedata.fetch_partition_fn()
-    k_coefficients = np.zeros((nwave, Spectroscopy.NG, Spectroscopy.NP, Spectroscopy.NT))
-    if len(linedata.combined_line_data.NU) == 0:
-        return k_coefficients
-
-    G_ORD = np.asarray(Spectroscopy.G_ORD, dtype=np.float64)
-    fil = None
-    if Measurement is not None:                                   # np.interp(delta_wave, VFIL - VCONV, AFIL)  (:3641)
-        nfil = np.asarray([Measurement.NFIL[iw] for iw in iwaves], dtype=np.int32)
-        NF = int(nfil.max())
-        dfil = np.zeros((NF, nwave)); afil = np.zeros((NF, nwave))
-        for j, iw in enumerate(iwaves):
-            dfil[:nfil[j], j] = Measurement.VFIL[0:nfil[j], iw] - Measurement.VCONV[iw, 0]
-            afil[:nfil[j], j] = Measurement.AFIL[0:nfil[j], iw]
-        fil = (WAVE[iwaves], nfil, dfil, afil)
-
-    for ip in range(Spectroscopy.NP):
-        for it in range(Spectroscopy.NT):
-            pressx = Spectroscopy.PRESS[ip]
-            tempx = Spectroscopy.TEMP[it]
-            alpha_d = linedata.calculate_doppler_width(tempx, combined_output=True)
-            gamma_l = linedata.calculate_lorentz_width(tempx, pressx, amb_frac=1. - self_frac, combined_output=True)
-            hwhm_voigt = 0.5346 * gamma_l + np.sqrt(0.2166 * gamma_l ** 2. + alpha_d ** 2.)
-            delwn_calc = np.min(hwhm_voigt) / 5.
-            delv_calc = delwn_calc * (vchunkmean ** 2.) / 1.0e4 if ispace == 1 else delwn_calc
-            ncalc = int((vchunkmax - vchunkmin) / delv_calc)
-            wavecalc = np.linspace(vchunkmin, vchunkmax, ncalc)
-            Spectroscopy_LBL.NWAVE = ncalc
-            Spectroscopy_LBL.WAVE = wavecalc
-            kabs = Spectroscopy_LBL.calc_klbl_online(1, [pressx], [tempx], amb_frac=1. - self_frac)[:, 0, 0]
-            k_coefficients[:, :, ip, it] = eng.kdist_bins(wavecalc, kabs, vbinmin, vbinmax, G_ORD, fil)
-    return k_coefficients
+    g_ord = np.asarray(table.G_ORD, dtype=np.float64)
+    fil = None if Measurement is None else (centres,) + _filter_tables(bins, Measurement)
+    amb = 1.0 - self_frac
+    for ip, it in np.ndindex(table.NP, table.NT):
+        p_atm, t_k = table.PRESS[ip], table.TEMP[it]
+        doppler = lines.calculate_doppler_width(t_k, combined_output=True)
+        lorentz = lines.calculate_lorentz_width(t_k, p_atm, amb_frac=amb, combined_output=True)
+        step = np.min(0.5346 * lorentz + np.sqrt(0.2166 * lorentz ** 2. + doppler ** 2.)) / 5.      # Voigt HWHM / 5
+        if in_wavelength:
+            step = step * (np.mean(centres) ** 2.) / 1.0e4
+        npts = int((span_hi - span_lo) / step)
+        lbl.NWAVE, lbl.WAVE = npts, np.linspace(span_lo, span_hi, npts)
+        kabs = lbl.calc_klbl_online(1, [p_atm], [t_k], amb_frac=amb)[:, 0, 0]
+        out[:, :, ip, it] = eng.kdist_bins(lbl.WAVE, kabs, lo, hi, g_ord, fil)
+    return out
 
 
 def install_gpu_ktable_generator(device=0):
