@@ -483,6 +483,31 @@ def test_lbl_runtime_batched_unsorted_vs_oracle(eng, oracle, golden_dir):
     np.testing.assert_allclose(out, ref, rtol=1e-10)
 
 
+def test_lbl_runtime_large_grid_properties(eng):
+    """C5-like sizes the oracle cannot reach in seconds (2e5 grid points x 2e4 lines x 4 layers): the spectrum of a line
+    list is the sum of the spectra of its parts (accumulation into `out` in line order, so exactly: two calls on the same
+    `out` vs one call), scales linearly with the isotopic abundance, and is non-negative."""
+    rng = np.random.default_rng(55)
+    nw, N, L, M = 200000, 20000, 4, 2
+    wn = 2000.0 + 1e-3 * np.arange(nw)
+    nu = np.sort(rng.uniform(1995.0, 2205.0, N))
+    sw = 10.0 ** rng.uniform(-28, -20, N); el = rng.uniform(0, 3000, N)
+    sr = 1.0 - np.exp(-1.4387769 * nu / 296.0)
+    bp = np.stack([rng.uniform(0.02, 0.1, N), rng.uniform(0.5, 0.8, N), rng.uniform(-0.01, 0.01, N),
+                   rng.uniform(0.05, 0.12, N), rng.uniform(0.5, 0.8, N), rng.uniform(-0.01, 0.01, N)])
+    mmf = np.array([0.9, 0.1])
+    t = np.array([150.0, 200.0, 250.0, 300.0]); p = np.array([1e-4, 1e-2, 0.3, 1.0]); q = np.array([2.1, 1.5, 1.1, 0.98])
+    run = lambda sel, out, iso=0.9: eng.add_line_set_monochromatic_absorption(
+        wn, 0, t, 296.0, p, 1.0, q, iso, 28.0, mmf, bp[:, sel], nu[sel], sw[sel], el[sel], sr[sel], out)
+    full = np.zeros((L, nw)); run(slice(None), full)
+    half = N // 2
+    parts = np.zeros((L, nw)); run(slice(0, half), parts); run(slice(half, N), parts)
+    assert np.array_equal(full, parts)                                # same additions in the same (ascending line) order
+    twice = np.zeros((L, nw)); run(slice(None), twice, iso=1.8)
+    np.testing.assert_allclose(twice, 2.0 * full, rtol=1e-14)
+    assert full.min() >= 0.0 and full.max() > 0.0
+
+
 @pytest.mark.parametrize("case", ["cg_nadir", "cg_slant", "mid_slant", "cg_dustunits"])
 def test_layer_average_golden(eng, golden_dir, case):
     """Layer_0.layer_average (Curtis-Godson / mid-path) vs the reference (golden), single state and a batch."""
