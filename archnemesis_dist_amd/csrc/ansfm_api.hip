@@ -198,8 +198,13 @@ int ansfm_upload_ktable_dev(ansfm_ctx *ctx, int W, int G, int NP, int NT, int S,
     HIPCHK(hipMemcpyAsync(ctx->d_wave.p, WAVE, (size_t)W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_delg.p, DELG, G * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_flag.p, 0, 16 * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_table_relayout, dim3(nblk(total, 256)), dim3(256), 0, ctx->stream, K_dev,
-                       ctx->lnK.as<double>(), W, Wpad, G, NP, NT, S, ctx->d_flag.as<int>());
+    {
+        const int Q = NP * NT * S;
+        hipLaunchKernelGGL(k_table_check, dim3(nblk((size_t)W * Q, 256)), dim3(256), 0, ctx->stream, K_dev, W, G, Q,
+                           ctx->d_flag.as<int>());
+        hipLaunchKernelGGL(k_table_relayout, dim3((unsigned)(Wpad / kWave), nblk((size_t)Q, 64), (unsigned)G), dim3(256), 0,
+                           ctx->stream, K_dev, ctx->lnK.as<double>(), W, Wpad, G, Q);
+    }
     HIPCHK(hipGetLastError());
     int flag = 0;
     HIPCHK(hipMemcpyAsync(&flag, ctx->d_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -119,32 +119,42 @@ __global__ void k_layer_prep(int n_layers_total, const double *__restrict__ lay_
 
 // ------------------------------------------------------------------------------------------------
 // Table upload: K[W][G][NP][NT][S] (reference layout) -> lnK[NP][NT][S][G][Wpad].
-// One thread per destination element; also checks k>=0 and non-decreasing in g (flag[0] |= 1).
+// For every g this is a transpose between w and q = (p, t, s): 64 x 64 tiles through LDS, reads coalesced along q,
+// writes coalesced along w.  k_table_check flags k < 0 / NaN or k decreasing in g (flag[0] |= 1), reading the source
+// coalesced as well (one thread per (w, q), g sequential).
 // ------------------------------------------------------------------------------------------------
-__global__ void k_table_relayout(const double *__restrict__ K, double *__restrict__ lnK, int W,
-                                 int Wpad, int G, int NP, int NT, int S, int *flag)
+__global__ __launch_bounds__(256) void k_table_relayout(const double *__restrict__ K, double *__restrict__ lnK, int W,
+                                                        int Wpad, int G, int Q)
 {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t total = (size_t)NP * NT * S * G * Wpad;
-    if (idx >= total) return;
-    int w = (int)(idx % Wpad);
-    size_t r = idx / Wpad;
-    int g = (int)(r % G); r /= G;
-    int s = (int)(r % S); r /= S;
-    int t = (int)(r % NT);
-    int p = (int)(r / NT);
-    double k = 0.0;
-    if (w < W) {
-        size_t src = ((((size_t)w * G + g) * NP + p) * NT + t) * S + s;
-        k = K[src];
-        bool bad = !(k >= 0.0);
-        if (g > 0) {
-            double kprev = K[src - (size_t)NP * NT * S];
-            if (k < kprev) bad = true;
-        }
-        if (bad) atomicOr(flag, 1);
+    __shared__ double tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+    const int w0 = blockIdx.x * 64, q0 = blockIdx.y * 64, g = blockIdx.z;
+    for (int r = ty; r < 64; r += 4) {
+        const int w = w0 + r, q = q0 + tx;
+        tile[r][tx] = (w < W && q < Q) ? K[((size_t)w * G + g) * Q + q] : 0.0;
     }
-    lnK[idx] = encode_lnk(k);
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int q = q0 + r;
+        if (q < Q) lnK[((size_t)q * G + g) * Wpad + w0 + tx] = encode_lnk(tile[tx][r]);      // pad lanes: k = 0
+    }
+}
+
+__global__ void k_table_check(const double *__restrict__ K, int W, int G, int Q, int *flag)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)W * Q) return;
+    const int q = (int)(idx % Q);
+    const size_t w = idx / Q;
+    const double *src = K + w * (size_t)G * Q + q;
+    bool bad = false;
+    double prev = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const double k = src[(size_t)g * Q];
+        bad |= !(k >= 0.0) || (g > 0 && k < prev);
+        prev = k;
+    }
+    if (bad) atomicOr(flag, 1);
 }
 
 // k for one (corner set, u, v): Spectroscopy_0.py:2391-2403 (+ dk/dT :2241-2247 when wanted)
