@@ -100,6 +100,27 @@ def test_k_overlap_unsorted_vs_oracle(eng, oracle, G, S, f32):
     np.testing.assert_allclose(tau, ref, rtol=1e-11, atol=0)
 
 
+@pytest.mark.parametrize("G,S", [(32, 3), (24, 2), (12, 4), (9, 5), (2, 3), (1, 4)])
+def test_merge_list_lengths_vs_oracle(eng, oracle, G, S):
+    """Every instantiated list length of the merge kernels (8, 10, 16, 20, 32), with and without padding entries, up
+    to the largest supported G (32: the column tag needs its sixth bit) and down to G = 1 -- forward and gradient."""
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(1000 + G)
+    W, L = 70, 4
+    _, delg = syn.gauss_legendre_01(G, G % 2 == 0)
+    k = np.sort(10.0 ** rng.uniform(-25, -20, (W, G, L, S)), axis=1)
+    dkdT = k * rng.uniform(-0.02, 0.02, k.shape)
+    amount = 10.0 ** rng.uniform(19, 22, (S, L))
+    np.testing.assert_allclose(eng.k_overlap(delg, k, amount), oracle.k_overlap(delg, k, amount), rtol=1e-11, atol=0)
+    tau, dk = eng.k_overlapg(delg, k, dkdT, amount)
+    rt, rdk = oracle.k_overlapg(delg, k, dkdT, amount)
+    np.testing.assert_allclose(tau, rt, rtol=1e-11, atol=0)
+    assert np.array_equal(np.isnan(dk), np.isnan(rdk))          # G = 1: rankg's single bin leaves 0/0 slots in the reference too
+    ok = ~np.isnan(rdk)
+    scale = np.max(np.where(ok, np.abs(rdk), 0.0), axis=1, keepdims=True) + 1e-300
+    assert np.max((np.abs(dk - rdk) / scale)[ok], initial=0.0) < 1e-10
+
+
 def test_nan_and_inf_input_stays_in_its_cells(eng, oracle):
     """NaN / inf absorption coefficients poison only the (wavenumber, layer) cells they are in: the merge kernels never
     index by data beyond what the bin sentinel bounds (a NaN key can displace list entries), so the other cells equal
