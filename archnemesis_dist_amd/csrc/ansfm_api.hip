@@ -992,11 +992,11 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
 #define LAUNCH_OVG(D, FK)                                                                                           \
     do {                                                                                                            \
         if (ctx->delg_f32) {                                                                                        \
-            if (sorted) hipLaunchKernelGGL((k_ck_overlapg<D, FK, true, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);   \
-            else hipLaunchKernelGGL((k_ck_overlapg<D, FK, true, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);         \
+            if (sorted) hipLaunchKernelGGL((k_ck_overlapg<D, true, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);   \
+            else hipLaunchKernelGGL((k_ck_overlapg<D, true, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);         \
         } else {                                                                                                    \
-            if (sorted) hipLaunchKernelGGL((k_ck_overlapg<D, FK, false, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);  \
-            else hipLaunchKernelGGL((k_ck_overlapg<D, FK, false, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);        \
+            if (sorted) hipLaunchKernelGGL((k_ck_overlapg<D, false, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);  \
+            else hipLaunchKernelGGL((k_ck_overlapg<D, false, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, pg);        \
         }                                                                                                           \
     } while (0)
 #define LAUNCH_OVG_D(FK)                                              \
@@ -1007,7 +1007,8 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
         case 20: LAUNCH_OVG(20, FK); break;                           \
         default: LAUNCH_OVG(32, FK); break;                           \
     }
-    if (from_k) { LAUNCH_OVG_D(true); } else { LAUNCH_OVG_D(false); }
+    (void)from_k;                     // the kernel tests p.kin (run-time flag, see load_gas_g)
+    LAUNCH_OVG_D(false);
 #undef LAUNCH_OVG_D
 #undef LAUNCH_OVG
     HIPCHK(hipGetLastError());

@@ -667,15 +667,17 @@ struct OverlapGParams {
     unsigned long long *perm; // [grid][ceil(G*G/4)][64]: four 16-bit step codes per word
 };
 
-template <bool FROM_K>
+// from_k (array-level k_overlapg seam) is a run-time flag here: the load phase is a few per cent of the kernel and one
+// template parameter less halves the number of instantiations of the largest kernel of the library.
 __device__ __forceinline__ void load_gas_g(const OverlapGParams &pg, const LayerInterp &q, int m, int l, int s,
                                            int nu, double *DST, double *KR, double *DT, int lane, bool &unsorted)
 {
+    const bool FROM_K = pg.o.kin != nullptr;
     const OverlapParams &p = pg.o;
     const int G = p.G;
     const double amt = p.amount[((size_t)m * p.S + s) * p.L + l];
     double prev = -__builtin_inf();
-    if constexpr (FROM_K) {
+    if (FROM_K) {
         const size_t base = (((size_t)s * p.L + l) * G) * p.Wpad + nu;
         for (int g0 = 0; g0 < G; g0 += kLoadBatch) {
             double r1[kLoadBatch], r2[kLoadBatch];
@@ -861,7 +863,7 @@ __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const doub
 // the original g-ordinate of each sorted position.  The gradient rows in the global scratch stay in ORIGINAL order while
 // a spectrum is unmerged (rows and columns are staged through PA / PB for the replay) and are in bin order -- the
 // identity -- after a merge.
-template <int NR, bool FROM_K, bool W32, bool SORTED = true>
+template <int NR, bool W32, bool SORTED = true>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_ck_overlapg(OverlapGParams pg)
 {
     const OverlapParams &p = pg.o;
@@ -902,11 +904,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         if (!tq.next(p, lane, vt, m, l)) break;
         const int nu = vt * kWave + lane;
         LayerInterp q;
-        if constexpr (!FROM_K) q = p.li[(size_t)m * p.L + l];
+        if (p.kin == nullptr) q = p.li[(size_t)m * p.L + l];
         bool unsorted = false;
         int cur = 0;
         // gas 0: a = k0*amount0 ; D[0] = k0 (d/d amount0), D[1] = dkdT0*amount0 (d/dT), rest 0
-        load_gas_g<FROM_K>(pg, q, m, l, 0, nu, A, Dbuf[0], Dbuf[0] + GW, lane, unsorted);
+        load_gas_g(pg, q, m, l, 0, nu, A, Dbuf[0], Dbuf[0] + GW, lane, unsorted);
         double alast = A[(G - 1) * kWave + lane];       // last g-ordinate in the ORIGINAL order
         if constexpr (!SORTED) sort_column(A, PA, G, lane);
         for (int pp = 2; pp < NP1; ++pp)
@@ -915,7 +917,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         for (int s = 1; s < p.S; ++s) {
             const int igas = s - 1;
             const int n = igas + 3;  // rankg's `n`
-            load_gas_g<FROM_K>(pg, q, m, l, s, nu, B, KRB, DTB, lane, unsorted);
+            load_gas_g(pg, q, m, l, s, nu, B, KRB, DTB, lane, unsorted);
             if constexpr (SORTED)                       // the call is rerun on the generic path: no point in merging
                 if (__builtin_amdgcn_ballot_w64(unsorted) != 0) break;
             double *Dold = Dbuf[cur], *Dnew = Dbuf[cur ^ 1];
