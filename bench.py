@@ -97,8 +97,10 @@ def main():
 
     # ---- synthetic inputs, resident in HBM -----------------------------------------------------
     _, delg = syn.gauss_legendre_01(G, as_float32=True)
+    delg = delg.astype(np.float32)          # a .kta header gives float32 arrays: NumPy then forms del_g[i]*del_g[j] in float32
     WAVE = 200.0 + 0.1 * np.arange(W)
     PRESS, TEMP, Kdev = torch_ktable(torch, dev, W, G, NP, NT, S, seed=20260704)
+    PRESS, TEMP = PRESS.astype(np.float32), TEMP.astype(np.float32)      # like read_ktahead (Spectroscopy_0.py:2544-2559)
     torch.cuda.synchronize()
     t0 = time.time()
     eng.upload_ktable(Kdev, PRESS, TEMP, WAVE, delg)
