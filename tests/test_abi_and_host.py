@@ -164,3 +164,19 @@ def test_jacobian_nemesis_sharded_gloo_world2(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_strict_switch_turns_delegations_into_errors():
+    """forward_model.set_strict: a case outside the GPU path is counted (default) or refused (strict)."""
+    import archnemesis_dist_amd.forward_model as fmod
+    before = dict(fmod.DELEGATED)
+    try:
+        fmod.set_strict(False)
+        fmod._delegate("unit-test case")
+        assert fmod.DELEGATED["unit-test case"] == before.get("unit-test case", 0) + 1
+        fmod.set_strict(True)
+        with pytest.raises(NotImplementedError):
+            fmod._delegate("unit-test case")
+    finally:
+        fmod.set_strict(False)
+        fmod.DELEGATED.pop("unit-test case", None)
