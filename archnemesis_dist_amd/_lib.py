@@ -52,8 +52,21 @@ def build(force=False, verbose=False):
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-fvisibility=hidden", "-o", LIB_PATH] + srcs
+    # one object per translation unit, compiled side by side, then one link
+    from concurrent.futures import ThreadPoolExecutor
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+    objs = [os.path.join(os.path.dirname(LIB_PATH), os.path.splitext(os.path.basename(src))[0] + ".o") for src in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        cmd = [hipcc_path()] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=len(srcs)) as pool:
+        list(pool.map(compile_one, zip(srcs, objs)))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
