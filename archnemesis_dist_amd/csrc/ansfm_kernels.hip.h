@@ -428,8 +428,9 @@ __device__ __forceinline__ unsigned merge_step(double (&R)[NR], MergeElem &e, Me
     asm("v_min_f64 %0, %1, %2" : "=v"(R[0]) : "v"(x), "v"(R[1]));
     // 2. fetch the operands of the new winner (LDS reads in flight during the rest of the pass and the walk)
     merge_fetch<W32, SORTED>(R[0], lane, A, B, DG, en, PA, PB);
-    // 3. finish the insertion (maxes and mins in blocks, so no result is consumed by the next instruction)
-    constexpr int kBlk = 6;
+    // 3. finish the insertion: every max first, then every min -- no result is consumed by a neighbouring instruction
+    //    (6.40 -> 6.32 ms against blocks of 6, same box)
+    constexpr int kBlk = NR;
 #pragma unroll
     for (int k0 = 1; k0 < NR - 1; k0 += kBlk) {
         double mk[kBlk];
