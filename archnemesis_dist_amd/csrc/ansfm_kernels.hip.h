@@ -378,8 +378,20 @@ __device__ __forceinline__ double pack_key11(double v, int row, int col)
 // sums in a different association.
 struct WalkState {
     double gd, kacc, sum1, gnext;
-    int ig;
+    unsigned roff;      // byte offset of this lane's slot in the record of the bin being filled: (ig * 6 * 64 + lane) * 8
+    unsigned gaddr;     // LDS byte address of GORD[ig + 1]
 };
+__device__ __forceinline__ WalkState walk_begin(const double *GORD, int lane)
+{
+    WalkState ws;
+    ws.gd = 0.0; ws.kacc = 0.0; ws.sum1 = 0.0;
+    ws.gaddr = lds_addr(GORD + 1);
+    ws.gnext = lds_ld(ws.gaddr);
+    ws.roff = (unsigned)lane * 8u;
+    return ws;
+}
+// number of bins closed so far
+__device__ __forceinline__ int walk_bins(const WalkState &ws, const double *GORD) { return (int)((ws.gaddr - lds_addr(GORD + 1)) >> 3); }
 
 template <bool REC_CODE>
 __device__ __forceinline__ bool merge_walk(const MergeElem &e, WalkState &ws, double *rec, const double *GORD,
@@ -388,20 +400,23 @@ __device__ __forceinline__ bool merge_walk(const MergeElem &e, WalkState &ws, do
     const double cv = e.ai + e.bc;
     const double w = e.w;
     const double gdn = ws.gd + w;
-    const double cw = cv * w;
-    double kn = ws.kacc + cw, sn = ws.sum1 + w;
+    double kn = ws.kacc + cv * w, sn = ws.sum1 + w;
     // ordered >= : GORD[G+1] is NaN, so nothing crosses after the last bin whatever gdn is (garbage weights of a call
-    // that is going to be rerun on the generic path, NaN / inf input) -- ig, and with it every record index, stays <= G
+    // that is going to be rerun on the generic path, NaN / inf input) -- the record index stays <= G
     const bool cross = (gdn >= ws.gnext);
     if (cross) {                                // this element straddles the bin boundary
-        double *rp = rec + (size_t)ws.ig * 6 * kWave + lane;
-        rp[0] = ws.kacc; rp[kWave] = ws.sum1; rp[2 * kWave] = cw; rp[3 * kWave] = w;
+        // The branch runs in almost every step (some lane of the 64 crosses), so it is kept to stores and two adds: the
+        // record slot is a running 32-bit byte offset onto the wave-uniform base (no 64-bit index arithmetic), the
+        // element's value goes out unmultiplied (the resolve loop forms cv * w, the same product).
+        double *rp = reinterpret_cast<double *>(reinterpret_cast<char *>(rec) + ws.roff);
+        rp[0] = ws.kacc; rp[kWave] = ws.sum1; rp[2 * kWave] = cv; rp[3 * kWave] = w;
         rp[4 * kWave] = ws.gd;
         if constexpr (REC_CODE)   // gradient kernel: which element closed the bin
             rp[5 * kWave] = __longlong_as_double((long long)(e.ci | ((e.np - 1) << 5)));
         kn = 0.0; sn = 0.0;
-        ws.ig += 1;
-        ws.gnext = GORD[ws.ig + 1];             // GORD[G+1] = NaN: nothing crosses after the last bin
+        ws.roff += 6u * kWave * 8u;
+        ws.gaddr += 8u;
+        ws.gnext = lds_ld(ws.gaddr);            // GORD[G+1] = NaN: nothing crosses after the last bin
     }
     ws.kacc = kn; ws.sum1 = sn;
     ws.gd = gdn;
@@ -580,7 +595,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 merge_init<NR>(R, G, lane, A, B[lane], HUGE_KEY);
                 MergeElem e0, e1;
                 merge_fetch<W32, SORTED>(R[0], lane, A, B, DG, e0, PA, PB);
-                WalkState ws{0.0, 0.0, 0.0, GORD[1], 0};
+                WalkState ws = walk_begin(GORD, lane);
                 const int nloop = G * G;
                 int it = 0;
                 for (; it + 1 < nloop; it += 2) {   // ping-pong: no register rotation
@@ -590,7 +605,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 if (it < nloop) merge_step<NR, W32, false, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
                 // ---- resolve the bins --------------------------------------------------------------------
                 double ck = 0.0, cs = 0.0;   // (1-frac) share carried into the next bin
-                const int ig = ws.ig;
+                const int ig = walk_bins(ws, GORD);
                 constexpr int kRB = 5;       // records of kRB bins are fetched together (one round trip)
                 for (int b0 = 0; b0 < G; b0 += kRB) {
                     double rka[kRB], rs1[kRB], rcw[kRB], rw[kRB], rgd[kRB];
@@ -607,7 +622,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                         if (b < G) {
                             double outv = 0.0;
                             if (b < ig) {
-                                const double ka = rka[k], s1 = rs1[k], cw = rcw[k], w = rw[k];
+                                const double ka = rka[k], s1 = rs1[k], w = rw[k], cw = rcw[k] * w;   // rcw holds cv
                                 // a crossing at the very first element (nothing accumulated yet) sees python's gdist[-1]
                                 const double gd0 = rgd[k];
                                 const double gprev = (b == 0 && s1 == 0.0) ? wtot : gd0;
@@ -959,7 +974,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 merge_init<NR>(R, G, lane, A, B[lane], HUGE_KEY);
                 MergeElem e0, e1;
                 merge_fetch<W32, SORTED>(R[0], lane, A, B, DG, e0, PA, PB);
-                WalkState ws{0.0, 0.0, 0.0, GORD[1], 0};
+                WalkState ws = walk_begin(GORD, lane);
                 unsigned long long *pw = perm + lane;
                 int it = 0;
                 for (; it + 3 < nloop; it += 4) {
@@ -981,7 +996,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 }
                 // ---- resolve the bins: merged k -> ASAVE, (frac, 1/sum) -> rec ------------------------------
                 double ck = 0.0, cs = 0.0;
-                const int ig = ws.ig;
+                const int ig = walk_bins(ws, GORD);
                 constexpr int kRB = 5;
                 for (int b0 = 0; b0 < G; b0 += kRB) {
                     double rka[kRB], rs1[kRB], rcw[kRB], rw[kRB], rgd[kRB];
@@ -997,7 +1012,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                         if (b < G) {
                             double outv = 0.0, fr = 0.0, rinv = 1.0;
                             if (b < ig) {
-                                const double ka = rka[k], s1 = rs1[k], cw = rcw[k], w = rw[k], gd0 = rgd[k];
+                                const double ka = rka[k], s1 = rs1[k], w = rw[k], cw = rcw[k] * w, gd0 = rgd[k];   // rcw holds cv
                                 const double gprev = (b == 0 && s1 == 0.0) ? wtot : gd0;
                                 const double gdn = gd0 + w;
                                 fr = (GORD[b + 1] - gprev) / (gdn - gprev);
