@@ -788,9 +788,12 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
     // four steps of one code word: all LDS operands first (one LDS round trip per word), then the dependent part
     auto group = [&](unsigned long long word, int nst) {
         double g[4], wr[4];
+        const unsigned wlo = (unsigned)word, whi = (unsigned)(word >> 32);     // 32-bit decode: no 64-bit shifts / compares
+        unsigned crs[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned code = (unsigned)(word >> (16 * k)) & 0xFFFFu;
+            const unsigned code = ((k < 2 ? wlo : whi) >> (16 * (k & 1))) & 0xFFFFu;
+            crs[k] = code & 0x8000u;
             const int row = code & 31, col = (code >> 5) & 31;
             if constexpr (SORTED) wr[k] = pair_weight<W32>(DG, row, col);
             else wr[k] = pair_weight<W32>(DG, PA[row * kWave + lane], PB[col * kWave + lane]);
@@ -799,7 +802,7 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < nst) {
-                const bool cross = ((word >> (16 * k + 15)) & 1ULL) != 0;
+                const bool cross = crs[k] != 0;
                 const double w = wr[k];
                 OUTL[bo] = acc;
                 const double an = acc + g[k] * w;
@@ -908,7 +911,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     const size_t GW = (size_t)G * kWave;
     double *gs = pg.gscratch + (size_t)blockIdx.x * (3 + 2 * (size_t)NP1) * GW;
     double *KRB = gs, *DTB = gs + GW;
-    double *Dbuf[2] = {gs + 2 * GW, gs + (2 + (size_t)NP1) * GW};
+    // the two gradient-row buffers as offsets onto `gs`: indexing an array of pointers would lose the global address
+    // space (flat loads / stores, which also tie up the LDS counter)
+    const size_t dboff[2] = {2 * GW, (2 + (size_t)NP1) * GW};
+    double *const Dbuf0 = gs + dboff[0];
     double *ASAVE = gs + (2 + 2 * (size_t)NP1) * GW;
     const int nloop = G * G;
     unsigned long long *perm = pg.perm + (size_t)blockIdx.x * ((nloop + 3) >> 2) * kWave;
@@ -924,11 +930,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         bool unsorted = false;
         int cur = 0;
         // gas 0: a = k0*amount0 ; D[0] = k0 (d/d amount0), D[1] = dkdT0*amount0 (d/dT), rest 0
-        load_gas_g(pg, q, m, l, 0, nu, A, Dbuf[0], Dbuf[0] + GW, lane, unsorted);
+        load_gas_g(pg, q, m, l, 0, nu, A, Dbuf0, Dbuf0 + GW, lane, unsorted);
         double alast = A[(G - 1) * kWave + lane];       // last g-ordinate in the ORIGINAL order
         if constexpr (!SORTED) sort_column(A, PA, G, lane);
         for (int pp = 2; pp < NP1; ++pp)
-            for (int g = 0; g < G; ++g) Dbuf[0][(size_t)pp * GW + g * kWave + lane] = 0.0;
+            for (int g = 0; g < G; ++g) Dbuf0[(size_t)pp * GW + g * kWave + lane] = 0.0;
 
         for (int s = 1; s < p.S; ++s) {
             const int igas = s - 1;
@@ -936,7 +942,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
             load_gas_g(pg, q, m, l, s, nu, B, KRB, DTB, lane, unsorted);
             if constexpr (SORTED)                       // the call is rerun on the generic path: no point in merging
                 if (__builtin_amdgcn_ballot_w64(unsorted) != 0) break;
-            double *Dold = Dbuf[cur], *Dnew = Dbuf[cur ^ 1];
+            double *Dold = gs + (cur ? dboff[1] : dboff[0]), *Dnew = gs + (cur ? dboff[0] : dboff[1]);
             const double blast = B[(G - 1) * kWave + lane];
             if constexpr (!SORTED) sort_column(B, PB, G, lane);
             if constexpr (SORTED) alast = A[(G - 1) * kWave + lane];
@@ -1076,7 +1082,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
             for (int g = 0; g < G; ++g) out[(size_t)PA[g * kWave + lane] * p.Wpad] = A[g * kWave + lane];
         }
         double *dout = pg.dk + (((size_t)m * p.L + l) * NP1) * G * p.Wpad + nu;
-        const double *Dc = Dbuf[cur];
+        const double *Dc = gs + (cur ? dboff[1] : dboff[0]);
         for (int pp = 0; pp < NP1; ++pp)
             for (int g = 0; g < G; ++g)
                 dout[((size_t)pp * G + g) * p.Wpad] = Dc[(size_t)pp * GW + g * kWave + lane];
