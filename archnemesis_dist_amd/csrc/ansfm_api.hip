@@ -554,6 +554,7 @@ static int read_unsorted(ansfm_ctx *ctx, int *flag)
     *flag = 0;
     HIPCHK(hipMemcpyAsync(flag, ctx->d_flag.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (*flag & 2) FAIL(ANSFM_ERR_HIP, "merge kernel: dynamic LDS does not start at address 0 (unexpected code object layout)");
     *flag &= 1;
     return ANSFM_OK;
 }

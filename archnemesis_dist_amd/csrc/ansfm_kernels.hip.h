@@ -251,6 +251,9 @@ struct OverlapParams {
 // g-ordinate (a wave has at most one sibling on its SIMD to hide it behind).  Indices are clamped, not
 // predicated, so the batch stays branch-free.
 constexpr int kLoadBatch = 10;
+// LDS byte offsets of the tables that open the merge kernels' dynamic LDS block (the kernels have no static LDS, so the
+// block starts at address 0 -- checked once per launch): reads become `ds_read vaddr = index << k, offset:const`.
+constexpr unsigned kLdsDG = 0, kLdsGORD = kMaxG * 8, kLdsDGF = (2 * kMaxG + 2) * 8, kLdsA = kLdsDGF + kMaxG * 4;
 
 template <bool FROM_K>
 __device__ __forceinline__ void load_gas(const OverlapParams &p, const LayerInterp &q, int m, int l,
@@ -324,6 +327,8 @@ typedef __attribute__((address_space(3))) double lds_double;
 __device__ __forceinline__ unsigned lds_addr(const double *p) { return (unsigned)(size_t)(const lds_double *)p; }
 __device__ __forceinline__ double lds_ld(unsigned a) { return *(const lds_double *)(size_t)a; }
 __device__ __forceinline__ void lds_st(unsigned a, double v) { *(lds_double *)(size_t)a = v; }
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ float lds_ldf(unsigned a) { return *(const lds_float *)(size_t)a; }
 
 struct MergeElem {
     double ai, bc, bn, w;
@@ -459,7 +464,9 @@ __device__ __forceinline__ unsigned merge_step(double (&R)[NR], MergeElem &e, Me
     asm("v_max_f64 %0, %1, %2" : "=v"(R[NR - 1]) : "v"(x), "v"(R[NR - 1]));
     // 4. rank walk on the element just consumed
     const bool cross = merge_walk<REC_CODE>(e, ws, rec, GORD, lane);
-    return (unsigned)(e.ci | ((e.np - 1) << 5) | (cross ? 0x8000 : 0));
+    // stream format of the gradient replay: bits 2-6 = row * 4, bits 9-13 = column * 4 (byte offsets into the float32
+    // weight table, << 7 more = the row of an [index][lane] LDS array), bit 15 = the element closed a bin
+    return (unsigned)((e.ci << 2) | ((e.np - 1) << 9) | (cross ? 0x8000 : 0));
 }
 
 // R[i] = head of row i = a_i + b_0: ascending in i because a is (fast path: by precondition; generic: sorted first).
@@ -537,11 +544,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
     const int G = p.G;
-    double *A = smem;
-    double *B = A + G * kWave;                   // G+1 rows
-    double *DG = B + (G + 1) * kWave;
+    // tables first: their LDS addresses are compile-time constants (dynamic LDS starts at 0), so a table read is
+    // `ds_read vaddr = index << k, offset:const` with no base add
+    double *DG = smem;                           // [kMaxG] doubles, then GORD [kMaxG + 2], then the float32 copy of DG
     double *GORD = DG + kMaxG;
-    unsigned char *PA = reinterpret_cast<unsigned char *>(GORD + kMaxG + 2) + kMaxG * sizeof(float);   // SORTED = false only
+    double *A = reinterpret_cast<double *>(reinterpret_cast<char *>(GORD + kMaxG + 2) + kMaxG * sizeof(float));
+    double *B = A + G * kWave;                   // G+1 rows
+    unsigned char *PA = reinterpret_cast<unsigned char *>(B + (G + 1) * kWave);   // SORTED = false only
     unsigned char *PB = PA + G * kWave;
     if (lane < G) {
         DG[lane] = p.del_g[lane];
@@ -784,30 +793,35 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
                                               const unsigned char *PA = nullptr, const unsigned char *PB = nullptr)
 {
     double acc = 0.0;
-    int bo = lane;                                  // b * 64 + lane
-    // four steps of one code word: all LDS operands first (one LDS round trip per word), then the dependent part
+    unsigned bo = lds_addr(OUTL + lane);            // LDS byte address of the lane's slot in the row of its current bin
+    const unsigned lane8 = (unsigned)lane * 8u;     // SL is the A region (offset kLdsA)
+    // four steps of one code word: all LDS operands first (one LDS round trip per word), then the dependent part.
+    // Code = row * 4 (bits 2-6) | column * 4 (bits 9-13) | closed-a-bin (bit 15): the two masked fields ARE the byte
+    // offsets into the float32 weight table, and << 7 the row offset of an [index][lane] array -- 32-bit ops only.
     auto group = [&](unsigned long long word, int nst) {
         double g[4], wr[4];
-        const unsigned wlo = (unsigned)word, whi = (unsigned)(word >> 32);     // 32-bit decode: no 64-bit shifts / compares
+        const unsigned wlo = (unsigned)word, whi = (unsigned)(word >> 32);
         unsigned crs[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned code = ((k < 2 ? wlo : whi) >> (16 * (k & 1))) & 0xFFFFu;
+            const unsigned code = (k < 2 ? wlo : whi) >> (16 * (k & 1));
             crs[k] = code & 0x8000u;
-            const int row = code & 31, col = (code >> 5) & 31;
-            if constexpr (SORTED) wr[k] = pair_weight<W32>(DG, row, col);
-            else wr[k] = pair_weight<W32>(DG, PA[row * kWave + lane], PB[col * kWave + lane]);
-            g[k] = SL[(COL ? col : row) * kWave + lane];
+            const unsigned r4 = code & 0x7Cu, c4 = (code >> 7) & 0x7Cu;
+            if constexpr (SORTED) {
+                if constexpr (W32) wr[k] = (double)(lds_ldf(kLdsDGF + r4) * lds_ldf(kLdsDGF + c4));
+                else wr[k] = lds_ld(kLdsDG + 2 * r4) * lds_ld(kLdsDG + 2 * c4);
+            } else
+                wr[k] = pair_weight<W32>(DG, PA[(r4 >> 2) * kWave + lane], PB[(c4 >> 2) * kWave + lane]);
+            g[k] = lds_ld(kLdsA + (((COL ? c4 : r4) << 7) + lane8));
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < nst) {
                 const bool cross = crs[k] != 0;
-                const double w = wr[k];
-                OUTL[bo] = acc;
-                const double an = acc + g[k] * w;
+                lds_st(bo, acc);
+                const double an = acc + g[k] * wr[k];
                 acc = cross ? 0.0 : an;
-                bo += cross ? kWave : 0;
+                bo += cross ? kWave * 8u : 0u;
             }
         }
     };
@@ -890,12 +904,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     const int lane = threadIdx.x;
     const int G = p.G;
     const int NP1 = p.S + 1;
-    double *A = smem;
-    double *B = A + G * kWave;                   // G+1 rows
-    double *DG = B + (G + 1) * kWave;
+    // tables first: their LDS addresses are compile-time constants (dynamic LDS starts at 0), so a table read is
+    // `ds_read vaddr = index << k, offset:const` with no base add
+    double *DG = smem;                           // [kMaxG] doubles, then GORD [kMaxG + 2], then the float32 copy of DG
     double *GORD = DG + kMaxG;
-    unsigned char *PA = reinterpret_cast<unsigned char *>(GORD + kMaxG + 2) + kMaxG * sizeof(float);   // SORTED = false only
+    double *A = reinterpret_cast<double *>(reinterpret_cast<char *>(GORD + kMaxG + 2) + kMaxG * sizeof(float));
+    double *B = A + G * kWave;                   // G+1 rows
+    unsigned char *PA = reinterpret_cast<unsigned char *>(B + (G + 1) * kWave);   // SORTED = false only
     unsigned char *PB = PA + G * kWave;
+    if (lds_addr(smem) != 0) {                   // the replay addresses the tables and A by literal LDS offsets
+        if (lane == 0) atomicOr(p.err_flag, 2);
+        return;
+    }
     if (lane < G) {
         DG[lane] = p.del_g[lane];
         const_cast<float *>(delg_f32_table(DG))[lane] = (float)p.del_g[lane];
