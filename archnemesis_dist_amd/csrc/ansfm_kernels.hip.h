@@ -1003,12 +1003,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 WalkState ws = walk_begin(GORD, lane);
                 unsigned long long *pw = perm + lane;
                 int it = 0;
-                for (; it + 3 < nloop; it += 4) {
-                    const unsigned long long c0 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
-                    const unsigned long long c1 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
-                    const unsigned long long c2 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
-                    const unsigned long long c3 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
-                    *pw = c0 | (c1 << 16) | (c2 << 32) | (c3 << 48);
+                for (; it + 3 < nloop; it += 4) {   // four 16-bit codes per word, assembled as two 32-bit halves
+                    const unsigned c0 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    const unsigned c1 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    const unsigned c2 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    const unsigned c3 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    *reinterpret_cast<uint2 *>(pw) = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
                     pw += kWave;
                 }
                 if (it < nloop) {   // G*G not a multiple of 4: a partial last word
