@@ -636,16 +636,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                                 const double gd0 = rgd[k];
                                 const double gprev = (b == 0 && s1 == 0.0) ? wtot : gd0;
                                 const double gdn = gd0 + w;                 // the same add the walk made
-                                const double frac = (GORD[b + 1] - gprev) / (gdn - gprev);
+                                const double frac = fast_div(GORD[b + 1] - gprev, gdn - gprev);     // <= 1 ulp, as every division of the resolve
                                 const double kb = (ck + ka) + frac * cw;
                                 const double sb = (cs + s1) + frac * w;
-                                outv = kb / sb;
+                                outv = fast_div(kb, sb);
                                 ck = (1.0 - frac) * cw;
                                 cs = (1.0 - frac) * w;
                             } else if (b == ig) {
                                 // trailing `if ig == ng-1` (:6171); an unfinished earlier bin stays un-normalised
                                 const double kb = ck + ws.kacc, sb = cs + ws.sum1;
-                                outv = (b == G - 1) ? kb / sb : kb;
+                                outv = (b == G - 1) ? fast_div(kb, sb) : kb;
                             }
                             A[b * kWave + lane] = outv;
                         }
@@ -1041,16 +1041,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                                 const double ka = rka[k], s1 = rs1[k], w = rw[k], cw = rcw[k] * w, gd0 = rgd[k];   // rcw holds cv
                                 const double gprev = (b == 0 && s1 == 0.0) ? wtot : gd0;
                                 const double gdn = gd0 + w;
-                                fr = (GORD[b + 1] - gprev) / (gdn - gprev);
+                                fr = fast_div(GORD[b + 1] - gprev, gdn - gprev);
                                 const double kb = (ck + ka) + fr * cw;
                                 const double sb = (cs + s1) + fr * w;
-                                rinv = 1.0 / sb;
-                                outv = kb / sb;
+                                rinv = fast_div(1.0, sb);
+                                outv = fast_div(kb, sb);
                                 ck = (1.0 - fr) * cw;
                                 cs = (1.0 - fr) * w;
                             } else if (b == ig) {
                                 const double kb = ck + ws.kacc, sb = cs + ws.sum1;
-                                if (b == G - 1) { outv = kb / sb; rinv = 1.0 / sb; } else outv = kb;
+                                if (b == G - 1) { outv = fast_div(kb, sb); rinv = fast_div(1.0, sb); } else outv = kb;
                             }
                             double *rp = rec + (size_t)b * 6 * kWave + lane;
                             ASAVE[b * kWave + lane] = outv;
