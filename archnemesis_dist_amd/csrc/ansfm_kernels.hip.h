@@ -327,6 +327,16 @@ typedef __attribute__((address_space(3))) double lds_double;
 __device__ __forceinline__ unsigned lds_addr(const double *p) { return (unsigned)(size_t)(const lds_double *)p; }
 __device__ __forceinline__ double lds_ld(unsigned a) { return *(const lds_double *)(size_t)a; }
 __device__ __forceinline__ void lds_st(unsigned a, double v) { *(lds_double *)(size_t)a = v; }
+// Global access as wave-uniform base + 32-bit byte offset: the compiler emits `global_load/store v_off, s[base]` and the
+// per-access address arithmetic stays 32-bit (64-bit pointer adds are multi-pass VALU instructions).
+template <class T> __device__ __forceinline__ T gld(const void *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <class T> __device__ __forceinline__ void gst(void *base, unsigned byte_off, T v)
+{
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
 typedef __attribute__((address_space(3))) float lds_float;
 __device__ __forceinline__ float lds_ldf(unsigned a) { return *(const lds_float *)(size_t)a; }
 
@@ -767,7 +777,8 @@ __device__ __forceinline__ void stage_slice(double *dst_lds, const double *__res
     for (int g0 = 0; g0 < G; g0 += kStageBatch) {
         double r[kStageBatch];
 #pragma unroll
-        for (int k = 0; k < kStageBatch; ++k) r[k] = src[((g0 + k < G) ? g0 + k : G - 1) * kWave + lane];
+        for (int k = 0; k < kStageBatch; ++k)
+            r[k] = gld<double>(src, (unsigned)(((g0 + k < G) ? g0 + k : G - 1) * kWave + lane) * 8u);
 #pragma unroll
         for (int k = 0; k < kStageBatch; ++k)
             if (g0 + k < G) dst_lds[(g0 + k) * kWave + lane] = r[k];
@@ -830,16 +841,16 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
     // rotation (a move of the newest word would wait for its load) and no predicated loads (clamped index).
     constexpr int kPF = 4;
     unsigned long long q[kPF];
-    const unsigned long long *pl = perm + lane;
+    const unsigned lane8p = (unsigned)lane * 8u;
 #pragma unroll
-    for (int k = 0; k < kPF; ++k) q[k] = pl[(size_t)(k < ngrp ? k : ngrp - 1) * kWave];
+    for (int k = 0; k < kPF; ++k) q[k] = gld<unsigned long long>(perm, (unsigned)(k < ngrp ? k : ngrp - 1) * (kWave * 8u) + lane8p);
     int gidx = 0;
     for (; gidx + kPF <= nfull; gidx += kPF) {
 #pragma unroll
         for (int j = 0; j < kPF; ++j) {
             const unsigned long long word = q[j];
             const int nxt = gidx + j + kPF;
-            q[j] = pl[(size_t)(nxt < ngrp ? nxt : ngrp - 1) * kWave];
+            q[j] = gld<unsigned long long>(perm, (unsigned)(nxt < ngrp ? nxt : ngrp - 1) * (kWave * 8u) + lane8p);
             group(word, 4);
         }
     }
@@ -868,9 +879,10 @@ __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const doub
 #pragma unroll
         for (int k = 0; k < kRB; ++k) {
             const int bi = (b0 + k < G) ? b0 + k : G - 1;
-            const double *rp = rec + (size_t)bi * 6 * kWave + lane;
-            rfr[k] = rp[0]; rri[k] = rp[kWave]; rw[k] = rp[3 * kWave]; rcd[k] = rp[5 * kWave];
-            if constexpr (ACCUM) rold[k] = OUT[bi * kWave + lane];
+            const unsigned ro = (unsigned)(bi * 6 * kWave + lane) * 8u;
+            rfr[k] = gld<double>(rec, ro); rri[k] = gld<double>(rec, ro + kWave * 8u);
+            rw[k] = gld<double>(rec, ro + 3 * kWave * 8u); rcd[k] = gld<double>(rec, ro + 5 * kWave * 8u);
+            if constexpr (ACCUM) rold[k] = gld<double>(OUT, (unsigned)(bi * kWave + lane) * 8u);
         }
 #pragma unroll
         for (int k = 0; k < kRB; ++k) {
@@ -886,7 +898,7 @@ __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const doub
                 } else if (b == ig)
                     v = (carry + tail) * rri[k];
                 if constexpr (ACCUM) v += rold[k];
-                OUT[b * kWave + lane] = v;
+                gst<double>(OUT, (unsigned)(b * kWave + lane) * 8u, v);
             }
         }
     }
