@@ -337,6 +337,15 @@ template <class T> __device__ __forceinline__ void gst(void *base, unsigned byte
 {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
+// Bin records, per block [bin][2][lane] pairs of doubles: pair 0 = (kacc, sum1), pair 1 = (gd, code of the element that
+// closed the bin: row | column << 5), each pair one 16-byte store per lane, the lanes of a pair contiguous (1 KiB rows).
+// The stores sit in the merge loop's crossing branch, which runs in about every second step, and every store
+// instruction there costs ~6 % of the kernel (doubling five 8-byte stores: +29 %; 16-byte stores at a 48-byte lane
+// stride: no gain) -- so the closing element's value and weight are not stored, the resolve loop recomputes them from
+// LDS (same operations), and what is stored goes out as two wide stores.  The gradient kernel's resolve rewrites the
+// pairs as (frac, 1/weight-sum) and (weight, code) for its replay passes.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kRecRow = 64u * 16u, kRecBin = 2u * kRecRow;
 typedef __attribute__((address_space(3))) float lds_float;
 __device__ __forceinline__ float lds_ldf(unsigned a) { return *(const lds_float *)(size_t)a; }
 
@@ -393,7 +402,7 @@ __device__ __forceinline__ double pack_key11(double v, int row, int col)
 // sums in a different association.
 struct WalkState {
     double gd, kacc, sum1, gnext;
-    unsigned roff;      // byte offset of this lane's slot in the record of the bin being filled: (ig * 6 * 64 + lane) * 8
+    unsigned roff;      // byte offset of this lane's first pair in the record of the bin being filled: ig * kRecBin + lane * 16
     unsigned gaddr;     // LDS byte address of GORD[ig + 1]
 };
 __device__ __forceinline__ WalkState walk_begin(const double *GORD, int lane)
@@ -402,7 +411,7 @@ __device__ __forceinline__ WalkState walk_begin(const double *GORD, int lane)
     ws.gd = 0.0; ws.kacc = 0.0; ws.sum1 = 0.0;
     ws.gaddr = lds_addr(GORD + 1);
     ws.gnext = lds_ld(ws.gaddr);
-    ws.roff = (unsigned)lane * 8u;
+    ws.roff = (unsigned)lane * 16u;
     return ws;
 }
 // number of bins closed so far
@@ -420,16 +429,12 @@ __device__ __forceinline__ bool merge_walk(const MergeElem &e, WalkState &ws, do
     // that is going to be rerun on the generic path, NaN / inf input) -- the record index stays <= G
     const bool cross = (gdn >= ws.gnext);
     if (cross) {                                // this element straddles the bin boundary
-        // The branch runs in almost every step (some lane of the 64 crosses), so it is kept to stores and two adds: the
-        // record slot is a running 32-bit byte offset onto the wave-uniform base (no 64-bit index arithmetic), the
-        // element's value goes out unmultiplied (the resolve loop forms cv * w, the same product).
-        double *rp = reinterpret_cast<double *>(reinterpret_cast<char *>(rec) + ws.roff);
-        rp[0] = ws.kacc; rp[kWave] = ws.sum1; rp[2 * kWave] = cv; rp[3 * kWave] = w;
-        rp[4 * kWave] = ws.gd;
-        if constexpr (REC_CODE)   // gradient kernel: which element closed the bin
-            rp[5 * kWave] = __longlong_as_double((long long)(e.ci | ((e.np - 1) << 5)));
+        // The branch runs in about every second step (some lane of the 64 crosses), so it is kept to four stores and two
+        // adds: the record slot is a running 32-bit byte offset onto the wave-uniform base (no 64-bit index arithmetic).
+        gst<dbl2>(rec, ws.roff, dbl2{ws.kacc, ws.sum1});
+        gst<dbl2>(rec, ws.roff + kRecRow, dbl2{ws.gd, __longlong_as_double((long long)(e.ci | ((e.np - 1) << 5)))});
         kn = 0.0; sn = 0.0;
-        ws.roff += 6u * kWave * 8u;
+        ws.roff += kRecBin;
         ws.gaddr += 8u;
         ws.gnext = lds_ld(ws.gaddr);            // GORD[G+1] = NaN: nothing crosses after the last bin
     }
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     for (int g = 0; g < G; ++g) wsum += DG[g];
     const double wtot = wsum * wsum;  // stands in for gdist[-1] (python wrap at iloop==0)
 
-    // per-block scratch: closed-bin records [bin][6][lane]: kacc, sum1, cw, w, gd (slot 5 unused)
+    // per-block scratch: closed-bin records, see kRecBin
     double *rec = p.scratch + (size_t)blockIdx.x * 6 * G * kWave;
     TileQueue tq;
     tq.init();
@@ -623,17 +628,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 }
                 if (it < nloop) merge_step<NR, W32, false, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
                 // ---- resolve the bins --------------------------------------------------------------------
+                // The closing element of every bin is re-formed from LDS (a[row] + b[col], its weight) exactly as the
+                // walk formed it, so `a` must stay intact until the last bin is done: the outputs go to row 0 of the bin
+                // records (full-wave coalesced stores) and come back into A afterwards.
                 double ck = 0.0, cs = 0.0;   // (1-frac) share carried into the next bin
                 const int ig = walk_bins(ws, GORD);
                 constexpr int kRB = 5;       // records of kRB bins are fetched together (one round trip)
                 for (int b0 = 0; b0 < G; b0 += kRB) {
-                    double rka[kRB], rs1[kRB], rcw[kRB], rw[kRB], rgd[kRB];
+                    double rka[kRB], rs1[kRB], rgd[kRB];
+                    unsigned rcd[kRB];
 #pragma unroll
                     for (int k = 0; k < kRB; ++k) {
                         const int bi = (b0 + k < G) ? b0 + k : G - 1;
-                        const double *rp = rec + (size_t)bi * 6 * kWave + lane;
-                        rka[k] = rp[0]; rs1[k] = rp[kWave]; rcw[k] = rp[2 * kWave]; rw[k] = rp[3 * kWave];
-                        rgd[k] = rp[4 * kWave];
+                        const unsigned ro = (unsigned)bi * kRecBin + (unsigned)lane * 16u;
+                        const dbl2 v0 = gld<dbl2>(rec, ro), v1 = gld<dbl2>(rec, ro + kRecRow);
+                        rka[k] = v0.x; rs1[k] = v0.y; rgd[k] = v1.x; rcd[k] = (unsigned)__double_as_longlong(v1.y);
                     }
 #pragma unroll
                     for (int k = 0; k < kRB; ++k) {
@@ -641,7 +650,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                         if (b < G) {
                             double outv = 0.0;
                             if (b < ig) {
-                                const double ka = rka[k], s1 = rs1[k], w = rw[k], cw = rcw[k] * w;   // rcw holds cv
+                                const int crow = rcd[k] & 31, ccol = (rcd[k] >> 5) & 63;
+                                const double cv = A[crow * kWave + lane] + B[ccol * kWave + lane];
+                                double w;
+                                if constexpr (SORTED) w = pair_weight<W32>(DG, crow, ccol);
+                                else w = pair_weight<W32>(DG, PA[crow * kWave + lane], PB[ccol * kWave + lane]);
+                                const double ka = rka[k], s1 = rs1[k], cw = cv * w;
                                 // a crossing at the very first element (nothing accumulated yet) sees python's gdist[-1]
                                 const double gd0 = rgd[k];
                                 const double gprev = (b == 0 && s1 == 0.0) ? wtot : gd0;
@@ -657,9 +671,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                                 const double kb = ck + ws.kacc, sb = cs + ws.sum1;
                                 outv = (b == G - 1) ? fast_div(kb, sb) : kb;
                             }
-                            A[b * kWave + lane] = outv;
+                            gst<double>(rec, (unsigned)b * kRecBin + (unsigned)lane * 16u, outv);
                         }
                     }
+                }
+                for (int g0 = 0; g0 < G; g0 += kLoadBatch) {          // merged spectrum: records' row 0 -> A
+                    double r[kLoadBatch];
+#pragma unroll
+                    for (int k = 0; k < kLoadBatch; ++k)
+                        r[k] = gld<double>(rec, (unsigned)((g0 + k < G) ? g0 + k : G - 1) * kRecBin + (unsigned)lane * 16u);
+#pragma unroll
+                    for (int k = 0; k < kLoadBatch; ++k)
+                        if (g0 + k < G) A[(g0 + k) * kWave + lane] = r[k];
                 }
                 if constexpr (!SORTED) {   // the merged spectrum is ascending with the plain del_g weights
                     for (int g = 0; g < G; ++g) PA[g * kWave + lane] = (unsigned char)g;
@@ -865,7 +888,7 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
     return acc;
 }
 
-// deferred bin boundaries of one replayed vector: rec[b] = (frac, 1/weight-sum, -, w, -, code) from the merge
+// deferred bin boundaries of one replayed vector: the record pairs of bin b = (frac, 1/weight-sum), (weight, code)
 // ACCUM: the column part of the temperature slot is added to the row part already in OUT.
 template <bool COL, bool ACCUM>
 __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const double *__restrict__ rec,
@@ -875,13 +898,14 @@ __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const doub
     double carry = 0.0;
     constexpr int kRB = 10;     // two memory round trips per pass for G = 20
     for (int b0 = 0; b0 < G; b0 += kRB) {
-        double rfr[kRB], rri[kRB], rw[kRB], rcd[kRB], rold[kRB];
+        double rfr[kRB], rri[kRB], rw[kRB], rold[kRB];
+        unsigned rcd[kRB];
 #pragma unroll
         for (int k = 0; k < kRB; ++k) {
             const int bi = (b0 + k < G) ? b0 + k : G - 1;
-            const unsigned ro = (unsigned)(bi * 6 * kWave + lane) * 8u;
-            rfr[k] = gld<double>(rec, ro); rri[k] = gld<double>(rec, ro + kWave * 8u);
-            rw[k] = gld<double>(rec, ro + 3 * kWave * 8u); rcd[k] = gld<double>(rec, ro + 5 * kWave * 8u);
+            const unsigned ro = (unsigned)bi * kRecBin + (unsigned)lane * 16u;
+            const dbl2 v0 = gld<dbl2>(rec, ro), v1 = gld<dbl2>(rec, ro + kRecRow);
+            rfr[k] = v0.x; rri[k] = v0.y; rw[k] = v1.x; rcd[k] = (unsigned)__double_as_longlong(v1.y);
             if constexpr (ACCUM) rold[k] = gld<double>(OUT, (unsigned)(bi * kWave + lane) * 8u);
         }
 #pragma unroll
@@ -890,7 +914,7 @@ __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const doub
             if (b < G) {
                 double v = 0.0;
                 if (b < ig) {
-                    const unsigned code = (unsigned)__double_as_longlong(rcd[k]);
+                    const unsigned code = rcd[k];
                     const double g = SL[(COL ? ((code >> 5) & 31) : (code & 31)) * kWave + lane];
                     const double gw = g * rw[k];
                     v = ((carry + OUTL[b * kWave + lane]) + rfr[k] * gw) * rri[k];
@@ -1032,25 +1056,32 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                     }
                     *pw = word;
                 }
-                // ---- resolve the bins: merged k -> ASAVE, (frac, 1/sum) -> rec ------------------------------
+                // ---- resolve the bins: merged k -> ASAVE, (frac, 1/sum, weight) -> rec rows 0-2 -------------------
                 double ck = 0.0, cs = 0.0;
                 const int ig = walk_bins(ws, GORD);
                 constexpr int kRB = 5;
                 for (int b0 = 0; b0 < G; b0 += kRB) {
-                    double rka[kRB], rs1[kRB], rcw[kRB], rw[kRB], rgd[kRB];
+                    double rka[kRB], rs1[kRB], rgd[kRB];
+                    unsigned rcd[kRB];
 #pragma unroll
                     for (int k = 0; k < kRB; ++k) {
-                        const double *rp = rec + (size_t)((b0 + k < G) ? b0 + k : G - 1) * 6 * kWave + lane;
-                        rka[k] = rp[0]; rs1[k] = rp[kWave]; rcw[k] = rp[2 * kWave]; rw[k] = rp[3 * kWave];
-                        rgd[k] = rp[4 * kWave];
+                        const int bi = (b0 + k < G) ? b0 + k : G - 1;
+                        const unsigned ro = (unsigned)bi * kRecBin + (unsigned)lane * 16u;
+                        const dbl2 v0 = gld<dbl2>(rec, ro), v1 = gld<dbl2>(rec, ro + kRecRow);
+                        rka[k] = v0.x; rs1[k] = v0.y; rgd[k] = v1.x; rcd[k] = (unsigned)__double_as_longlong(v1.y);
                     }
 #pragma unroll
                     for (int k = 0; k < kRB; ++k) {
                         const int b = b0 + k;
                         if (b < G) {
-                            double outv = 0.0, fr = 0.0, rinv = 1.0;
+                            double outv = 0.0, fr = 0.0, rinv = 1.0, w = 0.0;
                             if (b < ig) {
-                                const double ka = rka[k], s1 = rs1[k], w = rw[k], cw = rcw[k] * w, gd0 = rgd[k];   // rcw holds cv
+                                // the closing element, re-formed from LDS as the walk formed it
+                                const int crow = rcd[k] & 31, ccol = (rcd[k] >> 5) & 63;
+                                const double cv = A[crow * kWave + lane] + B[ccol * kWave + lane];
+                                if constexpr (SORTED) w = pair_weight<W32>(DG, crow, ccol);
+                                else w = pair_weight<W32>(DG, PA[crow * kWave + lane], PB[ccol * kWave + lane]);
+                                const double ka = rka[k], s1 = rs1[k], cw = cv * w, gd0 = rgd[k];
                                 const double gprev = (b == 0 && s1 == 0.0) ? wtot : gd0;
                                 const double gdn = gd0 + w;
                                 fr = fast_div(GORD[b + 1] - gprev, gdn - gprev);
@@ -1064,9 +1095,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                                 const double kb = ck + ws.kacc, sb = cs + ws.sum1;
                                 if (b == G - 1) { outv = fast_div(kb, sb); rinv = fast_div(1.0, sb); } else outv = kb;
                             }
-                            double *rp = rec + (size_t)b * 6 * kWave + lane;
+                            const unsigned ro = (unsigned)b * kRecBin + (unsigned)lane * 16u;
                             ASAVE[b * kWave + lane] = outv;
-                            rp[0] = fr; rp[kWave] = rinv;
+                            gst<dbl2>(rec, ro, dbl2{fr, rinv});
+                            gst<double>(rec, ro + kRecRow, w);          // pair 1 = (weight, code): the code stays
                         }
                     }
                 }
