@@ -540,7 +540,8 @@ static int lbl_prep_fwd(ansfm_ctx *ctx, int n_layers, const double *lay_press, c
 
 static int launch_rt(ansfm_ctx *ctx, const RtParams &p, int n_models)
 {
-    dim3 grid((unsigned)(p.Wpad / kWave), (unsigned)p.P, (unsigned)n_models);
+    dim3 grid((unsigned)n_models, (unsigned)p.P, (unsigned)(p.Wpad / kWave));
+    if (p.Wpad / kWave > 65535) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: more than 65535 wavenumber tiles (4.19e6 wavenumbers)");
     if (p.LIMAX > 1500) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: at most 1500 layers along a path");
     hipLaunchKernelGGL(k_thermal_rt, grid, dim3(kWave, kGY), (size_t)4 * p.LIMAX * sizeof(double), ctx->stream, p);
     HIPCHK(hipGetLastError());
@@ -1099,7 +1100,8 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
     q.slot_of_param[NVMR] = (signed char)S;   // :3872 (written last)
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     {
-        dim3 grid((unsigned)(Wpad / kWave), (unsigned)P, (unsigned)n_models);
+        dim3 grid((unsigned)n_models, (unsigned)P, (unsigned)(Wpad / kWave));
+        if (Wpad / kWave > 65535) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: more than 65535 wavenumber tiles (4.19e6 wavenumbers)");
         // reduction buffer [NP1+2][GY][64] doubles: the largest GY that leaves room for one block per CU
         const size_t per_gy = (size_t)(NP1 + 2) * kWave * sizeof(double);
         if (16 * per_gy <= 128 * 1024)

@@ -1426,9 +1426,11 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
 {
     __shared__ double red[kGY][kWave];
     const int lane = threadIdx.x, gy = threadIdx.y;
-    const int nu = blockIdx.x * kWave + lane;
+    // grid = (models, paths, wavenumber tiles): the models of a batch that share opacity rows (de-duplicated Jacobian
+    // states) run next to each other on a wavenumber tile, so the rows are re-read out of L2 instead of HBM
+    const int nu = blockIdx.z * kWave + lane;
     const int nuc = nu < p.W ? nu : p.W - 1;
-    const int ip = blockIdx.y, m = blockIdx.z;
+    const int ip = blockIdx.y, m = blockIdx.x;
     const int nl = p.nlayin[ip];
     const int G = p.G;
     const double c1 = 1.1911e-12, c2 = 1.439;  // ForwardModel_0.py:6214-6215
@@ -1593,9 +1595,11 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
     const RtParams &p = q.r;
     extern __shared__ double red[];  // [NP1+2][GY][kWave]
     const int lane = threadIdx.x, gy = threadIdx.y;
-    const int nu = blockIdx.x * kWave + lane;
+    // grid = (models, paths, wavenumber tiles): the models of a batch that share opacity rows (de-duplicated Jacobian
+    // states) run next to each other on a wavenumber tile, so the rows are re-read out of L2 instead of HBM
+    const int nu = blockIdx.z * kWave + lane;
     const int nuc = nu < p.W ? nu : p.W - 1;
-    const int ip = blockIdx.y, m = blockIdx.z;
+    const int ip = blockIdx.y, m = blockIdx.x;
     const int nl = p.nlayin[ip];
     const int G = p.G, NP1 = q.NP1, NR = NP1 + 2;
     const double wv = p.wave[nuc];
