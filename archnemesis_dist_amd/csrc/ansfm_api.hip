@@ -623,11 +623,8 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
     const double *cont_t = nullptr;
     if (taucont) {
         HIPCHK(ctx->cont_t.reserve((size_t)n_models * L * Wpad * sizeof(double)));
-        for (int m = 0; m < n_models; ++m) {
-            hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256)), dim3(256), 0, ctx->stream,
-                               taucont + (size_t)m * W * L, ctx->cont_t.as<double>() + (size_t)m * L * Wpad, W,
-                               Wpad, 1, L, 0, 0.0);
-        }
+        hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256), (unsigned)n_models), dim3(256), 0, ctx->stream,
+                           taucont, ctx->cont_t.as<double>(), W, Wpad, 1, L, 0, 0.0, (size_t)W * L, (size_t)L * Wpad);
         HIPCHK(hipGetLastError());
         cont_t = ctx->cont_t.as<double>();
     }
@@ -1045,18 +1042,15 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
     const double *cont_t = nullptr, *dcont_t = nullptr;
     if (taucont) {
         HIPCHK(ctx->cont_t.reserve((size_t)n_models * L * Wpad * sizeof(double)));
-        for (int m = 0; m < n_models; ++m)
-            hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256)), dim3(256), 0, ctx->stream,
-                               taucont + (size_t)m * W * L, ctx->cont_t.as<double>() + (size_t)m * L * Wpad, W, Wpad, 1, L,
-                               0, 0.0);
+        hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256), (unsigned)n_models), dim3(256), 0, ctx->stream,
+                           taucont, ctx->cont_t.as<double>(), W, Wpad, 1, L, 0, 0.0, (size_t)W * L, (size_t)L * Wpad);
         cont_t = ctx->cont_t.as<double>();
     }
     if (dtaucon) {
         HIPCHK(ctx->dcont_t.reserve((size_t)n_models * NPAR * L * Wpad * sizeof(double)));
-        for (int m = 0; m < n_models; ++m)
-            hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)NPAR * L * Wpad, 256)), dim3(256), 0, ctx->stream,
-                               dtaucon + (size_t)m * W * NPAR * L, ctx->dcont_t.as<double>() + (size_t)m * NPAR * L * Wpad,
-                               W, Wpad, NPAR, L, 0, 0.0);
+        hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)NPAR * L * Wpad, 256), (unsigned)n_models), dim3(256), 0, ctx->stream,
+                           dtaucon, ctx->dcont_t.as<double>(), W, Wpad, NPAR, L, 0, 0.0, (size_t)W * NPAR * L,
+                           (size_t)NPAR * L * Wpad);
         dcont_t = ctx->dcont_t.as<double>();
     }
     HIPCHK(hipGetLastError());

@@ -1760,12 +1760,15 @@ __global__ void k_dspec_to_ref(const double *__restrict__ src, double *__restric
 // ------------------------------------------------------------------------------------------------
 // layout helpers (host-pointer seams): src[W][X1][X2] -> dst[(x1,x2 or x2,x1)][Wpad]
 // ------------------------------------------------------------------------------------------------
+// blockIdx.y = model of a batch (src_stride / dst_stride elements apart; 0 for a single array)
 __global__ void k_w_to_last(const double *__restrict__ src, double *__restrict__ dst, int W, int Wpad,
-                            int X1, int X2, int swap12, double padval)
+                            int X1, int X2, int swap12, double padval, size_t src_stride = 0, size_t dst_stride = 0)
 {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t total = (size_t)X1 * X2 * Wpad;
     if (idx >= total) return;
+    src += (size_t)blockIdx.y * src_stride;
+    dst += (size_t)blockIdx.y * dst_stride;
     int w = (int)(idx % Wpad);
     size_t r = idx / Wpad;
     int x1, x2;
