@@ -1967,7 +1967,7 @@ int ansfm_add_line_set_monochromatic_absorption(
     p.max_shift = dmax * pmax * 1.0000001 + 1e-12;
     hipLaunchKernelGGL(k_lbl_line_params, dim3(nblk((size_t)L * N, 256)), dim3(256), 0, ctx->stream, p);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_lbl_accumulate, dim3(nblk(nw, 256), (unsigned)L), dim3(256), 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_lbl_accumulate, dim3(nblk(nw, 256 * kLblPts), (unsigned)L), dim3(256), 0, ctx->stream, p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, p.out, (size_t)L * nw * D, hipMemcpyDeviceToHost, ctx->stream));
     std::vector<double> hst;

@@ -162,15 +162,24 @@ __global__ void k_lbl_line_params(LblParams p)
     st[7 * (size_t)p.N + i] = nrm;
 }
 
+// kLblPts grid points per thread (256 apart, so a wave's loads and stores stay coalesced): the per-line work that does not
+// depend on the grid point -- scalar loads of the line's constants, the strength test, the loop itself -- is paid once
+// per kLblPts evaluations instead of once per evaluation.
+constexpr int kLblPts = 4;
+
 __global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
 {
     const int l = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int jc = j < p.nw ? j : p.nw - 1;
-    const double wn = p.wn_grid[jc];
+    const int j0 = blockIdx.x * (256 * kLblPts);
+    const int j1 = min(j0 + 256 * kLblPts - 1, p.nw - 1);
+    double wn[kLblPts], acc[kLblPts];
+#pragma unroll
+    for (int k = 0; k < kLblPts; ++k) {
+        const int j = j0 + k * 256 + (int)threadIdx.x;
+        wn[k] = p.wn_grid[j < p.nw ? j : p.nw - 1];
+        acc[k] = (j < p.nw) ? p.out[(size_t)l * p.nw + j] : 0.0;
+    }
     // line range shared by the block: every line that can reach any of its grid points
-    const int j0 = blockIdx.x * blockDim.x;
-    const int j1 = min(j0 + (int)blockDim.x - 1, p.nw - 1);
     const double lo_wn = p.wn_grid[j0] - p.wn_approx_window - p.max_shift;
     const double hi_wn = p.wn_grid[j1] + p.wn_approx_window + p.max_shift;
     int a = 0, b = p.N;
@@ -182,22 +191,30 @@ __global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
     const double *st = p.store + (size_t)l * kLblRows * p.N;
     const double cmin = -1 * p.wn_calc_window, cmax = p.wn_calc_window;
     const double amin = -1 * p.wn_approx_window, amax = p.wn_approx_window;
-    double acc = (j < p.nw) ? p.out[(size_t)l * p.nw + j] : 0.0;
     for (int i = ilo; i < ihi; ++i) {
         const double strength = st[i];
         if (strength < p.s_floor) continue;                                     // :258
-        const double wn_delta = wn - (p.nu[i] + st[3 * (size_t)p.N + i]);       // :264
-        if (wn_delta >= amax || wn_delta < amin) continue;                      // :266-269
-        if (cmin <= wn_delta && wn_delta < cmax) {
-            const double xs = st[5 * (size_t)p.N + i];
-            const double shape = (xs != 0.0) ? lbl_rew(wn_delta * xs, st[6 * (size_t)p.N + i]) * st[7 * (size_t)p.N + i]
-                                             : lbl_lineshape(p.lineshape_id, wn_delta, st[p.N + i], st[2 * (size_t)p.N + i]);
-            acc += p.iso_abundance * strength * shape;
+        const double centre = p.nu[i] + st[3 * (size_t)p.N + i];               // :264
+        const double wing = st[4 * (size_t)p.N + i];
+        const double xs = st[5 * (size_t)p.N + i], yv = st[6 * (size_t)p.N + i], nrm = st[7 * (size_t)p.N + i];
+        const double amp = p.iso_abundance * strength;
+#pragma unroll
+        for (int k = 0; k < kLblPts; ++k) {
+            const double wn_delta = wn[k] - centre;
+            if (wn_delta >= amax || wn_delta < amin) continue;                  // :266-269
+            if (cmin <= wn_delta && wn_delta < cmax) {
+                const double shape = (xs != 0.0) ? lbl_rew(wn_delta * xs, yv) * nrm
+                                                 : lbl_lineshape(p.lineshape_id, wn_delta, st[p.N + i], st[2 * (size_t)p.N + i]);
+                acc[k] += amp * shape;
+            } else
+                acc[k] += fast_div(wing, wn_delta * wn_delta);                  // <= 1 ulp
         }
-        else
-            acc += fast_div(st[4 * (size_t)p.N + i], wn_delta * wn_delta);   // <= 1 ulp
     }
-    if (j < p.nw) p.out[(size_t)l * p.nw + j] = acc;
+#pragma unroll
+    for (int k = 0; k < kLblPts; ++k) {
+        const int j = j0 + k * 256 + (int)threadIdx.x;
+        if (j < p.nw) p.out[(size_t)l * p.nw + j] = acc[k];
+    }
 }
 
 }  // namespace ansfm
