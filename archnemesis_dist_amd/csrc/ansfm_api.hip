@@ -1979,7 +1979,7 @@ int ansfm_add_line_set_monochromatic_absorption(
     if (store)   // store[L][4][N] in the caller's line order
         for (int l = 0; l < L; ++l)
             for (int r = 0; r < 4; ++r)
-                for (int i = 0; i < N; ++i) store[((size_t)l * 4 + r) * N + ord[i]] = hst[((size_t)l * kLblRows + r) * N + i];
+                for (int i = 0; i < N; ++i) store[((size_t)l * 4 + r) * N + ord[i]] = hst[((size_t)l * N + i) * kLblRows + r];
     return ANSFM_OK;
 }
 

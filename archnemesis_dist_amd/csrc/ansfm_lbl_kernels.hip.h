@@ -21,7 +21,7 @@ namespace ansfm {
 __device__ const double kLblE0[28] = {5.242885663363464e-22, 4.4777324417183015e-19, 2.319522830243569e-16, 7.287724095819692e-14, 1.3887943864964021e-11, 1.6052280551856116e-09, 1.1253517471925912e-07, 4.785117392129009e-06, 0.00012340980408667956, 0.0019304541362277093, 0.01831563888873418, 0.10539922456186433, 0.36787944117144233, 0.7788007830714049, 1.0, 0.7788007830714049, 0.36787944117144233, 0.10539922456186433, 0.01831563888873418, 0.0019304541362277093, 0.00012340980408667956, 4.785117392129009e-06, 1.1253517471925912e-07, 1.6052280551856116e-09, 1.3887943864964021e-11, 7.287724095819692e-14, 2.319522830243569e-16, 4.4777324417183015e-19};
 __device__ const double kLblE1[28] = {1.6310139226701858e-20, 1.0848552640429378e-17, 4.37661850287085e-15, 1.0709232382508077e-12, 1.5893910094516368e-10, 1.4307241918567688e-08, 7.811489408304491e-07, 2.586810022265412e-05, 0.0005195746821548384, 0.006329715427485747, 0.04677062238395898, 0.2096113871510978, 0.569782824730923, 0.9394130628134758, 0.9394130628134758, 0.569782824730923, 0.2096113871510978, 0.04677062238395898, 0.006329715427485747, 0.0005195746821548384, 2.586810022265412e-05, 7.811489408304491e-07, 1.4307241918567688e-08, 1.5893910094516368e-10, 1.0709232382508077e-12, 4.37661850287085e-15, 1.0848552640429378e-17, 1.6310139226701858e-20};
 
-constexpr int kLblRows = 8;   // rows of the per-(layer, line) store, see LblParams::store
+constexpr int kLblRows = 8;   // constants per (layer, line) in the store, see LblParams::store
 
 // n / d by v_rcp_f64 + two Newton steps + a residual correction (<= 1 ulp): the profile's divisions need no more
 __device__ __forceinline__ double lbl_div(double n, double d)
@@ -108,7 +108,7 @@ struct LblParams {
     const double *bparams;  // [3M][N]
     const double *mmf;      // [M]
     const double *t_calc, *p_calc, *q_ratio;  // [L]
-    double *store;          // [L][kLblRows][N]: strength, alpha_d, gamma_l, shift, wing numerator (iso * strength *
+    double *store;          // [L][N][kLblRows]: strength, alpha_d, gamma_l, shift, wing numerator (iso * strength *
                             // line_approx_const * cmax^2), then the Voigt constants of the line: 1/(sigma sqrt 2), y = gamma/(sigma
                             // sqrt 2), 1/(sigma sqrt(2 pi))   (row 5 = 0: the line takes the general lineshape function)
     double *out;            // [L][nw]  (added to)
@@ -137,13 +137,13 @@ __global__ void k_lbl_line_params(LblParams p)
         g += (pow(t_ratio, p.bparams[(size_t)(3 * j + 1) * p.N + i])) * p.bparams[(size_t)(3 * j) * p.N + i] * p.mmf[j] * p_ratio;
         sh += (p_ratio * p.bparams[(size_t)(3 * j + 2) * p.N + i]) * p.mmf[j];
     }
-    double *st = p.store + (size_t)l * kLblRows * p.N;
-    st[i] = strength;
-    st[p.N + i] = alpha_d;
-    st[2 * (size_t)p.N + i] = g;
-    st[3 * (size_t)p.N + i] = sh;
+    double *st = p.store + ((size_t)l * p.N + i) * kLblRows;      // one line's constants are contiguous (64 bytes)
+    st[0] = strength;
+    st[1] = alpha_d;
+    st[2] = g;
+    st[3] = sh;
     // row 4: the whole numerator of the wing term (:270), same association as the reference's expression
-    st[4 * (size_t)p.N + i] = p.iso_abundance * strength * lbl_lineshape(p.lineshape_id, p.wn_calc_window, alpha_d, g) *
+    st[4] = p.iso_abundance * strength * lbl_lineshape(p.lineshape_id, p.wn_calc_window, alpha_d, g) *
                               (p.wn_calc_window * p.wn_calc_window);
     // Voigt: scipy's voigt_profile(x, sigma, gamma) = Re w((x + i gamma) / (sigma sqrt 2)) / (sigma sqrt(2 pi)) -- the
     // three per-line factors once per (layer, line) instead of three divisions per grid point
@@ -157,9 +157,9 @@ __global__ void k_lbl_line_params(LblParams p)
             nrm = 1.0 / sigma / sqrt(2.0 * 3.141592653589793);
         }
     }
-    st[5 * (size_t)p.N + i] = xs;
-    st[6 * (size_t)p.N + i] = yv;
-    st[7 * (size_t)p.N + i] = nrm;
+    st[5] = xs;
+    st[6] = yv;
+    st[7] = nrm;
 }
 
 // kLblPts grid points per thread (256 apart, so a wave's loads and stores stay coalesced): the per-line work that does not
@@ -188,15 +188,16 @@ __global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
     b = p.N;
     while (a < b) { int mid = (a + b) >> 1; if (p.nu[mid] <= hi_wn) a = mid + 1; else b = mid; }
     const int ihi = a;
-    const double *st = p.store + (size_t)l * kLblRows * p.N;
+    const double *stl = p.store + (size_t)l * p.N * kLblRows;
     const double cmin = -1 * p.wn_calc_window, cmax = p.wn_calc_window;
     const double amin = -1 * p.wn_approx_window, amax = p.wn_approx_window;
     for (int i = ilo; i < ihi; ++i) {
-        const double strength = st[i];
+        const double *st = stl + (size_t)i * kLblRows;                          // 64 contiguous bytes: one scalar load
+        const double strength = st[0];
         if (strength < p.s_floor) continue;                                     // :258
-        const double centre = p.nu[i] + st[3 * (size_t)p.N + i];               // :264
-        const double wing = st[4 * (size_t)p.N + i];
-        const double xs = st[5 * (size_t)p.N + i], yv = st[6 * (size_t)p.N + i], nrm = st[7 * (size_t)p.N + i];
+        const double centre = p.nu[i] + st[3];                                  // :264
+        const double wing = st[4];
+        const double xs = st[5], yv = st[6], nrm = st[7];
         const double amp = p.iso_abundance * strength;
 #pragma unroll
         for (int k = 0; k < kLblPts; ++k) {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
             if (wn_delta >= amax || wn_delta < amin) continue;                  // :266-269
             if (cmin <= wn_delta && wn_delta < cmax) {
                 const double shape = (xs != 0.0) ? lbl_rew(wn_delta * xs, yv) * nrm
-                                                 : lbl_lineshape(p.lineshape_id, wn_delta, st[p.N + i], st[2 * (size_t)p.N + i]);
+                                                 : lbl_lineshape(p.lineshape_id, wn_delta, st[1], st[2]);
                 acc[k] += amp * shape;
             } else
                 acc[k] += fast_div(wing, wn_delta * wn_delta);                  // <= 1 ulp
