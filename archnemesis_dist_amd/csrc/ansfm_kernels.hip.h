@@ -312,7 +312,9 @@ __device__ __forceinline__ void load_gas(const OverlapParams &p, const LayerInte
 }
 
 __device__ __forceinline__ double fast_div(double n, double d)
-{   // n/d with v_rcp_f64 + 2 Newton steps + residual correction (<= ~1 ulp; frac of rank())
+{   // n/d with v_rcp_f64 + 2 Newton steps + residual correction (<= ~1 ulp; frac of rank()).  One Newton step gives the
+    // same quotients (tools/calib/div_check.hip) but k_ck_overlap measured 1.2 % SLOWER with it (5.88 -> 5.95 ms, same box,
+    // twice): the second step's two instructions fill issue slots the resolve otherwise leaves empty
     double r = __builtin_amdgcn_rcp(d);
     r = fma(fma(-d, r, 1.0), r, r);
     r = fma(fma(-d, r, 1.0), r, r);
