@@ -88,6 +88,11 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # launched by torch.distributed.run
     if use_dist:
         dist.init_process_group(backend="nccl", device_id=dev)
+    if not os.path.exists(pkg.LIB_PATH):        # source-only checkout: one rank compiles the library, the others wait for it
+        if local_rank == 0:
+            pkg.build()
+        if use_dist:
+            dist.barrier()
 
     W, G, S, L, NP, NT, P = args.waves, args.ng, args.gases, args.layers, 20, 15, 1
     f8 = torch.float64

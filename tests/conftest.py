@@ -24,3 +24,12 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _library_present():
+    """A source-only checkout has no lib/libansfm.so yet: compile it once (hipcc cross-compiles without a GPU).  An
+    existing library is left alone -- a snapshot copy does not keep modification times."""
+    import archnemesis_dist_amd as pkg
+    if not os.path.exists(pkg.LIB_PATH):
+        pkg.build()
