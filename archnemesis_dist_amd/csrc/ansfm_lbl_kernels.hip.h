@@ -34,6 +34,43 @@ __device__ __forceinline__ double lbl_div(double n, double d)
     return fma(fma(-d, q, n), r, q);
 }
 
+// |z| < 8: exponentially convergent trapezoid / midpoint rule with pole correction (x >= 0).
+// A function of its own, NOT inlined, and its node loop only unrolled twice: few evaluations come here (points within 8
+// widths of a line centre), but inlined into the four-point body of k_lbl_accumulate it (a) raised the kernel to 159
+// VGPRs = 3 waves per SIMD and (b) let the compiler move e^{2 pi y / h}, which depends on the line only, ahead of the window
+// tests: ~35 instructions per (line, thread) that almost no point used (4.49e11 -> 3.62e11 VALU instructions on C5).
+__device__ __attribute__((noinline)) double lbl_rew_near(double x, double y)
+{
+    const double PI = 3.141592653589793;
+    const double h = 0.5;
+    const double fr = x / h - floor(x / h);
+    const bool use_mid = (fr < 0.25) || (fr > 0.75);
+    const double shift = use_mid ? 0.25 : 0.0;
+    const double yy = y * y;
+    double s = 0.0;
+#pragma unroll 2
+    for (int k = 0; k < 28; k += 2) {          // two nodes per division: e1/d1 + e2/d2 = (e1 d2 + e2 d1)/(d1 d2)
+        const double t1 = (k - 14) * h + shift, t2 = (k - 13) * h + shift;
+        const double e1 = use_mid ? kLblE1[k] : kLblE0[k], e2 = use_mid ? kLblE1[k + 1] : kLblE0[k + 1];
+        const double d1 = (x - t1) * (x - t1) + yy, d2 = (x - t2) * (x - t2) + yy;
+        s += lbl_div(e1 * d2 + e2 * d1, d1 * d2);
+    }
+    s *= y;
+    s *= h / PI;
+    if (y < PI / h) {
+        const double er = exp(-(x * x - y * y)), ang = -2.0 * x * y;
+        double sa, ca, s2, c2;
+        sincos(ang, &sa, &ca);
+        const double nr = 2.0 * er * ca, ni = 2.0 * er * sa;
+        const double em = exp(2.0 * PI * y / h);
+        sincos(-2.0 * PI * x / h, &s2, &c2);
+        const double sg = use_mid ? -1.0 : 1.0;
+        const double dr = 1.0 - sg * em * c2, di = -sg * em * s2;
+        s += (nr * dr + ni * di) / (dr * dr + di * di);
+    }
+    return s;
+}
+
 __device__ __forceinline__ double lbl_rew(double x, double y)
 {
     const double PI = 3.141592653589793;
@@ -53,38 +90,7 @@ __device__ __forceinline__ double lbl_rew(double x, double y)
         const double dr = x - rr, di = y - ri;
         return lbl_div(di, 1.7724538509055159 * (dr * dr + di * di));
     }
-    const double h = 0.5;
-    const double fr = x / h - floor(x / h);
-    const bool use_mid = (fr < 0.25) || (fr > 0.75);
-    const double shift = use_mid ? 0.25 : 0.0;
-    const double yy = y * y;
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 28; k += 2) {          // two nodes per division: e1/d1 + e2/d2 = (e1 d2 + e2 d1)/(d1 d2)
-        const double t1 = (k - 14) * h + shift, t2 = (k - 13) * h + shift;
-        const double e1 = use_mid ? kLblE1[k] : kLblE0[k], e2 = use_mid ? kLblE1[k + 1] : kLblE0[k + 1];
-        const double d1 = (x - t1) * (x - t1) + yy, d2 = (x - t2) * (x - t2) + yy;
-        s += lbl_div(e1 * d2 + e2 * d1, d1 * d2);
-    }
-    s *= y;
-    s *= h / PI;
-    if (y < PI / h) {
-        const double er = exp(-(x * x - y * y)), ang = -2.0 * x * y;
-        double sa, ca, s2, c2;
-        sincos(ang, &sa, &ca);
-        const double nr = 2.0 * er * ca, ni = 2.0 * er * sa;
-        // y is the same for every grid point of a line: without the barrier the compiler computes this exponential once
-        // per (line, thread) AHEAD of the window tests, ~35 instructions that all but the few points within 8 widths of
-        // the line centre never use
-        double yb = y;
-        asm("" : "+v"(yb) : "v"(x));     // not volatile: a volatile asm counts as a memory write and turns the scalar loads of the line constants into vector loads
-        const double em = exp(2.0 * PI * yb / h);
-        sincos(-2.0 * PI * x / h, &s2, &c2);
-        const double sg = use_mid ? -1.0 : 1.0;
-        const double dr = 1.0 - sg * em * c2, di = -sg * em * s2;
-        s += (nr * dr + ni * di) / (dr * dr + di * di);
-    }
-    return s;
+    return lbl_rew_near(x, y);
 }
 
 __device__ __forceinline__ double lbl_voigt_profile(double x, double sigma, double gamma)
@@ -173,7 +179,12 @@ __global__ void k_lbl_line_params(LblParams p)
 // per kLblPts evaluations instead of once per evaluation.
 constexpr int kLblPts = 4;
 
-__global__ __launch_bounds__(256) void k_lbl_accumulate(LblParams p)
+// Seven waves per SIMD (72 VGPRs): the scalar loads of each line's constants are a round trip per line that only other
+// waves can cover.  What is spilled (128 bytes) are polynomial coefficients of exp() in the Doppler / general-lineshape
+// branches, not the Voigt wing path.  C5 wall time on one box: near-centre branch inlined, 3 waves 0.847 s, 4 waves
+// 0.746, 5 waves 0.729, 6 waves 0.762 (spills in the hot path); near-centre branch out of line, 5 waves 0.675, 6 waves
+// 0.646, 7 waves 0.635, 8 waves 0.634.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_lbl_accumulate(LblParams p)
 {
     const int l = blockIdx.y;
     const int j0 = blockIdx.x * (256 * kLblPts);
