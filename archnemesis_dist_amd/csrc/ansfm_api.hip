@@ -1952,7 +1952,7 @@ int ansfm_add_line_set_monochromatic_absorption(
     if ((rc = h2d(ctx, ctx->hb[5], q_ratio, (size_t)L * D, &d_q))) return rc;
     if ((rc = h2d(ctx, ctx->hb[6], out, (size_t)L * nw * D, &d_out))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));   // h is a local buffer
-    HIPCHK(ctx->misc.reserve((size_t)L * kLblRows * N * D));
+    HIPCHK(ctx->misc.reserve((size_t)L * (kLblRows + 1) * N * D));
     LblParams p;
     memset(&p, 0, sizeof p);
     const double *dl = (const double *)d_lines;
@@ -1960,6 +1960,7 @@ int ansfm_add_line_set_monochromatic_absorption(
     p.nu = dl; p.sw = dl + N; p.e_lower = dl + 2 * (size_t)N; p.stim_ref = dl + 3 * (size_t)N; p.bparams = dl + 4 * (size_t)N;
     p.mmf = (const double *)d_mmf; p.t_calc = (const double *)d_t; p.p_calc = (const double *)d_p; p.q_ratio = (const double *)d_q;
     p.store = ctx->misc.as<double>();
+    p.shift = p.store + (size_t)L * kLblRows * N;
     p.out = (double *)const_cast<void *>(d_out);
     p.nw = nw; p.N = N; p.M = M; p.L = L; p.lineshape_id = lineshape_id;
     p.t_ref = t_ref; p.p_ref = p_ref; p.iso_abundance = isotopic_abundance; p.iso_mass = isotopic_mass; p.s_floor = s_floor;
@@ -1972,14 +1973,20 @@ int ansfm_add_line_set_monochromatic_absorption(
     HIPCHK(hipMemcpyAsync(out, p.out, (size_t)L * nw * D, hipMemcpyDeviceToHost, ctx->stream));
     std::vector<double> hst;
     if (store) {
-        hst.resize((size_t)L * kLblRows * N);
+        hst.resize((size_t)L * (kLblRows + 1) * N);
         HIPCHK(hipMemcpyAsync(hst.data(), p.store, hst.size() * D, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (store)   // store[L][4][N] in the caller's line order
+    if (store) {   // store[L][4][N] = strength, alpha_d, gamma_l, shift in the caller's line order
+        static const int src[3] = {0, 6, 7};
+        const double *hsh = hst.data() + (size_t)L * kLblRows * N;
         for (int l = 0; l < L; ++l)
-            for (int r = 0; r < 4; ++r)
-                for (int i = 0; i < N; ++i) store[((size_t)l * 4 + r) * N + ord[i]] = hst[((size_t)l * N + i) * kLblRows + r];
+            for (int i = 0; i < N; ++i) {
+                const double *rec = hst.data() + ((size_t)l * N + i) * kLblRows;
+                for (int r = 0; r < 3; ++r) store[((size_t)l * 4 + r) * N + ord[i]] = rec[src[r]];
+                store[((size_t)l * 4 + 3) * N + ord[i]] = hsh[(size_t)l * N + i];
+            }
+    }
     return ANSFM_OK;
 }
 

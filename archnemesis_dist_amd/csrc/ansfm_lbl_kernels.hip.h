@@ -120,15 +120,18 @@ struct LblParams {
     const double *bparams;  // [3M][N]
     const double *mmf;      // [M]
     const double *t_calc, *p_calc, *q_ratio;  // [L]
-    double *store;          // [L][N][kLblRows]: strength, alpha_d, gamma_l, shift, wing numerator (iso * strength *
-                            // line_approx_const * cmax^2), then the Voigt constants of the line: 1/(sigma sqrt 2), y = gamma/(sigma
-                            // sqrt 2), 1/(sigma sqrt(2 pi))   (row 5 = 0: the line takes the general lineshape function)
+    double *store;          // [L][N][kLblRows]: strength, shifted centre nu + shift, wing numerator (iso * strength *
+                            // line_approx_const * cmax^2), the Voigt constants of the line 1/(sigma sqrt 2), y = gamma/(sigma
+                            // sqrt 2), 1/(sigma sqrt(2 pi)) (the first = 0: the line takes the general lineshape function),
+                            // alpha_d, gamma_l -- everything k_lbl_accumulate reads about a line, in 64 bytes
+    double *shift;          // [L][N] pressure shift (only the caller's `store` wants it)
     double *out;            // [L][nw]  (added to)
     int nw, N, M, L, lineshape_id;
     double t_ref, p_ref, iso_abundance, iso_mass, s_floor, wn_calc_window, wn_approx_window, max_shift;
 };
 
-// per (layer, line): store[0..3] exactly as the reference fills them (:306-341) + the wing term's numerator (:261, :270)
+// per (layer, line): strength, alpha_d, gamma_l, shift exactly as the reference fills them (:306-341) + the wing term's
+// numerator (:261, :270)
 __global__ void k_lbl_line_params(LblParams p)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,11 +154,12 @@ __global__ void k_lbl_line_params(LblParams p)
     }
     double *st = p.store + ((size_t)l * p.N + i) * kLblRows;      // one line's constants are contiguous (64 bytes)
     st[0] = strength;
-    st[1] = alpha_d;
-    st[2] = g;
-    st[3] = sh;
-    // row 4: the whole numerator of the wing term (:270), same association as the reference's expression
-    st[4] = p.iso_abundance * strength * lbl_lineshape(p.lineshape_id, p.wn_calc_window, alpha_d, g) *
+    st[1] = nu + sh;                                              // :264
+    st[6] = alpha_d;
+    st[7] = g;
+    p.shift[(size_t)l * p.N + i] = sh;
+    // the whole numerator of the wing term (:270), same association as the reference's expression
+    st[2] = p.iso_abundance * strength * lbl_lineshape(p.lineshape_id, p.wn_calc_window, alpha_d, g) *
                               (p.wn_calc_window * p.wn_calc_window);
     // Voigt: scipy's voigt_profile(x, sigma, gamma) = Re w((x + i gamma) / (sigma sqrt 2)) / (sigma sqrt(2 pi)) -- the
     // three per-line factors once per (layer, line) instead of three divisions per grid point
@@ -169,9 +173,9 @@ __global__ void k_lbl_line_params(LblParams p)
             nrm = 1.0 / sigma / sqrt(2.0 * 3.141592653589793);
         }
     }
-    st[5] = xs;
-    st[6] = yv;
-    st[7] = nrm;
+    st[3] = xs;
+    st[4] = yv;
+    st[5] = nrm;
 }
 
 // kLblPts grid points per thread (256 apart, so a wave's loads and stores stay coalesced): the per-line work that does not
@@ -212,9 +216,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         const double *st = stl + (size_t)i * kLblRows;                          // 64 contiguous bytes: one scalar load
         const double strength = st[0];
         if (strength < p.s_floor) continue;                                     // :258
-        const double centre = p.nu[i] + st[3];                                  // :264
-        const double wing = st[4];
-        const double xs = st[5], yv = st[6], nrm = st[7];
+        const double centre = st[1];
+        const double wing = st[2];
+        const double xs = st[3], yv = st[4], nrm = st[5];
         const double amp = p.iso_abundance * strength;
 #pragma unroll
         for (int k = 0; k < kLblPts; ++k) {
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
             if (wn_delta >= amax || wn_delta < amin) continue;                  // :266-269
             if (cmin <= wn_delta && wn_delta < cmax) {
                 const double shape = (xs != 0.0) ? lbl_rew(wn_delta * xs, yv) * nrm
-                                                 : lbl_lineshape(p.lineshape_id, wn_delta, st[1], st[2]);
+                                                 : lbl_lineshape(p.lineshape_id, wn_delta, st[6], st[7]);
                 acc[k] += amp * shape;
             } else
                 acc[k] += lbl_div(wing, wn_delta * wn_delta);
