@@ -26,7 +26,7 @@ EXPORTS = [
     "ansfm_k_overlapg", "ansfm_cirsradg_ck_thermal", "ansfm_cirsradg_ck_thermal_dev", "ansfm_scloud11wave_core", "ansfm_upload_lbltable", "ansfm_calc_klbl", "ansfm_add_line_set_monochromatic_absorption", "ansfm_layer_average",
     "ansfm_map2pro", "ansfm_map2xvec", "ansfm_layer_averageg", "ansfm_lblconv", "ansfm_lblconv_fil", "ansfm_lblconv_ngeom", "ansfm_lblconv_fil_ngeom", "ansfm_conv_fil", "ansfm_integrate_filter", "ansfm_calc_tau_rayleigh", "ansfm_calc_tau_dust", "ansfm_set_layer_dedup", "ansfm_last_layer_rows",
     "ansfm_ktable_file_header", "ansfm_upload_ktable_files", "ansfm_ktable_grids", "ansfm_lbltable_file_header",
-    "ansfm_upload_lbltable_files", "ansfm_kdist_bins", "ansfm_calc_tau_cia",
+    "ansfm_upload_lbltable_files", "ansfm_kdist_bins", "ansfm_calc_tau_cia", "ansfm_set_merge_keys", "ansfm_merge_redo_count",
 ]
 
 _lib = None
@@ -45,7 +45,7 @@ def hipcc_path():
 
 def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into lib/libansfm.so (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, "ansfm_api.hip"), os.path.join(CSRC, "ansfm_kdist.hip")]
+    srcs = [os.path.join(CSRC, "ansfm_api.hip"), os.path.join(CSRC, "ansfm_kdist.hip"), os.path.join(CSRC, "ansfm_merge32.hip")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "ansfm.h")]
     if not force and os.path.exists(LIB_PATH):
         newest = max(os.path.getmtime(d) for d in deps)
@@ -143,6 +143,8 @@ def load():
     lib.ansfm_lbltable_file_header.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp]
     lib.ansfm_upload_lbltable_files.argtypes = [vp, ci, C.POINTER(C.c_char_p), cd, cd]
     lib.ansfm_set_layer_dedup.argtypes = [vp, ci]
+    lib.ansfm_set_merge_keys.argtypes = [vp, ci]
+    lib.ansfm_merge_redo_count.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.ansfm_last_layer_rows.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.ansfm_lblconv.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, ci, cd, vp, vp]
     lib.ansfm_lblconv_fil.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp]

@@ -8,6 +8,7 @@
 #include "ansfm_conv_kernels.hip.h"
 #include "ansfm_cont_kernels.hip.h"
 #include "ansfm_kdist.hip.h"
+#include "ansfm_merge32_launch.h"
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -56,6 +57,7 @@ struct ansfm_ctx {
     int monotone = 0;
     std::vector<double> h_wave, h_press, h_temp;   // host copies of the grids of the table in HBM
     int force_generic = 0;   // rerun of a call whose k-distributions turned out not to be sorted in g
+    int merge_keys = 64;     // 32: run the forward merge on k_ck_overlap32's float32 keys (ansfm_set_merge_keys)
     bool have_table = false;
     int grid_f32 = 0, delg_f32 = 0;
     int is_lbl = 0, temp2d = 0;   // LBL-table mode (ILBL=2): G = 1, TEMP may be [NP][NT]
@@ -496,9 +498,23 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
         p.g_ord[G] = 1.0;
         p.g_ord[G + 1] = __builtin_nan("");        // never crossed: merge_walk compares with an ordered >=
     }
-    const size_t lds = (size_t)(2 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) + kMaxG * sizeof(float) +
-                       (sorted ? 0 : (size_t)2 * G * kWave);
-    int per_cu = (int)((160 * 1024) / lds);
+    // The division-free walk (merge_walk_nodiv) and the 32-bit-key kernel (ansfm_merge32.hip.h, opt-in) need sorted,
+    // non-negative input and a first element of the merged order that does not close a bin (rank()'s python [-1] wrap,
+    // which only the recorded walk reproduces).  A negative value raises the same flag as an unsorted one in the 32-bit
+    // kernel and the call is rerun on the generic path.
+    bool nodiv = sorted && G >= 2;
+    if (nodiv) {
+        const double w00 = ctx->delg_f32 ? (double)((float)del_g_host[0] * (float)del_g_host[0]) : del_g_host[0] * del_g_host[0];
+        if (!(w00 < p.g_ord[1])) nodiv = false;
+    }
+    if (const char *ev = getenv("ANSFM_MERGE_WALK")) { if (!strcmp(ev, "records")) nodiv = false; }
+    bool keys32 = nodiv && ctx->merge_keys == 32;
+    if (const char *ev = getenv("ANSFM_MERGE_KEYS")) { keys32 = nodiv && atoi(ev) == 32; }
+    const size_t lds = keys32 ? (size_t)overlap32_lds_bytes(G, ctx->delg_f32 != 0)
+                              : (size_t)(2 * G + 1) * kWave * sizeof(double) + (size_t)(2 * kMaxG + 2) * sizeof(double) +
+                                    kMaxG * sizeof(float) + (sorted ? 0 : (size_t)2 * G * kWave);
+    const size_t lds_alloc = (lds + 127) / 128 * 128;      // measured (tools/calib/lds_granule.hip): 7 blocks up to 23 360 bytes
+    int per_cu = (int)((160 * 1024) / lds_alloc);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     if (const char *ev = getenv("ANSFM_WAVES_PER_CU")) { int v = atoi(ev); if (v >= 1 && v < per_cu) per_cu = v; }
@@ -508,9 +524,15 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
     if (grid < 1) grid = 1;
     HIPCHK(ctx->scratch.reserve((size_t)grid * 6 * G * kWave * sizeof(double)));
     p.scratch = ctx->scratch.as<double>();
+    if (keys32) {
+        HIPCHK(launch_overlap32(p, from_k, merge_list_len(G), (unsigned)grid, ctx->stream));
+        return ANSFM_OK;
+    }
 #define LAUNCH_OV2(D, FK, W32)                                                                                      \
     do {                                                                                                            \
-        if (sorted)                                                                                                 \
+        if (nodiv)                                                                                                  \
+            hipLaunchKernelGGL((k_ck_overlap<D, FK, W32, true, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p); \
+        else if (sorted)                                                                                            \
             hipLaunchKernelGGL((k_ck_overlap<D, FK, W32, true>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p);  \
         else                                                                                                        \
             hipLaunchKernelGGL((k_ck_overlap<D, FK, W32, false>), dim3((unsigned)grid), dim3(kWave), lds, ctx->stream, p); \
@@ -671,6 +693,27 @@ int ansfm_set_layer_dedup(ansfm_ctx *ctx, int enable)
 {
     CHECK_CTX(ctx);
     ctx->dedup = enable ? 1 : 0;
+    return ANSFM_OK;
+}
+
+int ansfm_set_merge_keys(ansfm_ctx *ctx, int bits)
+{
+    CHECK_CTX(ctx);
+    if (bits != 32 && bits != 64) FAIL(ANSFM_ERR_INVALID, "set_merge_keys: bits must be 32 or 64");
+    ctx->merge_keys = bits;
+    return ANSFM_OK;
+}
+
+int ansfm_merge_redo_count(ansfm_ctx *ctx, int64_t *count)
+{
+    CHECK_CTX(ctx);
+    if (!count) FAIL(ANSFM_ERR_INVALID, "merge_redo_count: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    int v = 0;
+    HIPCHK(ctx->d_flag.reserve(16 * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(&v, ctx->d_flag.as<int>() + 13, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *count = v;
     return ANSFM_OK;
 }
 

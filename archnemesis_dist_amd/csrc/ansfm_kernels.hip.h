@@ -16,39 +16,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "ansfm_merge_common.hip.h"
 
 namespace ansfm {
-
-constexpr int kWave = 64;
-constexpr int kMaxG = 32;
-
-// ------------------------------------------------------------------------------------------------
-// ln-k table encoding.  k > 0  -> ln k (finite double)
-//                       k <= 0 -> quiet NaN whose 51 payload bits are the top 51 bits of k
-// (sign, exponent, 39 mantissa bits: exact for tables that were float32 on disk).  The
-// good/bad/mixed corner logic of calc_k (Spectroscopy_0.py:2391-2403) needs the sign and, for the
-// all-non-positive "bad" branch, the raw value.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double encode_lnk(double k)
-{
-    if (k > 0.0) return log(k);
-    unsigned long long b = (unsigned long long)__double_as_longlong(k);
-    unsigned long long box = 0x7FF8000000000000ULL | (b >> 13);
-    return __longlong_as_double((long long)box);
-}
-__device__ __forceinline__ bool lnk_is_boxed(double x) { return x != x; }
-__device__ __forceinline__ double lnk_unbox(double x)
-{
-    unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    return __longlong_as_double((long long)((b & 0x0007FFFFFFFFFFFFULL) << 13));
-}
-
-// Per (model, layer) interpolation constants: the nearest-then-bracket corner choice of calc_k
-// (Spectroscopy_0.py:2336-2389) is wave-uniform, so it is computed once per layer.
-struct LayerInterp {
-    int ipl, iph, itl, ith;
-    double v, u, dudt;
-};
 
 __global__ void k_layer_prep(int n_layers_total, const double *__restrict__ lay_press_pa,
                              const double *__restrict__ lay_temp, int NP,
@@ -157,39 +127,6 @@ __global__ void k_table_check(const double *__restrict__ K, int W, int G, int Q,
     if (bad) atomicOr(flag, 1);
 }
 
-// k for one (corner set, u, v): Spectroscopy_0.py:2391-2403 (+ dk/dT :2241-2247 when wanted)
-__device__ __forceinline__ double interp_k(double l1, double l2, double h1, double h2, double v,
-                                           double u)
-{
-    // l1 = (ip_low,it_low)  l2 = (ip_low,it_high)  h1 = (ip_high,it_low)  h2 = (ip_high,it_high)
-    bool b1 = lnk_is_boxed(l1), b2 = lnk_is_boxed(l2), b3 = lnk_is_boxed(h1), b4 = lnk_is_boxed(h2);
-    double kk = 0.0;
-    if (!(b1 | b2 | b3 | b4)) {
-        double x = (1.0 - v) * (1.0 - u) * l1 + v * (1.0 - u) * h1 + v * u * h2 + (1.0 - v) * u * l2;
-        kk = exp(x);
-    } else if (b1 & b2 & b3 & b4) {
-        double klo1 = lnk_unbox(l1), klo2 = lnk_unbox(l2), khi1 = lnk_unbox(h1), khi2 = lnk_unbox(h2);
-        kk = (1.0 - v) * (1.0 - u) * klo1 + v * (1.0 - u) * khi1 + v * u * khi2 + (1.0 - v) * u * klo2;
-    }
-    return kk;
-}
-__device__ __forceinline__ void interp_kg(double l1, double l2, double h1, double h2, double v,
-                                          double u, double dudt, double &kk, double &dk)
-{
-    bool b1 = lnk_is_boxed(l1), b2 = lnk_is_boxed(l2), b3 = lnk_is_boxed(h1), b4 = lnk_is_boxed(h2);
-    kk = 0.0; dk = 0.0;
-    if (!(b1 | b2 | b3 | b4)) {
-        double x = (1.0 - v) * (1.0 - u) * l1 + v * (1.0 - u) * h1 + v * u * h2 + (1.0 - v) * u * l2;
-        kk = exp(x);
-        double dxdt = (-l1 * (1.0 - v) - h1 * v + h2 * v + l2 * (1.0 - v)) * dudt;
-        dk = kk * dxdt;
-    } else if (b1 & b2 & b3 & b4) {
-        double klo1 = lnk_unbox(l1), klo2 = lnk_unbox(l2), khi1 = lnk_unbox(h1), khi2 = lnk_unbox(h2);
-        kk = (1.0 - v) * (1.0 - u) * klo1 + v * (1.0 - u) * khi1 + v * u * khi2 + (1.0 - v) * u * klo2;
-        dk = (-klo1 * (1.0 - v) - khi1 * v + khi2 * v + klo2 * (1.0 - v)) * dudt;
-    }
-}
-
 // Array-level seam calc_k / calc_kg: writes the reference layout k[W][G][L][S] directly.
 __global__ void k_calc_k_seam(const double *__restrict__ lnK, int W, int Wpad, int G, int NT, int S,
                               int L, const LayerInterp *__restrict__ li, double *__restrict__ k_out,
@@ -231,114 +168,13 @@ __global__ void k_calc_k_seam(const double *__restrict__ lnK, int W, int Wpad, i
 //
 // LDS per wave: (2G+1)*64*8 bytes (+ shared del_g / g_ord tables)  -> 21.1 KiB at G=20, 7 waves per CU.
 // ------------------------------------------------------------------------------------------------
-struct OverlapParams {
-    const double *lnK;        // [NP][NT][S][G][Wpad]            (FROM_K: unused)
-    const double *kin;        // FROM_K: k[S][L][G][Wpad] (array-level k_overlap seam)
-    const LayerInterp *li;    // [n][L]
-    const double *amount;     // [n][S][L]
-    const double *del_g;      // [G]
-    double *tau;              // [n][L][G][Wpad]
-    double *scratch;          // [gridDim.x][2][G][64]
-    int *err_flag;            // bit0: unsorted input k-distribution
-    unsigned int *tile_counter;  // [8] dynamic tile queues, one per XCD (zeroed before every launch)
-    int W, Wpad, G, NT, S, L, n_models;
-    int delg_f32;             // DELG is a float32 array: del_g[i]*del_g[j] is a float32 product
-    double g_ord[kMaxG + 2];  // [0, cumsum(del_g)] (float32 cumsum when delg_f32), g_ord[G]=1, NaN
-};
-
-// Table reads of one gas for one (64-wavenumber, layer) tile.  The loads of kLoadBatch g-ordinates (4 corner
-// rows each) are all issued before the first value is used: one memory round trip per batch instead of one per
-// g-ordinate (a wave has at most one sibling on its SIMD to hide it behind).  Indices are clamped, not
-// predicated, so the batch stays branch-free.
-constexpr int kLoadBatch = 10;
 // LDS byte offsets of the tables that open the merge kernels' dynamic LDS block (the kernels have no static LDS, so the
 // block starts at address 0 -- checked once per launch): reads become `ds_read vaddr = index << k, offset:const`.
 constexpr unsigned kLdsDG = 0, kLdsGORD = kMaxG * 8, kLdsDGF = (2 * kMaxG + 2) * 8, kLdsA = kLdsDGF + kMaxG * 4;
 
-template <bool FROM_K>
-__device__ __forceinline__ void load_gas(const OverlapParams &p, const LayerInterp &q, int m, int l,
-                                         int s, int nu, double *DST, int lane, bool &unsorted)
-{
-    const int G = p.G;
-    const double amt = p.amount[((size_t)m * p.S + s) * p.L + l];
-    double prev = -__builtin_inf();
-    if constexpr (FROM_K) {
-        const double *src = p.kin + (((size_t)s * p.L + l) * G) * p.Wpad + nu;
-        for (int g0 = 0; g0 < G; g0 += kLoadBatch) {
-            double r[kLoadBatch];
-#pragma unroll
-            for (int k = 0; k < kLoadBatch; ++k) {
-                const int gi = (g0 + k < G) ? g0 + k : G - 1;
-                r[k] = src[(size_t)gi * p.Wpad];
-            }
-#pragma unroll
-            for (int k = 0; k < kLoadBatch; ++k)
-                if (g0 + k < G) {
-                    const double kk = r[k] * amt;
-                    DST[(g0 + k) * kWave + lane] = kk;
-                    unsorted |= (kk < prev);
-                    prev = kk;
-                }
-        }
-    } else {
-        const size_t strideT = (size_t)p.S * G * p.Wpad;
-        const size_t off = (size_t)s * G * p.Wpad + nu;
-        const double *c1 = p.lnK + ((size_t)q.ipl * p.NT + q.itl) * strideT + off;
-        const double *c2 = p.lnK + ((size_t)q.ipl * p.NT + q.ith) * strideT + off;
-        const double *c3 = p.lnK + ((size_t)q.iph * p.NT + q.itl) * strideT + off;
-        const double *c4 = p.lnK + ((size_t)q.iph * p.NT + q.ith) * strideT + off;
-        for (int g0 = 0; g0 < G; g0 += kLoadBatch) {
-            double r1[kLoadBatch], r2[kLoadBatch], r3[kLoadBatch], r4[kLoadBatch];
-#pragma unroll
-            for (int k = 0; k < kLoadBatch; ++k) {
-                const int gi = (g0 + k < G) ? g0 + k : G - 1;
-                const size_t go = (size_t)gi * p.Wpad;
-                // streamed once per tile: non-temporal so the table does not push the merge scratch out of L2
-                r1[k] = __builtin_nontemporal_load(c1 + go);
-                r2[k] = __builtin_nontemporal_load(c2 + go);
-                r3[k] = __builtin_nontemporal_load(c3 + go);
-                r4[k] = __builtin_nontemporal_load(c4 + go);
-            }
-#pragma unroll
-            for (int k = 0; k < kLoadBatch; ++k)
-                if (g0 + k < G) {
-                    const double kk = interp_k(r1[k], r2[k], r3[k], r4[k], q.v, q.u) * amt;
-                    DST[(g0 + k) * kWave + lane] = kk;
-                    unsorted |= (kk < prev);
-                    prev = kk;
-                }
-        }
-    }
-}
-
-__device__ __forceinline__ double fast_div(double n, double d)
-{   // n/d with v_rcp_f64 + 2 Newton steps + residual correction (<= ~1 ulp; frac of rank()).  One Newton step gives the
-    // same quotients (tools/calib/div_check.hip) but k_ck_overlap measured 1.2 % SLOWER with it (5.88 -> 5.95 ms, same box,
-    // twice): the second step's two instructions fill issue slots the resolve otherwise leaves empty
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    double q = n * r;
-    return fma(fma(-d, q, n), r, q);
-}
-
 // One popped element of the merge with everything the rank walk and the row's next key need, fetched from LDS
 // as soon as the winner key is known (software pipelining: the walk of element t and the rest of the insertion
 // pass run while the operands of element t+1 are in flight).
-typedef __attribute__((address_space(3))) double lds_double;
-__device__ __forceinline__ unsigned lds_addr(const double *p) { return (unsigned)(size_t)(const lds_double *)p; }
-__device__ __forceinline__ double lds_ld(unsigned a) { return *(const lds_double *)(size_t)a; }
-__device__ __forceinline__ void lds_st(unsigned a, double v) { *(lds_double *)(size_t)a = v; }
-// Global access as wave-uniform base + 32-bit byte offset: the compiler emits `global_load/store v_off, s[base]` and the
-// per-access address arithmetic stays 32-bit (64-bit pointer adds are multi-pass VALU instructions).
-template <class T> __device__ __forceinline__ T gld(const void *base, unsigned byte_off)
-{
-    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
-}
-template <class T> __device__ __forceinline__ void gst(void *base, unsigned byte_off, T v)
-{
-    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
-}
 // Bin records, per block [bin][2][lane] pairs of doubles: pair 0 = (kacc, sum1), pair 1 = (gd, code of the element that
 // closed the bin: row | column << 5), each pair one 16-byte store per lane, the lanes of a pair contiguous (1 KiB rows).
 // The stores sit in the merge loop's crossing branch, which runs in about every second step, and every store
@@ -349,8 +185,6 @@ template <class T> __device__ __forceinline__ void gst(void *base, unsigned byte
 // pairs as (frac, 1/weight-sum) and (weight, code) for its replay passes.
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 constexpr unsigned kRecRow = 64u * 16u, kRecBin = 2u * kRecRow;
-typedef __attribute__((address_space(3))) float lds_float;
-__device__ __forceinline__ float lds_ldf(unsigned a) { return *(const lds_float *)(size_t)a; }
 
 struct MergeElem {
     double ai, bc, bn, w;
@@ -446,6 +280,34 @@ __device__ __forceinline__ bool merge_walk(const MergeElem &e, WalkState &ws, do
     return cross;
 }
 
+// Division-free form of the walk (forward kernel, NODIV).  rank()'s boundary element contributes frac * cont * w to the bin
+// it closes and (1 - frac) * cont * w to the next one, frac = (g_ord[ig+1] - gdist_prev) / w: that is
+// (g_ord[ig+1] - gdist_prev) * cont and (gdist - g_ord[ig+1]) * cont -- no division -- and the bin's weight sum (carry
+// (1-frac) w of the previous boundary element, the weights inside, frac w) telescopes to g_ord[ig+1] - g_ord[ig].  A closed
+// bin is then ONE 8-byte store of its un-normalised sum (rec = [bin][lane] doubles) instead of a 32-byte record, and the
+// resolve pass is a division by the bin width when the merged spectrum is read back.  Differs from the recorded form
+// in the last bits only (the reference itself forms frac from a difference of cumulative sums, good to ~1e-12).
+// Precondition (checked at launch): the first element of the merged order does not close a bin -- rank()'s python
+// gdist[-1] wrap, which only the recorded form reproduces.
+__device__ __forceinline__ bool merge_walk_nodiv(const MergeElem &e, WalkState &ws, double *rec)
+{
+    const double cv = e.ai + e.bc;
+    const double w = e.w;
+    const double gdn = ws.gd + w;
+    double kn = fma(cv, w, ws.kacc);
+    const bool cross = (gdn >= ws.gnext);       // ordered: GORD[G+1] is NaN
+    if (cross) {
+        gst<double>(rec, ws.roff, fma(ws.gnext - ws.gd, cv, ws.kacc));
+        kn = (gdn - ws.gnext) * cv;
+        ws.roff += kWave * 8u;
+        ws.gaddr += 8u;
+        ws.gnext = lds_ld(ws.gaddr);
+    }
+    ws.kacc = kn;
+    ws.gd = gdn;
+    return cross;
+}
+
 // The heads of the G rows are kept as a SORTED LIST IN REGISTERS (R[0] = the current winner): popping is free and the
 // row's next key is inserted by one pass of v_max_f64 + v_min_f64 pairs over statically indexed
 // registers -- no tree in LDS, no lane-dependent addressing, and the next winner is known after the FIRST
@@ -453,7 +315,7 @@ __device__ __forceinline__ bool merge_walk(const MergeElem &e, WalkState &ws, do
 // (compile time, >= G; unused entries hold "huge" keys).
 // Returns the consumed element's (row, column) and whether it closed a bin, as 16 bits: the gradient kernel
 // records them and replays the sorted order for the gradient rows.
-template <int NR, bool W32, bool REC_CODE = false, bool SORTED = true>
+template <int NR, bool W32, bool REC_CODE = false, bool SORTED = true, bool NODIV = false>
 __device__ __forceinline__ unsigned merge_step(double (&R)[NR], MergeElem &e, MergeElem &en, WalkState &ws,
                                                int lane, const double *A, const double *B,
                                                const double *DG, const double *GORD, double *rec,
@@ -481,56 +343,42 @@ __device__ __forceinline__ unsigned merge_step(double (&R)[NR], MergeElem &e, Me
     }
     asm("v_max_f64 %0, %1, %2" : "=v"(R[NR - 1]) : "v"(x), "v"(R[NR - 1]));
     // 4. rank walk on the element just consumed
-    const bool cross = merge_walk<REC_CODE>(e, ws, rec, GORD, lane);
+    bool cross;
+    if constexpr (NODIV) cross = merge_walk_nodiv(e, ws, rec);
+    else cross = merge_walk<REC_CODE>(e, ws, rec, GORD, lane);
     // stream format of the gradient replay: bits 2-6 = row * 4, bits 9-13 = column * 4 (byte offsets into the float32
     // weight table, << 7 more = the row of an [index][lane] LDS array), bit 15 = the element closed a bin
     return (unsigned)((e.ci << 2) | ((e.np - 1) << 9) | (cross ? 0x8000 : 0));
 }
 
-// R[i] = head of row i = a_i + b_0: ascending in i because a is (fast path: by precondition; generic: sorted first).
+// R[i] = head of row i = a_i + b_0: ascending in i when a is.  A loaded gas is (fast path: by precondition; generic: sorted
+// first); a MERGED spectrum is non-decreasing only up to the rounding of its bin averages, and two neighbours that
+// rounding has swapped can fall on either side of a key boundary (seen with k(g) flat to 1e-9: an unsorted list loses an
+// entry in the insertion network and a sentinel is consumed).  So the keys are checked, and when some lane's are not
+// ascending the heads are put in order one by one (the merge itself only needs every ROW ascending, i.e. b sorted).
 template <int NR>
 __device__ __forceinline__ void merge_init(double (&R)[NR], int G, int lane, const double *A, double b0, double huge)
 {
 #pragma unroll
     for (int i = 0; i < NR; ++i) R[i] = (i < G) ? pack_key11(A[(i < G ? i : 0) * kWave + lane] + b0, i, 0) : huge;
-}
-
-// Dynamic tile queues.  With 5 resident waves per CU one SIMD hosts two waves that run slower than the solo
-// ones; static striding would make the launch wait for them.  One relaxed atomic per tile (~2800*7 merge steps
-// of work) -- every wave exits when the counters pass the tile counts.
-// Eight queues, queue q = wavenumber tiles vt with vt % 8 == q (layer fastest): the layers of one wavenumber
-// tile share k-table corner rows, so they are kept on one XCD's L2.  A wave starts on the queue of the XCD it
-// runs on (HW_REG_XCC_ID; affinity only, any placement is correct) and steals from the others when its own
-// is empty.
-struct TileQueue {
-    int myq, qoff;
-    __device__ __forceinline__ void init()
-    {
-        myq = (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 7);
-        qoff = 0;
-    }
-    __device__ __forceinline__ bool next(const OverlapParams &p, int lane, int &vt, int &m, int &l)
-    {
-        const int NVT = p.Wpad / kWave;
-        while (qoff < 8) {
-            const int qq = (myq + qoff) & 7;
-            const int nvt_q = (NVT - qq + 7) / 8;                     // tiles vt = qq, qq+8, ...
-            const long nq = (long)p.n_models * nvt_q * p.L;
-            unsigned int tq = 0;
-            if (lane == 0 && nq > 0) tq = atomicAdd(p.tile_counter + qq, 1u);
-            const long t = (long)__builtin_amdgcn_readfirstlane(tq);
-            if (nq > 0 && t < nq) {
-                l = (int)(t % p.L);
-                const long r = t / p.L;
-                vt = qq + 8 * (int)(r % nvt_q);
-                m = (int)(r / nvt_q);
-                return true;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i + 1 < NR; ++i) bad |= (R[i + 1] < R[i]);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+        double T[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { T[i] = R[i]; R[i] = huge; }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (i < G) {
+                const double x = T[i];
+#pragma unroll
+                for (int k = NR - 1; k >= 1; --k) R[k] = fmin(fmax(x, R[k - 1]), R[k]);
+                R[0] = fmin(x, R[0]);
             }
-            ++qoff;
         }
-        return false;
     }
-};
+}
 
 // Per-lane insertion sort of one LDS column (values ascending, stable) carrying the original index of every
 // position in P.  Only the generic path (k not sorted in g) uses it.
@@ -556,7 +404,7 @@ __device__ __forceinline__ void sort_column(double *X, unsigned char *P, int G, 
 // (product, weight) is unchanged, so rank()'s walk sees the same sequence up to the order of exact ties -- and the
 // skip rules keep looking at the LAST g-ordinate in the original order (:6075-6102).  A spectrum that passes through
 // unmerged comes out in its original order.
-template <int NR, bool FROM_K, bool W32, bool SORTED = true>
+template <int NR, bool FROM_K, bool W32, bool SORTED = true, bool NODIV = false>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_ck_overlap(OverlapParams p)
 {
     extern __shared__ double smem[];
@@ -623,13 +471,34 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 MergeElem e0, e1;
                 merge_fetch<W32, SORTED>(R[0], lane, A, B, DG, e0, PA, PB);
                 WalkState ws = walk_begin(GORD, lane);
+                if constexpr (NODIV) ws.roff = (unsigned)lane * 8u;
                 const int nloop = G * G;
                 int it = 0;
                 for (; it + 1 < nloop; it += 2) {   // ping-pong: no register rotation
-                    merge_step<NR, W32, false, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
-                    merge_step<NR, W32, false, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    merge_step<NR, W32, false, SORTED, NODIV>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    merge_step<NR, W32, false, SORTED, NODIV>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
                 }
-                if (it < nloop) merge_step<NR, W32, false, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                if (it < nloop) merge_step<NR, W32, false, SORTED, NODIV>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                if constexpr (NODIV) {
+                    // ---- normalise: closed bins by their width; the open one as rank()'s trailing `if ig == ng-1` (:6171) ----
+                    const int ig = walk_bins(ws, GORD);
+                    for (int g0 = 0; g0 < G; g0 += kLoadBatch) {
+                        double r[kLoadBatch];
+#pragma unroll
+                        for (int k = 0; k < kLoadBatch; ++k)
+                            r[k] = gld<double>(rec, (unsigned)((g0 + k < G) ? g0 + k : G - 1) * (kWave * 8u) + (unsigned)lane * 8u);
+#pragma unroll
+                        for (int k = 0; k < kLoadBatch; ++k) {
+                            const int b = g0 + k;
+                            if (b < G) {
+                                double outv = 0.0;
+                                if (b < ig) outv = fast_div(r[k], GORD[b + 1] - GORD[b]);
+                                else if (b == ig) outv = (b == G - 1) ? fast_div(ws.kacc, ws.gd - GORD[G - 1]) : ws.kacc;
+                                A[b * kWave + lane] = outv;
+                            }
+                        }
+                    }
+                } else {
                 // ---- resolve the bins --------------------------------------------------------------------
                 // The closing element of every bin is re-formed from LDS (a[row] + b[col], its weight) exactly as the
                 // walk formed it, so `a` must stay intact until the last bin is done: the outputs go to row 0 of the bin
@@ -686,6 +555,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
 #pragma unroll
                     for (int k = 0; k < kLoadBatch; ++k)
                         if (g0 + k < G) A[(g0 + k) * kWave + lane] = r[k];
+                }
                 }
                 if constexpr (!SORTED) {   // the merged spectrum is ascending with the plain del_g weights
                     for (int g = 0; g < G; ++g) PA[g * kWave + lane] = (unsigned char)g;

@@ -590,6 +590,16 @@ class AnsfmEngine:
         """Share the gas opacity of layers that are bit-identical to the first model's inside a batched call."""
         self._check(self._lib.ansfm_set_layer_dedup(self._ctx, int(bool(enable))), "set_layer_dedup")
 
+    def set_merge_keys(self, bits=64):
+        """Row-head keys of the forward k_overlap merge: 32 (float32 keys + exact tie branch) or 64 (double keys)."""
+        self._check(self._lib.ansfm_set_merge_keys(self._ctx, int(bits)), "set_merge_keys")
+
+    def merge_redo_count(self):
+        """(wave, gas) merges the 32-bit-key kernel had to rerun in its exact mode since the last table upload."""
+        n = C.c_int64(0)
+        self._check(self._lib.ansfm_merge_redo_count(self._ctx, C.byref(n)), "merge_redo_count")
+        return int(n.value)
+
     def last_layer_rows(self):
         """(layer opacities computed, n_models * L) of the last cirsrad_ck_thermal call."""
         a = C.c_int(); b = C.c_int()

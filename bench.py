@@ -278,6 +278,7 @@ def main():
                    "forward_models_per_step_per_gpu": 1, "parallelism": f"replicas x{world} (independent forward models)"},
         "roofline": roof, "cpu_baseline": cpu, "jacobian": jac,
         "table_relayout_s": table_relayout_s,
+        "merge_reruns": eng.merge_redo_count(),
     }
     print(json.dumps(line))
     if use_dist:

@@ -378,6 +378,18 @@ int ansfm_calc_tau_dust(ansfm_ctx *ctx, int W, const double *WAVEC, int NWS, con
 int ansfm_set_layer_dedup(ansfm_ctx *ctx, int enable);
 int ansfm_last_layer_rows(const ansfm_ctx *ctx, int *rows_computed, int *rows_total);
 
+/* Row-head list of the forward random-overlap merge (k_overlap / rank, ForwardModel_0.py:6029-6173): bits = 64 (default)
+ * orders the heads on double keys (k_ck_overlap: values closer than 2^-41 count as ties); bits = 32 on float32 keys
+ * (k_ck_overlap32: heads whose float32 values coincide are settled by their exact double sums, every merge carries a
+ * check that the sums were consumed in non-decreasing order and is rerun exactly when it was not).  Both produce the
+ * reference's merged order.  Measured on MI355X: the 32-bit kernel issues fewer instructions but
+ * exposes more LDS latency and is the slower of the two at C2, hence opt-in.  Input that is unsorted or negative runs
+ * on the generic 64-bit path either way. */
+int ansfm_set_merge_keys(ansfm_ctx *ctx, int bits);
+/* Statistics of the 32-bit-key kernel: (wave, gas) merges whose fast pass did not consume the sums in non-decreasing
+ * order and were rerun with every step popping the exact minimum; counted since the last table upload. */
+int ansfm_merge_redo_count(ansfm_ctx *ctx, int64_t *count);
+
 /* Vertical gas opacity of the last cirsrad call's first model, TAUGAS[W][G][L]
  * (what CIRSrad leaves in LayerX.TAUGAS, ForwardModel_0.py:3925) -- host pointer out. */
 int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS);

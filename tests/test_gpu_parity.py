@@ -121,10 +121,12 @@ def test_merge_list_lengths_vs_oracle(eng, oracle, G, S):
     assert np.max((np.abs(dk - rdk) / scale)[ok], initial=0.0) < 1e-10
 
 
-def test_nan_and_inf_input_stays_in_its_cells(eng, oracle):
+@pytest.mark.parametrize("keys", [32, 64])
+def test_nan_and_inf_input_stays_in_its_cells(eng, oracle, keys):
     """NaN / inf absorption coefficients poison only the (wavenumber, layer) cells they are in: the merge kernels never
     index by data beyond what the bin sentinel bounds (a NaN key can displace list entries), so the other cells equal
-    the clean run bit for bit."""
+    the clean run bit for bit.  keys = 32: the float32-key forward kernel (NaN and +inf stay on it; a negative value
+    such as -inf sends the call to the generic 64-bit path, whose clean run is the comparison then)."""
     from archnemesis_dist_amd import synthetic as syn
     rng = np.random.default_rng(99)
     W, G, L, S = 70, 10, 5, 4
@@ -132,20 +134,67 @@ def test_nan_and_inf_input_stays_in_its_cells(eng, oracle):
     k = np.sort(10.0 ** rng.uniform(-25, -20, (W, G, L, S)), axis=1)
     amount = 10.0 ** rng.uniform(19, 22, (S, L))
     dkdT = k * 0.01
-    clean = eng.k_overlap(delg, k, amount)
-    cleang, cleandk = eng.k_overlapg(delg, k, dkdT, amount)
-    bad = k.copy()
-    bad[3, 4, 1, 2] = np.nan; bad[10, G - 1, 2, 0] = np.inf; bad[20, 0, 3, 1] = -np.inf; bad[33, :, 4, 3] = np.nan
-    cells = [(3, 1), (10, 2), (20, 3), (33, 4)]
-    mask = np.ones((W, L), bool)
-    for w, l in cells:
-        mask[w, l] = False
-    with np.errstate(all="ignore"):
-        tau = eng.k_overlap(delg, bad, amount)
-        taug, dk = eng.k_overlapg(delg, bad, dkdT, amount)
-    assert np.array_equal(tau.transpose(0, 2, 1)[mask], clean.transpose(0, 2, 1)[mask])
-    assert np.array_equal(taug.transpose(0, 2, 1)[mask], cleang.transpose(0, 2, 1)[mask])
-    assert np.array_equal(dk.transpose(0, 2, 1, 3)[mask], cleandk.transpose(0, 2, 1, 3)[mask])
+    eng.set_merge_keys(keys)
+    try:
+        clean = eng.k_overlap(delg, k, amount)
+        cleang, cleandk = eng.k_overlapg(delg, k, dkdT, amount)
+        bad = k.copy()
+        bad[3, 4, 1, 2] = np.nan; bad[10, G - 1, 2, 0] = np.inf; bad[33, :, 4, 3] = np.nan
+        cells = [(3, 1), (10, 2), (33, 4)]
+        if keys == 64:
+            bad[20, 0, 3, 1] = -np.inf
+            cells.append((20, 3))
+        mask = np.ones((W, L), bool)
+        for w, l in cells:
+            mask[w, l] = False
+        with np.errstate(all="ignore"):
+            tau = eng.k_overlap(delg, bad, amount)
+            taug, dk = eng.k_overlapg(delg, bad, dkdT, amount)
+        assert np.array_equal(tau.transpose(0, 2, 1)[mask], clean.transpose(0, 2, 1)[mask])
+        assert np.array_equal(taug.transpose(0, 2, 1)[mask], cleang.transpose(0, 2, 1)[mask])
+        assert np.array_equal(dk.transpose(0, 2, 1, 3)[mask], cleandk.transpose(0, 2, 1, 3)[mask])
+        if keys == 32:      # a negative value: rerun on the generic path, still confined to its cell
+            bad[20, 0, 3, 1] = -np.inf
+            mask[20, 3] = False
+            with np.errstate(all="ignore"):
+                tau = eng.k_overlap(delg, bad, amount)
+            np.testing.assert_allclose(tau.transpose(0, 2, 1)[mask], clean.transpose(0, 2, 1)[mask], rtol=1e-12, atol=0)
+    finally:
+        eng.set_merge_keys(64)
+
+
+@pytest.mark.parametrize("G,S,f32,kind", [(20, 8, True, "lattice"), (20, 3, False, "flat"), (10, 4, True, "lattice"),
+                                           (16, 3, False, "mixed"), (32, 2, False, "lattice")])
+def test_k_overlap_float32_key_ties_vs_oracle(eng, oracle, G, S, f32, kind):
+    """The float32-key merge (k_ck_overlap32) on input made of heads whose float32 keys coincide: sums that differ by
+    1e-9 .. 1e-13 relative (all inside one float32 value), exactly equal sums, and a mix with ordinary columns.  The
+    exact-sum tie branch has to reproduce the reference's order: same tolerance as every other k_overlap test; and
+    the 64-bit-key kernel gives the same numbers."""
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(4242 + G + S)
+    W, L = 130, 3
+    _, delg = syn.gauss_legendre_01(G, f32)
+    g = np.arange(G, dtype=np.float64)[None, :, None, None]
+    if kind == "lattice":       # k_g = k0 (1 + g eps): every pair sum lies within 2 G eps of every other
+        eps = 10.0 ** rng.uniform(-13, -9, (W, 1, L, S))
+        k = 10.0 ** rng.uniform(-24, -21, (W, 1, L, S)) * (1.0 + g * eps)
+    elif kind == "flat":        # exact ties everywhere
+        k = np.repeat(10.0 ** rng.uniform(-24, -21, (W, 1, L, S)), G, axis=1)
+    else:
+        k = np.sort(10.0 ** rng.uniform(-25, -20, (W, G, L, S)), axis=1)
+        flat = rng.uniform(size=(W, 1, L, S)) < 0.4
+        k = np.where(flat, k[:, :1] * (1.0 + g * 1e-11), k)
+    amount = 10.0 ** rng.uniform(19, 22, (S, L))
+    ref = oracle.k_overlap(delg, k, amount)
+    eng.set_merge_keys(32)
+    try:
+        tau32 = eng.k_overlap(delg, k, amount)
+    finally:
+        eng.set_merge_keys(64)
+    eng.set_merge_keys(64)
+    tau64 = eng.k_overlap(delg, k, amount)
+    np.testing.assert_allclose(tau32, ref, rtol=1e-11, atol=0)
+    np.testing.assert_allclose(tau64, ref, rtol=1e-11, atol=0)
 
 
 def test_cirsrad_unsorted_table_vs_oracle(eng, oracle):
