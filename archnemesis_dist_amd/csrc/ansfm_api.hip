@@ -1634,6 +1634,32 @@ int ansfm_calc_tau_rayleigh(ansfm_ctx *ctx, int mode, int ISPACE, int W, const d
     return ANSFM_OK;
 }
 
+int ansfm_calc_tau_rayleigh_batch_dev(ansfm_ctx *ctx, int mode, int ISPACE, int n_models, int L, const double *TOTAM,
+                                      const double *f4, double *TAURAY_dev)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "calc_tau_rayleigh_batch_dev: upload a table first (its wavenumber grid is used)");
+    if (n_models <= 0 || L <= 0 || !TOTAM || !TAURAY_dev || (ISPACE != 0 && ISPACE != 1) ||
+        (mode != 1 && mode != 2 && mode != 4 && mode != 12) || (mode == 4 && !f4))
+        FAIL(ANSFM_ERR_INVALID, "calc_tau_rayleigh_batch_dev: bad argument (mode = IRAY 1, 2, 4 or 12 for calc_tau_rayleighv)");
+    if ((long)n_models * L > 65535) FAIL(ANSFM_ERR_UNSUPPORTED, "calc_tau_rayleigh_batch_dev: at most 65535 layers in a batch");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t D = sizeof(double), nl = (size_t)n_models * L;
+    const void *d[2] = {nullptr, nullptr};
+    int rc;
+    if ((rc = h2d(ctx, ctx->hb[1], TOTAM, nl * D, &d[0]))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[2], f4, mode == 4 ? nl * 4 * D : 0, &d[1]))) return rc;
+    RayParams p;
+    memset(&p, 0, sizeof p);
+    p.wavec = ctx->d_wave.as<double>(); p.totam = (const double *)d[0]; p.f4 = (const double *)d[1];
+    p.tau = TAURAY_dev; p.dtau = nullptr;
+    p.W = ctx->W; p.L = (int)nl; p.mode = mode; p.ispace = ISPACE; p.Lm = L;
+    hipLaunchKernelGGL(k_tau_rayleigh, dim3(nblk((size_t)ctx->W, 128), (unsigned)nl), dim3(128), 0, ctx->stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));       // the pinned-size host staging buffers are reused by the next call
+    return ANSFM_OK;
+}
+
 // not-a-knot cubic spline through (x, y[stride]) : per interval b, c, d of  y_a + t (b + t (c + t d)),  t = x - x_a
 static void notaknot_coeffs(int n, const double *x, const double *y, size_t stride, double *coef)
 {

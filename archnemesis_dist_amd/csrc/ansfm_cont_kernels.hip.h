@@ -103,8 +103,9 @@ struct RayParams {
     const double *wavec;        // [W] wavenumber (ISPACE 0) or wavelength in micron (ISPACE 1)
     const double *totam;        // [L]
     const double *f4;           // mode 4: [L][4] mixing ratios of H2, He, CH4, NH3 (0 where the gas is absent)
-    double *tau, *dtau;         // [W][L]
+    double *tau, *dtau;         // [W][L]  (batch: [n][W][Lm], the L = n * Lm layers of n states; dtau may be null)
     int W, L, mode, ispace;     // mode = IRAY (1, 2, 4); 12 = calc_tau_rayleighv
+    int Lm;                     // layers per state of a batch, 0 = one state
 };
 
 __global__ __launch_bounds__(128) void k_tau_rayleigh(RayParams p)
@@ -173,9 +174,9 @@ __global__ __launch_bounds__(128) void k_tau_rayleigh(RayParams p)
         const double fact = 8.0 * (PI * PI * PI) / (3.0 * (wl2 * wl2) * (losch * losch));
         k = fact * xc1 * 1.0E-8 / sumwt * 1.0e-4;
     }
-    const size_t o = (size_t)w * p.L + l;
+    const size_t o = p.Lm ? ((size_t)(l / p.Lm) * p.W + w) * p.Lm + (l % p.Lm) : (size_t)w * p.L + l;
     p.tau[o] = k * p.totam[l];
-    p.dtau[o] = k;
+    if (p.dtau) p.dtau[o] = k;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

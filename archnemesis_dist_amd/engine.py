@@ -460,6 +460,30 @@ class AnsfmEngine:
         self._check(rc, "calc_tau_rayleigh")
         return tau, dtau
 
+    def calc_tau_rayleigh_batch_dev(self, IRAY, ISPACE, TOTAM, out, ID=None, ISO=None, VMR=None, variant=None):
+        """calc_tau_rayleigh (:4869) for the n states of a batch on the uploaded table's wavenumber grid, left in HBM:
+        TOTAM (n, NLAY) host, VMR (n, NLAY, NVMR) host for IRAY 4, out = torch device tensor (n, NWAVE, NLAY) float64."""
+        TOTAM = _np(TOTAM)
+        n, L = TOTAM.shape
+        mode = 12 if variant == "v" else int(IRAY)
+        if mode not in (1, 2, 4, 12):
+            raise ValueError("error in CIRSrad :: IRAY = " + str(IRAY) + " type has not been implemented yet")
+        f4 = None
+        if mode == 4:
+            ID = np.asarray(ID); ISO = np.asarray(ISO); VMR = _np(VMR).reshape(n, L, -1)
+            f4 = np.zeros((n, L, 4))
+            for j in range(ID.size):                               # :5748-5767 (the last matching gas wins)
+                if ISO[j] in (0, 1):
+                    col = {39: 0, 40: 1, 6: 2, 11: 3}.get(int(ID[j]))
+                    if col is not None:
+                        f4[:, :, col] = VMR[:, :, j]
+            f4 = _np(f4)
+        if tuple(out.shape)[0] != n or tuple(out.shape)[2] != L or not out.is_contiguous():
+            raise ValueError("out must be a contiguous (n, NWAVE, NLAY) float64 device tensor")
+        rc = self._lib.ansfm_calc_tau_rayleigh_batch_dev(self._ctx, mode, int(ISPACE), n, L, _ptr(TOTAM), _ptr(f4), _ptr(out))
+        self._check(rc, "calc_tau_rayleigh_batch_dev")
+        return out
+
     def calc_tau_dust(self, WAVEC, SWAVE, KEXT, KSCA, CONT):
         """ForwardModel_0.calc_tau_dust (:4790): KEXT / KSCA (NWAVE_scatter, NDUST) on SWAVE, CONT (NLAY, NDUST) ->
         TAUDUST, TAUCLSCAT, dTAUDUSTdq, dTAUCLSCATdq (NWAVE, NLAY, NDUST)."""

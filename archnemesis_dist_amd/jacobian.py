@@ -69,6 +69,54 @@ def gather_columns(local_block, nfm, rank, world_size, group=None, force=False):
     return torch.cat(parts, dim=0)
 
 
+def finite_difference_jacobian_dev(allY, XN, inum, FIX=None):
+    """The same quotient on the device: allY torch (nfm, NY), row 0 the unperturbed spectrum -> YN (NY,), KK (NY, NX)
+    as NumPy arrays after ONE device-to-host copy of the assembled (NX_run + 1, NY) block."""
+    import torch
+    XN = np.asarray(XN, dtype=float)
+    xn1 = XN[inum] * 1.05
+    xn1[xn1 == 0.0] = 0.05
+    den = torch.as_tensor(xn1 - XN[inum], dtype=allY.dtype, device=allY.device)
+    block = torch.empty_like(allY)
+    block[0] = allY[0]
+    block[1:] = (allY[1:] - allY[0:1]) / den[:, None]
+    host = block.cpu().numpy()
+    KK = np.zeros((host.shape[1], XN.shape[0]))
+    keep = np.ones(len(inum), bool) if FIX is None else (np.asarray(FIX)[inum] == 0)
+    KK[:, np.asarray(inum)[keep]] = host[1:][keep].T
+    return host[0].copy(), KK
+
+
+def jacobian_nemesis_batched(model, rank=0, world_size=1, group=None, force_collective=False):
+    """jacobian_nemesis (ForwardModel_0.py:2184-2361, numerical part) with every forward model of a rank in ONE batched
+    call.  `model` offers the state (`model.state`: XN, NX, NUM, FIX, calc_DSTEP()) and `spectra_batch(X (n, NX)) ->
+    torch (n, NY)` on its GPU (profile_state.BatchedCKThermalModel).
+
+    Rank r of n takes the reference's contiguous chunk of the nfm = NX_run + 1 forward models (:2322-2330).  A rank whose
+    chunk does not start with the unperturbed state puts it in front of its batch all the same: the engine shares every
+    layer that is bit-identical to the FIRST state of a batch, and every perturbed state is one step away from the
+    unperturbed one, not from its neighbour.  One all_gather of the (nfm_local, NY) blocks (RCCL over xGMI when the
+    backend is nccl), then KK on the device and a single copy to the host."""
+    V = model.state
+    V.calc_DSTEP()
+    XN = np.array(V.XN, dtype=float)
+    xnx = perturbed_states(XN, V.DSTEP)
+    inum = np.where((np.ones_like(np.asarray(V.NUM)) == 1) & (np.asarray(V.FIX) == 0))[0]
+    nfm = len(inum) + 1
+    ixrun = np.zeros(nfm, dtype="int32")
+    ixrun[1:nfm] = inum[:] + 1
+    s, e = chunk_range(nfm, world_size, rank)
+    cols = list(ixrun[s:e])
+    lead = 0 if (s == 0 or e == s) else 1           # the unperturbed state as the batch's de-duplication reference
+    X = xnx[:, [0] * lead + cols].T                 # (lead + nfm_local, NX)
+    Y = model.spectra_batch(np.ascontiguousarray(X))
+    if Y is None:
+        raise RuntimeError(f"Something went wrong when calculating forward models {s + 1}-{e}/{nfm}.")        # :2177
+    block = Y[lead:]
+    allY = gather_columns(block, nfm, rank, world_size, group=group, force=force_collective)
+    return finite_difference_jacobian_dev(allY, XN, inum, FIX=np.asarray(V.FIX))
+
+
 def jacobian_nemesis_sharded(fm, rank=0, world_size=1, device=None, analytical_gradient=False, group=None, **flags):
     """Numerical Jacobian with the forward models sharded over ranks (one process per GPU).
 
@@ -81,6 +129,8 @@ def jacobian_nemesis_sharded(fm, rank=0, world_size=1, device=None, analytical_g
     `fm` needs: Variables.{XN, NX, NUM, FIX, calc_DSTEP(), DSTEP}, Measurement.{NY, NGEOM, NCONV}, nemesisfm().
     analytical_gradient=True defers to the reference's own jacobian_nemesis (nemesisfmg path)."""
     import torch
+    if hasattr(fm, "spectra_batch"):                # a batched model: one call per rank instead of one per column
+        return jacobian_nemesis_batched(fm, rank=rank, world_size=world_size, group=group)
     V, M = fm.Variables, fm.Measurement
     if analytical_gradient:
         return fm.jacobian_nemesis(analytical_gradient=True, **flags)

@@ -1,0 +1,141 @@
+"""State vector <-> atmosphere <-> spectra for a batch of states: what `ForwardModel_0.nemesisfm` does between
+`Variables.XN` and `SPECONV` (ForwardModel_0.py:437-589) for the configuration of BASELINE configs[2],
+evaluated for n states at once so that a numerical Jacobian is ONE batched call per GPU instead of nfm calls of
+nemesisfm (the reference fans them out to joblib workers, :2305-2337).
+
+    state vector  --subprofretg / model 0-->  T(level), VMR(level, gas)          host, a few kB per state
+                  --calc_path: layer_average (Curtis-Godson) + ray geometry-->   k_layer_average (one launch, all states)
+                  --calculate_layer_opacity: Rayleigh continuum-->               k_tau_rayleigh, stays in HBM
+                  --CIRSrad: calc_k + k_overlap + thermal emission-->            k_ck_overlap + k_thermal_rt, layers that
+                                                                                  equal the first state's are not recomputed
+Supported here: ILBL = K_TABLES, thermal emission, nadir / limb rays through AtmCalc_0's geometry, continuous-profile
+variables (Models/PreRTModels/model_0.py:35: temperature, ln volume mixing ratio), no hydrostatic re-adjustment
+(`adjust_hydrostat = False`), no instrument convolution (FWHM = 0 on the calculation grid).  Anything else keeps using
+the per-column route of jacobian.jacobian_nemesis_sharded.
+"""
+import numpy as np
+
+from . import layering
+
+SQ_CM_TO_SQ_METER = 1.0e-4       # ForwardModel_0.py:66
+
+
+class ContinuousProfileState:
+    """`Variables_0` restricted to model 0 blocks: every element of the state vector is the value of one atmospheric
+    profile at one level -- T itself for temperature, ln(value) for a volume mixing ratio
+    (model_0.py from_apr_to_state_vector: x0 = ref for temperature, log(ref) otherwise; subprofretg un-logs it,
+    ForwardModel_0.py:2397-2560).
+
+    H (m), P (Pa), T (K): (NPRO,); VMR (NPRO, NVMR); blocks: sequence of "T" or ("VMR", column)."""
+
+    def __init__(self, H, P, T, VMR, blocks):
+        self.H = np.asarray(H, float); self.P = np.asarray(P, float); self.T = np.asarray(T, float)
+        self.VMR = np.asarray(VMR, float)
+        self.NPRO = self.H.size
+        self.blocks = [("T", None) if b == "T" else ("VMR", int(b[1])) for b in blocks]
+        self.NX = self.NPRO * len(self.blocks)
+        xs = [self.T if kind == "T" else np.log(self.VMR[:, j]) for kind, j in self.blocks]
+        self.XN = np.concatenate(xs) if xs else np.zeros(0)
+        self.NUM = np.ones(self.NX, dtype=np.int32)      # jacobian_nemesis treats every element numerically here
+        self.FIX = np.zeros(self.NX, dtype=np.int32)
+        self.DSTEP = None
+
+    def calc_DSTEP(self):
+        """Variables_0.calc_DSTEP (:535): 5 % of each element."""
+        self.DSTEP = 0.05 * self.XN
+        return self.DSTEP
+
+    def profiles(self, X):
+        """X (n, NX) -> T (n, NPRO), VMR (n, NPRO, NVMR): the model-0 part of subprofretg for n states."""
+        X = np.atleast_2d(np.asarray(X, float))
+        n = X.shape[0]
+        T = np.repeat(self.T[None], n, 0)
+        VMR = np.repeat(self.VMR[None], n, 0)
+        for b, (kind, j) in enumerate(self.blocks):
+            xb = X[:, b * self.NPRO:(b + 1) * self.NPRO]
+            if kind == "T":
+                T = xb.copy()
+            else:
+                VMR[:, :, j] = np.exp(xb)
+        return T, VMR
+
+
+class BatchedCKThermalModel:
+    """nemesisfm for n states at once (see the module docstring).
+
+    eng: AnsfmEngine with the k-table uploaded (its wavenumber grid is the calculation grid).
+    state: ContinuousProfileState.  ID / ISO: gas identifiers of the VMR columns; igas_map (S,): VMR column of every
+    spectroscopic gas of the table (AtmosphereX.locate_gas, ForwardModel_0.py:3860).
+    layering: dict(NLAY, LAYTYP, LAYINT, LAYHT, LAYANG, NINT) of Layer_0; geometry: dict(pointing, BOTLAY, ANGLE,
+    EMISS_ANG, IPZEN) of AtmCalc_0.  IRAY as in calc_tau_rayleigh (0 = none); extra_continuum (W, L) is added to every
+    state (e.g. a fixed aerosol opacity)."""
+
+    def __init__(self, eng, state, RADIUS, ID, ISO, igas_map, layering_args=None, geometry=None, ISPACE=0, IRAY=0,
+                 TSURF=-1.0, extra_continuum=None, DUST=None, PARAH2=None):
+        self.eng, self.state = eng, state
+        self.RADIUS = float(RADIUS)
+        self.ID = np.asarray(ID); self.ISO = np.asarray(ISO)
+        self.igas_map = np.asarray(igas_map, dtype=np.int64)
+        la = dict(NLAY=20, LAYTYP=layering.EQUAL_LOG_PRESSURE, LAYINT=1, LAYHT=0.0, LAYANG=0.0, NINT=101)
+        la.update(layering_args or {})
+        self.lay = la
+        ge = dict(pointing=layering.NADIR, BOTLAY=0, ANGLE=0.0, EMISS_ANG=0.0, IPZEN=layering.IPZEN_BOTTOM)
+        ge.update(geometry or {})
+        self.geo = ge
+        self.ISPACE, self.IRAY, self.TSURF = int(ISPACE), int(IRAY), float(TSURF)
+        self.extra = None if extra_continuum is None else np.asarray(extra_continuum, float)
+        self.DUST, self.PARAH2 = DUST, PARAH2
+        dims, _ = eng.ktable_info()
+        self.W = int(dims[0])
+        # the layer grid is a property of the pressure-height profile, which no supported variable changes
+        self.BASEH, self.BASEP = layering.layer_split(self.RADIUS, state.H, state.P, LAYANG=la["LAYANG"], LAYHT=la["LAYHT"],
+                                                      NLAY=la["NLAY"], LAYTYP=la["LAYTYP"])
+        self.last_rows = (0, 0)
+
+    # ---- host part: subprofretg + calc_path for n states -------------------------------------------------------
+    def layers(self, X):
+        """X (n, NX) -> dict of per-state layer arrays (Layer_0 attributes after calc_layering) and the ray path."""
+        st, la = self.state, self.lay
+        T, VMR = st.profiles(X)
+        n = T.shape[0]
+        H = np.repeat(st.H[None], n, 0); P = np.repeat(st.P[None], n, 0)
+        out = self.eng.layer_average(self.RADIUS, H, P, T, self.ID, VMR, self.DUST, self.PARAH2, self.BASEH, self.BASEP,
+                                     LAYANG=la["LAYANG"], LAYINT=la["LAYINT"], LAYHT=la["LAYHT"], NINT=la["NINT"])
+        names = ("HEIGHT", "PRESS", "TEMP", "TOTAM", "AMOUNT", "PP", "CONT", "FRAC", "DELH", "BASET", "LAYSF")
+        lay = dict(zip(names, out))
+        ge = self.geo
+        lay["path"] = layering.calc_path(self.RADIUS, self.BASEH, lay["DELH"][0], lay["TEMP"], float(st.H[-1]),
+                                         pointing=ge["pointing"], BOTLAY=ge["BOTLAY"], ANGLE=ge["ANGLE"],
+                                         EMISS_ANG=ge["EMISS_ANG"], IPZEN=ge["IPZEN"])
+        # amount of every spectroscopic gas in molecule cm-2 (ForwardModel_0.py:3861)
+        lay["amount"] = np.ascontiguousarray(np.transpose(lay["AMOUNT"][:, :, self.igas_map], (0, 2, 1))) * SQ_CM_TO_SQ_METER
+        lay["VMRLAY"] = lay["PP"] / lay["PRESS"][:, :, None]          # Layer_0: PP / PRESS is the layer's mixing ratio
+        return lay
+
+    # ---- device part ------------------------------------------------------------------------------------------
+    def spectra_batch(self, X, device=None):
+        """Spectra of the n states X (n, NX): torch tensor (n, NY), NY = NWAVE * NPATH (path fastest like SPECOUT),
+        resident on the engine's device."""
+        import torch
+        eng = self.eng
+        lay = self.layers(X)
+        n, L = lay["PRESS"].shape
+        dev = torch.device("cuda", eng.device) if device is None else device
+        td = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        path = lay["path"]
+        P_, LIMAX = path.NPATH, path.LAYINC.shape[0]
+        cont = None
+        if self.IRAY != 0 or self.extra is not None:
+            cont = torch.zeros((n, self.W, L), dtype=torch.float64, device=dev)
+            if self.IRAY != 0:
+                eng.calc_tau_rayleigh_batch_dev(self.IRAY, self.ISPACE, lay["TOTAM"], cont, ID=self.ID, ISO=self.ISO,
+                                                VMR=lay["VMRLAY"])
+            if self.extra is not None:
+                cont += td(self.extra)[None]
+        out = torch.empty((n, self.W, P_), dtype=torch.float64, device=dev)
+        scale = np.repeat(path.SCALE[None], n, 0)
+        eng.cirsrad_ck_thermal_dev(self.ISPACE, n, L, td(lay["PRESS"]), td(lay["TEMP"]), td(lay["amount"]), cont, P_, LIMAX,
+                                   td(path.NLAYIN, torch.int32), td(path.LAYINC, torch.int32), td(scale), td(path.EMTEMP),
+                                   td(np.full(n, self.TSURF)), None, None, None, None, None, None, out)
+        self.last_rows = eng.last_layer_rows()
+        return out.reshape(n, self.W * P_)

@@ -84,3 +84,32 @@ def synth_continuum(W, L, seed=3, n_models=1):
     lv = np.linspace(0, 1, L)[None, :]
     base = 1e-3 * np.exp(-6.0 * lv) * (1.0 + 0.5 * np.sin(9.0 * wv + rng.uniform(0, 6.28)))
     return np.repeat(base[None], n_models, 0)
+
+
+# Jovian-like composition of the synthetic profile set: H2 and He carry the bulk (and the Rayleigh opacity, IRAY = 4),
+# the k-table gases are CH4, NH3 and trace species.  IDs are the radtran gas numbers the reference uses.
+PROFILE_GAS_ID = np.array([39, 40, 6, 11, 26, 27, 28, 32, 33, 41, 1, 2, 4, 5, 7, 8, 9, 10, 12, 13, 14, 15], dtype=np.int32)
+
+
+def synth_profiles(NPRO, NVMR, seed=11, p_bottom_bar=10.0, p_top_bar=1.0e-6):
+    """Reference-atmosphere profiles on NPRO levels (bottom -> top, like Atmosphere_0): H (m) from the hydrostatic
+    equation of an H2/He atmosphere (g = 24.8 m s-2), P (Pa), T (K) 110..400 K, VMR (NPRO, NVMR) with H2, He first and
+    NVMR - 2 absorbers (log-uniform 1e-9 .. 1e-3, mild vertical gradient).  Returns dict(H, P, T, VMR, ID, ISO, RADIUS)."""
+    if not 3 <= NVMR <= PROFILE_GAS_ID.size:
+        raise ValueError("synth_profiles: 3 <= NVMR <= %d" % PROFILE_GAS_ID.size)
+    rng = np.random.default_rng(seed)
+    p_bar = np.logspace(np.log10(p_bottom_bar), np.log10(p_top_bar), NPRO)
+    z = np.linspace(0.0, 1.0, NPRO)
+    T = 110.0 + 290.0 * (1.0 - z) ** 3 + 60.0 * z ** 2
+    scale_height = 8.314462618 * T / (2.3e-3 * 24.8)                       # R T / (mu g), m
+    dlnp = -np.diff(np.log(p_bar))
+    H = np.concatenate([[0.0], np.cumsum(0.5 * (scale_height[1:] + scale_height[:-1]) * dlnp)])
+    VMR = np.empty((NPRO, NVMR))
+    trace = 10.0 ** rng.uniform(-9, -3, NVMR - 2)
+    slope = rng.uniform(-0.5, 0.5, NVMR - 2)
+    VMR[:, 2:] = trace[None, :] * (p_bar[:, None] / p_bar[0]) ** (0.1 * slope[None, :])
+    rest = 1.0 - VMR[:, 2:].sum(axis=1)
+    VMR[:, 0] = 0.864 * rest
+    VMR[:, 1] = 0.136 * rest
+    return dict(H=H, P=p_bar * 1.0e5, T=T, VMR=VMR, ID=PROFILE_GAS_ID[:NVMR].copy(), ISO=np.zeros(NVMR, dtype=np.int32),
+                RADIUS=7.1492e7)

@@ -163,51 +163,46 @@ def main():
         elapsed = float(t.item())
     value = world * args.steps / elapsed
 
-    # ---- numerical Jacobian (C3): nj forward models sharded over ranks + one gather ---------------
-    # Every perturbed state differs from the base state in one layer element (jacobian_nemesis perturbs one state-vector
-    # element per forward model, :2234-2242).  Measured twice on the same states: every layer of every model merged
-    # (`wall_s_all_layers`), and with the engine's layer de-duplication (`wall_s`: layers bit-identical to the first
-    # model of the batch share its opacity rows; same spectra to the last bit, checked below).
+    # ---- numerical Jacobian (C3): NX = 2 L state vector, nfm = NX + 1 forward models, sharded + one gather -------
+    # jacobian_nemesis (ForwardModel_0.py:2184-2361) for a state vector of T at every level and ln VMR of the first
+    # absorber at every level (model 0, continuous profiles): every perturbed state goes through Curtis-Godson
+    # layer_average, the Rayleigh continuum and CIRSrad -- one batched call per rank (jacobian_nemesis_batched).  A level
+    # perturbation changes the few layers whose slant paths cross it; the engine recomputes only those
+    # (`layer_opacities_computed`).  Measured twice: with and without that de-duplication (same KK to the last bit).
     jac = None
+    model = None
     if not args.no_jacobian:
-        s, e = chunk_range(nj, world, rank)
-        nloc = e - s
-        sub = 16
-        d_cont_b = d_cont1.expand(nloc, W, L).contiguous()  # continuum is per-model in the ABI
-        out_b = torch.empty((nloc, W, P), dtype=f8, device=dev)
-        out_d = torch.empty((nloc, W, P), dtype=f8, device=dev)
+        from archnemesis_dist_amd.jacobian import jacobian_nemesis_batched
+        from archnemesis_dist_amd.profile_state import ContinuousProfileState, BatchedCKThermalModel
+        npro = (nj - 1) // 2
+        pr = syn.synth_profiles(npro, S + 2, seed=11)
+        st = ContinuousProfileState(pr["H"], pr["P"], pr["T"], pr["VMR"], ["T", ("VMR", 2)])
+        model = BatchedCKThermalModel(eng, st, pr["RADIUS"], pr["ID"], pr["ISO"], list(range(2, S + 2)),
+                                      layering_args=dict(NLAY=L, LAYINT=1, NINT=101), IRAY=4)
 
-        def run_jac(dedup, out):
+        def run_jac(dedup):
             eng.set_layer_dedup(dedup)
-            step_models = nloc if dedup else sub
-            rows = 0
             barrier()
             t0 = time.perf_counter()
-            for b0 in range(s, e, step_models):
-                b1 = min(e, b0 + step_models)
-                nb = b1 - b0
-                eng.cirsrad_ck_thermal_dev(0, nb, L, d_lp[b0:b1], d_lt[b0:b1], d_am[b0:b1],
-                                           d_cont_b[:nb], P, L, d_nlayin, d_layinc,
-                                           d_scale[b0:b1], d_emtemp[b0:b1], d_tsurf[b0:b1], None, None, None, None, None,
-                                           None, out[b0 - s:b1 - s])
-                rows += eng.last_layer_rows()[0]
-            spectra = gather_columns(out.reshape(nloc, W * P), nj, rank, world, force=use_dist)
+            YN, KK = jacobian_nemesis_batched(model, rank=rank, world_size=world, force_collective=use_dist)
             barrier()
             jt = time.perf_counter() - t0
             if use_dist:
                 t = torch.tensor([jt], dtype=f8, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 jt = float(t.item())
-            assert spectra.shape == (nj, W * P)
-            return jt, rows
+            return jt, model.last_rows, YN, KK
 
-        jt_all, rows_all = run_jac(False, out_b)
-        jt, rows = run_jac(True, out_d)
-        same = bool(torch.equal(out_b, out_d))
+        run_jac(True)                                   # warm-up: buffers of the batch sizes
+        jt_all, rows_all, YN_a, KK_a = run_jac(False)
+        jt, rows, YN_j, KK_j = run_jac(True)
         eng.set_layer_dedup(True)
-        jac = {"forward_models": nj, "wall_s": jt, "fm_per_s": nj / jt, "wall_s_all_layers": jt_all,
-               "layer_opacities_computed_rank0": rows, "layer_opacities_all_rank0": rows_all,
-               "dedup_bit_identical": same,
+        jac = {"forward_models": st.NX + 1, "state_vector": f"T and ln(VMR) of one absorber at {npro} levels (NX = {st.NX}), "
+               "through layer_average (Curtis-Godson, NINT 101) and the Rayleigh continuum",
+               "wall_s": jt, "fm_per_s": (st.NX + 1) / jt, "wall_s_all_layers": jt_all,
+               "layer_opacities_computed_rank0": int(rows[0]), "layer_opacities_all_rank0": int(rows_all[0]),
+               "dedup_bit_identical": bool(np.array_equal(KK_a, KK_j) and np.array_equal(YN_a, YN_j)),
+               "kk_shape": list(KK_j.shape),
                "collective": "all_gather_into_tensor (RCCL)" if use_dist else None}
 
     if rank != 0:
@@ -268,6 +263,20 @@ def main():
                           f"({Wc} wavenumbers x {L} layers x {S} gases, G={G}) through oracle/ansfm_oracle.c, OpenMP over "
                           f"wavenumbers, {ct:.2f} s wall x {cores} threads" + ("" if Wc == W else f"; value scaled by {Wc}/{W}")),
                "gpu_vs_oracle_max_rel_err_on_sample": perr}
+
+    # ---- C3 check: a sample of KK columns against the reference's recipe run on the oracle's forward models -------
+    if do_cpu and jac is not None:
+        from oracle import jacobian_twin as twin
+        cols = np.array([npro // 8, npro // 2, npro + npro // 4, 2 * npro - 5])
+        t0 = time.perf_counter()
+        y0, kk = twin.jacobian(model, K_sample, PRESS, TEMP, WAVE[:Wc], delg, columns=cols)
+        sc = np.max(np.abs(kk), axis=0)
+        sc = np.maximum(sc, 1.0e-6 * float(np.max(np.abs(KK_j))))       # a column without sensitivity is rounding noise
+        nyc = kk.shape[0]
+        jac["kk_max_rel_err_vs_oracle"] = float(np.max(np.abs(KK_j[:nyc, cols] - kk) / sc))
+        jac["yn_max_rel_err_vs_oracle"] = float(np.max(np.abs(YN_j[:nyc] - y0) / np.abs(y0)))
+        jac["oracle_sample"] = (f"columns {cols.tolist()} of KK ({len(cols) + 1} oracle forward models at "
+                                f"{Wc} wavenumbers, {time.perf_counter() - t0:.1f} s); error relative to each column's maximum")
 
     line = {
         "metric": "forward-models/sec (10k nu x 100 layers)", "value": value, "unit": "forward-models/s",

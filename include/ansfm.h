@@ -359,6 +359,12 @@ int ansfm_calc_tau_cia(ansfm_ctx *ctx, int W, const double *WAVEN, int NWC, cons
 int ansfm_calc_tau_rayleigh(ansfm_ctx *ctx, int mode, int ISPACE, int W, const double *WAVEC, int L,
                             const double *TOTAM, const double *f4, double *TAURAY, double *dTAURAY);
 
+/* calc_tau_rayleigh for the n states of a Jacobian batch, on the uploaded table's wavenumber grid, left in HBM:
+ * TOTAM[n][L] and (mode 4) f4[n][L][4] are host arrays (a few kB per state), TAURAY_dev[n][W][L] is a DEVICE pointer in
+ * the layout ansfm_cirsrad_ck_thermal_dev takes as taucont (8 MB per state at C2 that never cross PCIe). */
+int ansfm_calc_tau_rayleigh_batch_dev(ansfm_ctx *ctx, int mode, int ISPACE, int n_models, int L, const double *TOTAM,
+                                      const double *f4, double *TAURAY_dev);
+
 /* ForwardModel_0.calc_tau_dust (ForwardModel_0.py:4790): KEXT / KSCA[NWS][NDUST] tabulated on SWAVE[NWS] (Scatter.WAVE,
  * strictly ascending) interpolated to WAVEC[W] like scipy interp1d(kind='cubic') (not-a-knot spline; linear when
  * NWS == 2; NWS == 3 is refused as scipy refuses it), out-of-range values replaced by the linear interpolant

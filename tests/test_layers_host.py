@@ -1,4 +1,4 @@
-"""Host-side layering / path geometry (archnemesis_dist_amd.layers) vs goldens from the reference's
+"""Host-side layering / path geometry (archnemesis_dist_amd.layering) vs goldens from the reference's
 Layer_0.layer_split and AtmCalc_0."""
 import os
 import numpy as np
@@ -6,7 +6,7 @@ import pytest
 
 
 def test_layer_split(golden_dir):
-    from archnemesis_dist_amd import layers
+    from archnemesis_dist_amd import layering as layers
     z = np.load(os.path.join(golden_dir, "layer_average.npz"))
     for typ in range(4):
         bh, bp = layers.layer_split(float(z["RADIUS"]), z["H"], z["P"], LAYANG=20.0, LAYHT=-6.0e4, NLAY=17, LAYTYP=typ)
@@ -18,7 +18,7 @@ def test_layer_split(golden_dir):
 
 
 def test_calc_path(golden_dir):
-    from archnemesis_dist_amd import layers
+    from archnemesis_dist_amd import layering as layers
     z = np.load(os.path.join(golden_dir, "path_geometry.npz"))
     for n in z["names"]:
         n = str(n)

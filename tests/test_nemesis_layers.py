@@ -28,7 +28,7 @@ def _check_nemesis(z, BASEH, BASEP, r):
 
 
 def _split(z):
-    from archnemesis_dist_amd import layers
+    from archnemesis_dist_amd import layering as layers
     kw = {k[len("split_kw_"):]: z[k] for k in z.files if k.startswith("split_kw_")}
     return layers.layer_split(float(kw["RADIUS"]), kw["H"], kw["P"], LAYANG=float(kw["LAYANG"]), LAYHT=float(kw["LAYHT"]),
                               NLAY=int(kw["NLAY"]), LAYTYP=int(kw["LAYTYP"]))
