@@ -73,6 +73,7 @@ struct ansfm_ctx {
     int dspec_dims[4] = {0, 0, 0, 0};   // W, NPAR, LIMAX, P of dspec_ref (single-model cirsradg result)
     int map_dims[4] = {0, 0, 0, 0};     // W, NPAR, NPRO, P of map_out
     DevBuf gscratch, perm, dkbuf, trold_ws, dspec_i, dcont_t, tmp_in2, tmp_out2, lbl_li;
+    DevBuf ms_taus, ms_omegas, ms_bnu;   // scattering branch of CIRSrad: TAUTOT / OMEGA (W,G,L) and BB (W,L) in HBM
     DevBuf hb[24];  // staging buffers of the host-pointer entry points
     int last_n = 0, last_L = 0;
 
@@ -142,7 +143,7 @@ void ansfm_destroy(ansfm_ctx *ctx)
     DevBuf *bufs[] = {&ctx->lnK, &ctx->d_press, &ctx->d_temp, &ctx->d_wave, &ctx->d_delg, &ctx->d_flag,
                       &ctx->li, &ctx->tau, &ctx->scratch, &ctx->cont_t, &ctx->tmp_in, &ctx->tmp_out,
                       &ctx->misc, &ctx->gscratch, &ctx->dkbuf, &ctx->trold_ws, &ctx->dspec_i, &ctx->dcont_t,
-                      &ctx->tmp_in2, &ctx->tmp_out2, &ctx->lbl_li};
+                      &ctx->tmp_in2, &ctx->tmp_out2, &ctx->lbl_li, &ctx->ms_taus, &ctx->ms_omegas, &ctx->ms_bnu};
     for (auto *b : bufs) b->release();
     for (auto &b : ctx->hb) b.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1810,44 +1811,19 @@ int ansfm_kdist_bins(ansfm_ctx *ctx, int ncalc, const double *wavecalc, const do
 /* ------------------------------------------------------------------------------------------ */
 /* multiple scattering                                                                         */
 /* ------------------------------------------------------------------------------------------ */
-int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const double *phasarr, const double *radg,
-                            int ngeom, const double *sol_angs, const double *emiss_angs, const double *solar,
-                            const double *aphis, int lowbc, const double *brdf_matrix, int nmu, const double *mu1,
-                            const double *wt1, int nf, const double *bnu, int ng, int nlay, const double *taus,
-                            const double *tauray, const double *omegas_s, int nphi, int iray, int imie,
-                            const double *lfrac, double *rad)
+// The kernels of scloud11wave_core on device-resident inputs: p holds the nine input pointers; dims, quadrature and
+// angles are filled in here.  Leaves rad[ngeom][ng][nwave] in ctx->tmp_out (asynchronous).
+static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth, int ngeom, const double *sol_angs,
+                     const double *emiss_angs, const double *aphis, int lowbc, int nmu, const double *mu1, const double *wt1,
+                     int nf, int ng, int nlay, int nphi, int iray, int imie)
 {
-    CHECK_CTX(ctx);
-    if (ncont < 0 || nwave <= 0 || ngeom <= 0 || nmu < 2 || nf < 0 || ng <= 0 || nlay <= 0 || nphi <= 0 || !radg ||
-        !sol_angs || !emiss_angs || !solar || !aphis || !brdf_matrix || !mu1 || !wt1 || !bnu || !taus || !tauray ||
-        !omegas_s || !rad || (ncont > 0 && (!phasarr || !lfrac || nth < 3)))
-        FAIL(ANSFM_ERR_INVALID, "scloud11wave_core: bad argument");
     if (nmu > 20 || ngeom > kMsMaxPath || ncont > 60)
         FAIL(ANSFM_ERR_UNSUPPORTED, "scloud11wave_core: nmu <= 20, npath <= 16 per call supported");
     int nless = 0, nmore = 0;
     for (int i = 0; i < ngeom; ++i) { if (emiss_angs[i] < 90) ++nless; if (emiss_angs[i] > 90) ++nmore; }
     if (nless != ngeom && nmore != ngeom)
         FAIL(ANSFM_ERR_INVALID, "Emission angles are a mix of values above and below 90 degrees.");   // :776
-    HIPCHK(hipSetDevice(ctx->device));
-    MsParams p;
-    memset(&p, 0, sizeof p);
     const size_t D = sizeof(double);
-    const void *d[10];
-    int i = 0, rc;
-#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
-    UP(phasarr, (size_t)ncont * nwave * 2 * nth * D);           // 0
-    UP(radg, (size_t)nwave * nmu * D);                          // 1
-    UP(solar, (size_t)nwave * D);                               // 2
-    UP(brdf_matrix, (size_t)nwave * nmu * nmu * (nf + 1) * D);  // 3
-    UP(bnu, (size_t)nwave * nlay * D);                          // 4
-    UP(taus, (size_t)nwave * ng * nlay * D);                    // 5
-    UP(tauray, (size_t)nwave * nlay * D);                       // 6
-    UP(omegas_s, (size_t)nwave * ng * nlay * D);                // 7
-    UP(lfrac, (size_t)nwave * ncont * nlay * D);                // 8
-#undef UP
-    p.phasarr = (const double *)d[0]; p.radg = (const double *)d[1]; p.solar = (const double *)d[2];
-    p.brdf = (const double *)d[3]; p.bnu = (const double *)d[4]; p.taus = (const double *)d[5];
-    p.tauray = (const double *)d[6]; p.omegas = (const double *)d[7]; p.lfrac = (const double *)d[8];
     p.ncont = ncont; p.ncomp = ncont + 1; p.nwave = nwave; p.nth = nth; p.ngeom = ngeom; p.lowbc = lowbc; p.nmu = nmu;
     p.nf = nf; p.ng = ng; p.nlay = nlay; p.nphi = nphi; p.iray = iray; p.imie = imie;
     p.lookup = (nmore == ngeom) ? 1 : 0;
@@ -1891,7 +1867,142 @@ int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const
     const size_t tot = (size_t)nwave * ng * ngeom;
     hipLaunchKernelGGL(k_ms_fourier, dim3(nblk(tot, 128)), dim3(128), 0, ctx->stream, p);
     HIPCHK(hipGetLastError());
+    return ANSFM_OK;
+}
+
+int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const double *phasarr, const double *radg,
+                            int ngeom, const double *sol_angs, const double *emiss_angs, const double *solar,
+                            const double *aphis, int lowbc, const double *brdf_matrix, int nmu, const double *mu1,
+                            const double *wt1, int nf, const double *bnu, int ng, int nlay, const double *taus,
+                            const double *tauray, const double *omegas_s, int nphi, int iray, int imie,
+                            const double *lfrac, double *rad)
+{
+    CHECK_CTX(ctx);
+    if (ncont < 0 || nwave <= 0 || ngeom <= 0 || nmu < 2 || nf < 0 || ng <= 0 || nlay <= 0 || nphi <= 0 || !radg ||
+        !sol_angs || !emiss_angs || !solar || !aphis || !brdf_matrix || !mu1 || !wt1 || !bnu || !taus || !tauray ||
+        !omegas_s || !rad || (ncont > 0 && (!phasarr || !lfrac || nth < 3)))
+        FAIL(ANSFM_ERR_INVALID, "scloud11wave_core: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    MsParams p;
+    memset(&p, 0, sizeof p);
+    const size_t D = sizeof(double);
+    const void *d[10];
+    int i = 0, rc;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(phasarr, (size_t)ncont * nwave * 2 * nth * D);           // 0
+    UP(radg, (size_t)nwave * nmu * D);                          // 1
+    UP(solar, (size_t)nwave * D);                               // 2
+    UP(brdf_matrix, (size_t)nwave * nmu * nmu * (nf + 1) * D);  // 3
+    UP(bnu, (size_t)nwave * nlay * D);                          // 4
+    UP(taus, (size_t)nwave * ng * nlay * D);                    // 5
+    UP(tauray, (size_t)nwave * nlay * D);                       // 6
+    UP(omegas_s, (size_t)nwave * ng * nlay * D);                // 7
+    UP(lfrac, (size_t)nwave * ncont * nlay * D);                // 8
+#undef UP
+    p.phasarr = (const double *)d[0]; p.radg = (const double *)d[1]; p.solar = (const double *)d[2];
+    p.brdf = (const double *)d[3]; p.bnu = (const double *)d[4]; p.taus = (const double *)d[5];
+    p.tauray = (const double *)d[6]; p.omegas = (const double *)d[7]; p.lfrac = (const double *)d[8];
+    if ((rc = ms_launch(ctx, p, ncont, nwave, nth, ngeom, sol_angs, emiss_angs, aphis, lowbc, nmu, mu1, wt1, nf, ng, nlay,
+                        nphi, iray, imie)))
+        return rc;
     HIPCHK(hipMemcpyAsync(rad, ctx->tmp_out.p, (size_t)ngeom * ng * nwave * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+int ansfm_cirsrad_ck_scatter(ansfm_ctx *ctx, int ISPACE, int L, const double *lay_press_pa, const double *lay_temp,
+                             const double *amount, const double *taucia, const double *taudust, const double *tauray,
+                             const double *tauscat, int ncont, int nth, const double *phasarr, const double *lfrac,
+                             const double *radg, int ngeom, const double *sol_angs, const double *emiss_angs,
+                             const double *aphis, const double *solar, int lowbc, const double *brdf_matrix, int nmu,
+                             const double *mu1, const double *wt1, int nf, int nphi, int iray, int imie, const double *xfac,
+                             double *SPECOUT, double *SPEC_G)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "cirsrad_ck_scatter: upload a k-table first");
+    if (ctx->is_lbl) FAIL(ANSFM_ERR_UNSUPPORTED, "cirsrad_ck_scatter: k-tables only (ILBL = K_TABLES)");
+    if (L <= 0 || !lay_press_pa || !lay_temp || !amount || ncont < 0 || ngeom <= 0 || nmu < 2 || nf < 0 || nphi <= 0 || !radg ||
+        !sol_angs || !emiss_angs || !aphis || !solar || !brdf_matrix || !mu1 || !wt1 || !SPECOUT ||
+        (ISPACE != 0 && ISPACE != 1) || (ncont > 0 && (!phasarr || !lfrac || nth < 3)))
+        FAIL(ANSFM_ERR_INVALID, "cirsrad_ck_scatter: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, S = ctx->S;
+    const size_t D = sizeof(double), WL = (size_t)W * L;
+    const void *d[14];
+    int i = 0, rc;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(lay_press_pa, (size_t)L * D);                            // 0
+    UP(lay_temp, (size_t)L * D);                                // 1
+    UP(amount, (size_t)S * L * D);                              // 2
+    UP(taucia, WL * D);                                         // 3
+    UP(taudust, WL * D);                                        // 4
+    UP(tauray, WL * D);                                         // 5
+    UP(tauscat, WL * D);                                        // 6
+    UP(phasarr, (size_t)ncont * W * 2 * nth * D);               // 7
+    UP(lfrac, (size_t)W * ncont * L * D);                       // 8
+    UP(radg, (size_t)W * nmu * D);                              // 9
+    UP(solar, (size_t)W * D);                                   // 10
+    UP(brdf_matrix, (size_t)W * nmu * nmu * (nf + 1) * D);      // 11
+    UP(xfac, (size_t)W * D);                                    // 12
+#undef UP
+    // ---- vertical gas opacities: calc_k + k_overlap (:3855-3874), as in the thermal branch --------------------------
+    HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx->li.reserve((size_t)L * sizeof(LayerInterp)));
+    HIPCHK(ctx->tau.reserve((size_t)L * G * Wpad * D));
+    HIPCHK(ctx->ms_taus.reserve(WL * G * D));
+    HIPCHK(ctx->ms_omegas.reserve(WL * G * D));
+    HIPCHK(ctx->ms_bnu.reserve(WL * D));
+    // the chain kernels read TAURAY per (wavenumber, layer) even when there is none
+    const double *d_tauray = (const double *)d[5];
+    if (!d_tauray) {
+        HIPCHK(ctx->cont_t.reserve(WL * D));
+        HIPCHK(hipMemsetAsync(ctx->cont_t.p, 0, WL * D, ctx->stream));
+        d_tauray = ctx->cont_t.as<double>();
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        ctx->force_generic = pass;       // pass 1 only if the fast merge met an unsorted k-distribution
+        hipLaunchKernelGGL(k_layer_prep, dim3(nblk((size_t)L, 128)), dim3(128), 0, ctx->stream, L, (const double *)d[0],
+                           (const double *)d[1], ctx->NP, ctx->d_press.as<double>(), ctx->NT, ctx->d_temp.as<double>(),
+                           101325.0, ctx->grid_f32, ctx->li.as<LayerInterp>());
+        HIPCHK(hipGetLastError());
+        if (pass) HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+        rc = launch_overlap(ctx, false, nullptr, W, Wpad, G, S, L, 1, ctx->li.as<LayerInterp>(), (const double *)d[2],
+                            ctx->d_delg.as<double>(), ctx->h_delg.data(), ctx->tau.as<double>());
+        ctx->force_generic = 0;
+        if (rc) return rc;
+        int flag = 0;
+        if ((rc = read_unsorted(ctx, &flag))) return rc;
+        if (!flag) break;
+    }
+    ctx->last_n = 1; ctx->last_L = L; ctx->last_rows = L; ctx->last_dedup = 0;
+    // ---- TAUTOT, OMEGA, BB -----------------------------------------------------------------------------------------
+    MsOpticsParams o;
+    memset(&o, 0, sizeof o);
+    o.taugas = ctx->tau.as<double>(); o.taucia = (const double *)d[3]; o.taudust = (const double *)d[4];
+    o.tauray = (const double *)d[5]; o.tauscat = (const double *)d[6];
+    o.wave = ctx->d_wave.as<double>(); o.lay_temp = (const double *)d[1];
+    o.taus = ctx->ms_taus.as<double>(); o.omegas = ctx->ms_omegas.as<double>(); o.bnu = ctx->ms_bnu.as<double>();
+    o.W = W; o.Wpad = Wpad; o.G = G; o.L = L; o.ispace = ISPACE;
+    hipLaunchKernelGGL(k_ms_optics, dim3(nblk((size_t)W, 128), (unsigned)L), dim3(128), 0, ctx->stream, o);
+    HIPCHK(hipGetLastError());
+    // ---- doubling / adding ------------------------------------------------------------------------------------------
+    MsParams p;
+    memset(&p, 0, sizeof p);
+    p.phasarr = (const double *)d[7]; p.radg = (const double *)d[9]; p.solar = (const double *)d[10];
+    p.brdf = (const double *)d[11]; p.bnu = o.bnu; p.taus = o.taus; p.tauray = d_tauray; p.omegas = o.omegas;
+    p.lfrac = (const double *)d[8];
+    if ((rc = ms_launch(ctx, p, ncont, W, nth, ngeom, sol_angs, emiss_angs, aphis, lowbc, nmu, mu1, wt1, nf, G, L, nphi,
+                        iray, imie)))
+        return rc;
+    // ---- g-quadrature (:4504) ----------------------------------------------------------------------------------------
+    const size_t nspec = (size_t)W * ngeom;
+    HIPCHK(ctx->tmp_out2.reserve(nspec * (1 + (size_t)G) * D));
+    double *d_spec = ctx->tmp_out2.as<double>(), *d_specg = SPEC_G ? d_spec + nspec : nullptr;
+    hipLaunchKernelGGL(k_ms_gquad, dim3(nblk(nspec, 128)), dim3(128), 0, ctx->stream, ctx->tmp_out.as<double>(),
+                       ctx->d_delg.as<double>(), (const double *)d[12], d_spec, d_specg, W, G, ngeom);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(SPECOUT, d_spec, nspec * D, hipMemcpyDeviceToHost, ctx->stream));
+    if (SPEC_G) HIPCHK(hipMemcpyAsync(SPEC_G, d_specg, nspec * G * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ANSFM_OK;
 }

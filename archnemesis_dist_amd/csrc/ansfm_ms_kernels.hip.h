@@ -900,4 +900,62 @@ __global__ void k_ms_fourier(MsParams p)
     p.rad[((size_t)ipath * p.ng + ig) * p.nwave + widx] = rad;
 }
 
+
+// ---- scattering branch of CIRSrad on the device -----------------------------------------------------------------------
+// calculate_layer_opacity (ForwardModel_0.py:3989) and the host preparation of scloud11wave (:5099-5119) for the arrays that
+// have a g axis: TAUTOT = TAUGAS + TAUCIA + TAUDUST + TAURAY, OMEGA = (TAURAY + TAUSCAT) / TAUTOT where TAUTOT > 0, and
+// BB = planck(TEMP) -- from the merge kernel's [L][G][Wpad] gas opacities straight into the layouts the chain kernels
+// read, so that TAUGAS / TAUTOT / OMEGA (NWAVE x NG x NLAY each) never leave HBM.  One thread per (wavenumber, layer).
+struct MsOpticsParams {
+    const double *taugas;       // [L][G][Wpad]
+    const double *taucia;       // [W][L] or null
+    const double *taudust;      // [W][L] aerosol extinction summed over the populations, or null
+    const double *tauray;       // [W][L] or null
+    const double *tauscat;      // [W][L] or null
+    const double *wave;         // [W]
+    const double *lay_temp;     // [L]
+    double *taus, *omegas;      // [W][G][L]
+    double *bnu;                // [W][L]
+    int W, Wpad, G, L, ispace;
+};
+
+__global__ __launch_bounds__(128) void k_ms_optics(MsOpticsParams p)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (w >= p.W) return;
+    const size_t wl = (size_t)w * p.L + l;
+    const double cia = p.taucia ? p.taucia[wl] : 0.0, dust = p.taudust ? p.taudust[wl] : 0.0;
+    const double ray = p.tauray ? p.tauray[wl] : 0.0, sca = p.tauscat ? p.tauscat[wl] : 0.0;
+    for (int g = 0; g < p.G; ++g) {
+        const double tt = ((p.taugas[((size_t)l * p.G + g) * p.Wpad + w] + cia) + dust) + ray;      // the sum order of :3989
+        const size_t o = ((size_t)w * p.G + g) * p.L + l;
+        p.taus[o] = tt;
+        p.omegas[o] = (tt > 0.0) ? (ray + sca) / tt : 0.0;
+    }
+    const double c1 = 1.1911e-12, c2 = 1.439;                     // ForwardModel_0.py:6214-6215
+    const double wv = p.wave[w];
+    double y, a;
+    if (p.ispace == 0) { y = wv; a = c1 * (y * y * y); }
+    else { y = 1.0e4 / wv; a = c1 * (y * y * y * y * y) / 1.0e4; }
+    p.bnu[wl] = a / (exp(c2 * y / p.lay_temp[l]) - 1.0);
+}
+
+// CIRSrad's g-quadrature of the scattering branch (:4504): SPECOUT[w][path] = xfac[w] * sum_g rad[path][g][w] * DELG[g];
+// the radiances before the quadrature go out as well when wanted (spec_g[w][g][path], what scloud11wave returns).
+__global__ void k_ms_gquad(const double *__restrict__ rad, const double *__restrict__ delg, const double *__restrict__ xfac,
+                           double *__restrict__ specout, double *__restrict__ spec_g, int W, int G, int P)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)W * P) return;
+    const int ip = (int)(idx % P), w = (int)(idx / P);
+    const double xf = xfac ? xfac[w] : 1.0;
+    double acc = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const double r = rad[((size_t)ip * G + g) * W + w] * xf;
+        if (spec_g) spec_g[((size_t)w * G + g) * P + ip] = r;
+        acc += r * delg[g];
+    }
+    specout[idx] = acc;
+}
+
 }  // namespace ansfm

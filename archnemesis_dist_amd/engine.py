@@ -285,6 +285,35 @@ class AnsfmEngine:
         self._check(rc, "scloud11wave_core")
         return rad
 
+    def cirsrad_ck_scatter(self, ISPACE, lay_press_pa, lay_temp, amount, TAUCIA, TAUDUST, TAURAY, TAUSCAT, phasarr, lfrac,
+                           radg, sol_angs, emiss_angs, aphis, solar, lowbc, brdf_matrix, mu1, wt1, nf, nphi, iray, imie,
+                           xfac=None, return_spec_g=False):
+        """CIRSrad, scattering branch (ForwardModel_0.py:4478-4501, :4343, scloud11wave :5018-5165) on the uploaded k-table:
+        vertical gas opacities, TAUTOT, OMEGA and BB are formed in HBM and go straight into the doubling / adding kernels.
+        TAUCIA / TAUDUST / TAURAY / TAUSCAT (NWAVE, NLAY) or None; phasarr (NDUST, NWAVE, 2, NTHETA) and lfrac (NWAVE, NDUST,
+        NLAY) as scloud11wave_core takes them -> SPECOUT (NWAVE, NPATH) [, SPEC (NWAVE, NG, NPATH)]."""
+        dims, _ = self.ktable_info()
+        W, G, S = dims[0], dims[1], dims[4]
+        lay_press_pa = _np(lay_press_pa); L = lay_press_pa.shape[0]
+        amount = _np(amount)
+        if amount.shape != (S, L):
+            raise ValueError("amount must be (NGAS, NLAY)")
+        wl = lambda a: None if a is None else _np(a).reshape(W, L)
+        phasarr = None if phasarr is None else _np(phasarr)
+        ncont = 0 if phasarr is None else phasarr.shape[0]
+        nth = 0 if phasarr is None else phasarr.shape[3]
+        sol = _np(np.atleast_1d(sol_angs)); emi = _np(np.atleast_1d(emiss_angs)); aph = _np(np.atleast_1d(aphis))
+        P = sol.shape[0]
+        mu1 = _np(mu1); nmu = mu1.shape[0]
+        out = np.empty((W, P)); spec_g = np.empty((W, G, P)) if return_spec_g else None
+        rc = self._lib.ansfm_cirsrad_ck_scatter(
+            self._ctx, int(ISPACE), L, _ptr(lay_press_pa), _ptr(_np(lay_temp)), _ptr(amount), _ptr(wl(TAUCIA)), _ptr(wl(TAUDUST)),
+            _ptr(wl(TAURAY)), _ptr(wl(TAUSCAT)), ncont, nth, _ptr(phasarr), _ptr(_np(lfrac)), _ptr(_np(radg)), P, _ptr(sol),
+            _ptr(emi), _ptr(aph), _ptr(_np(solar)), int(lowbc), _ptr(_np(brdf_matrix)), nmu, _ptr(mu1), _ptr(_np(wt1)), int(nf),
+            int(nphi), int(iray), int(imie), _ptr(_np(xfac)), _ptr(out), _ptr(spec_g))
+        self._check(rc, "cirsrad_ck_scatter")
+        return (out, spec_g) if return_spec_g else out
+
     def add_line_set_monochromatic_absorption(self, wn_grid, lineshape_id, t_calc, t_ref, p_calc, p_ref, q_ratio,
                                               isotopic_abundance, isotopic_mass, mol_mix_frac, broadening_params, nu, sw,
                                               e_lower, stimulated_emission_at_t_ref, out, store=None, s_floor=0.0,

@@ -22,6 +22,7 @@ ILBL_K_TABLES = 0                      # SpectralCalculationModeEnum.K_TABLES
 ILBL_LBL_TABLES = 2                    # SpectralCalculationModeEnum.LINE_BY_LINE_TABLES
 IMOD_THERMAL_EMISSION = 64             # PathCalcEnum.THERMAL_EMISSION
 IMOD_MULTIPLE_SCATTERING = 256
+IMOD_DOWNWARD_FLUX = 16
 IMOD_SINGLE_SCATTERING_PLANE_PARALLEL = 1024
 IMOD_ABSORBTION = 4096
 IFORM_FLUXRATIO = 1                    # SpectraUnitEnum.FluxRatio
@@ -29,6 +30,19 @@ ATM_TO_PASCAL = 101325.0               # ForwardModel_0.py:61
 SQ_CM_TO_SQ_METER = 1.0e-4             # ForwardModel_0.py:66
 
 _ENGINES = {}
+
+
+def _planck(ispace, wave, temp):
+    """planck (ForwardModel_0.py:6183-6227): W cm-2 sr-1 (cm-1)-1 for wavenumbers (ISPACE 0), W cm-2 sr-1 um-1 for
+    wavelengths in micron (ISPACE 1); c1 = 1.1911e-12, c2 = 1.439 as there."""
+    wave = np.asarray(wave, dtype=np.float64)
+    c1, c2 = 1.1911e-12, 1.439
+    if int(ispace) == 0:
+        y, a = wave, c1 * wave ** 3
+    else:
+        y = 1.0e4 / wave
+        a = c1 * y ** 5 / 1.0e4
+    return a / (np.exp(c2 * y / temp) - 1.0)
 
 
 def get_engine(device=0):
@@ -132,10 +146,20 @@ class CIRSradGPU:
         if imod.size != 1:
             return False
         imod = int(imod[0])
-        # dispatch order of CIRSrad :4478-4489: transmission / absorption come before thermal emission
-        if not (imod & IMOD_THERMAL_EMISSION) or (imod & IMOD_ABSORBTION):
+        # dispatch order of CIRSrad :4478-4501: transmission / absorption come before thermal emission, thermal emission
+        # before single scattering, the downward-flux variant before plain multiple scattering
+        if imod & IMOD_ABSORBTION:
             return False
-        return True
+        if imod & IMOD_THERMAL_EMISSION:
+            return True
+        if self._ansfm_scatter_branch(imod):
+            return (not return_grad) and int(S.ILBL) == ILBL_K_TABLES      # the reference has no gradients there either
+        return False
+
+    @staticmethod
+    def _ansfm_scatter_branch(imod):
+        return bool(imod & IMOD_MULTIPLE_SCATTERING) and not (
+            imod & (IMOD_ABSORBTION | IMOD_THERMAL_EMISSION | IMOD_SINGLE_SCATTERING_PLANE_PARALLEL | IMOD_DOWNWARD_FLUX))
 
     # ---- continuum opacities: the reference's own host routines when present ---------------------
     def _ansfm_continuum(self, return_grad=False):
@@ -157,8 +181,8 @@ class CIRSradGPU:
             if return_grad:
                 dTAUCON = np.zeros((S.NWAVE, A.NVMR + 2 + Sc.NDUST, L.NLAY))
                 if dTAUCIA is not None:                                           # :3940-3942
-                    dTAUCON[:, 0:A.NVMR, :] += np.transpose(
-                        np.transpose(dTAUCIA[:, :, 0:A.NVMR], axes=(2, 0, 1)) / (L.TOTAM.T), axes=(1, 0, 2))
+                    # d TAUCIA / d amount of every gas: per unit column, with the gas axis ahead of the layer axis
+                    dTAUCON[:, 0:A.NVMR, :] += np.moveaxis(dTAUCIA[:, :, 0:A.NVMR], 2, 1) / np.asarray(L.TOTAM)[None, None, :]
                     dTAUCON[:, A.NVMR, :] += dTAUCIA[:, :, A.NVMR]
                 if dTAURAY is not None:                                           # :3955-3957
                     for i in range(A.NVMR):
@@ -175,6 +199,14 @@ class CIRSradGPU:
             TAUDUST = getattr(L, "TAUDUST", None)
             TAUDUST = z if TAUDUST is None else TAUDUST
         return TAUCIA, TAUDUST, TAURAY, dTAUCON
+
+    @staticmethod
+    def _ansfm_total_opacity(TAUGAS, TAUCIA, TAUDUST, TAURAY):
+        """LayerX.TAUTOT (NWAVE, NG, NLAY): the continuum terms joined to every g-ordinate in the order of :3989."""
+        out = TAUGAS.copy()
+        for cont in (TAUCIA, TAUDUST, TAURAY):
+            out += cont[:, None, :]
+        return out
 
     def _ansfm_units_and_surface(self):
         """xfac and EMISSIVITY exactly as calculate_thermal_emission_spectrum prepares them
@@ -218,6 +250,51 @@ class CIRSradGPU:
             f_gas[i, :] = L.AMOUNT[:, IGAS] * SQ_CM_TO_SQ_METER             # :3861
         return f_gas
 
+    # ---- scattering branch: host preparation of scloud11wave (:5018-5165) for what has no g axis ----------------
+    def _ansfm_cirsrad_scatter(self, eng, TAUCIA, TAUDUST, TAURAY, f_gas):
+        """calculate_multiple_scattering_spectrum (:4343-4374) + scloud11wave (:5018-5165): the boundary vectors, phase
+        functions and aerosol fractions are small host arrays prepared as the reference does; the gas opacities, TAUTOT,
+        OMEGA and BB are formed on the device (ansfm_cirsrad_ck_scatter).  -> SPECOUT (NWAVE, NPATH)."""
+        import scipy.interpolate
+        S, L, P, Sc, Su, M = self.SpectroscopyX, self.LayerX, self.PathX, self.ScatterX, self.SurfaceX, self.MeasurementX
+        WAVE = np.asarray(S.WAVE, dtype=np.float64)
+        W, ISPACE = WAVE.size, int(M.ISPACE)
+        solar = np.zeros(W)
+        if self.StellarX.SOLEXIST:                                               # :4353-4357
+            self.StellarX.calc_solar_flux()
+            solar[:] = scipy.interpolate.interp1d(self.StellarX.WAVE, self.StellarX.SOLFLUX)(WAVE)
+        # (the reference works xfac out here, :4359-4368, and never applies it to this branch's spectrum: nor is it here)
+        NMU, NDUST = int(Sc.NMU), int(Sc.NDUST)
+        RADGROUND = np.zeros((W, NMU))
+        if Su.GASGIANT or (Su.TSURF <= 0.0):                                     # :5082-5089
+            RADGROUND[:, :] = _planck(ISPACE, WAVE, L.TEMP[0])[:, None]
+        else:
+            emis = scipy.interpolate.interp1d(Su.VEM, Su.EMISSIVITY)(WAVE)
+            RADGROUND[:, :] = (_planck(ISPACE, WAVE, Su.TSURF) * emis)[:, None]
+        if (not Su.GASGIANT) and int(Su.LOWBC) != 0:                             # :5091-5094 (0 = THERMAL)
+            BRDF = self.calc_brdf_matrix(WAVEC=WAVE, Surface=Su, Scatter=Sc)
+        else:
+            BRDF = np.zeros((W, NMU, NMU, int(Sc.NF) + 1))
+        TAUSCAT, TAUCLSCAT = L.TAUSCAT, L.TAUCLSCAT
+        FRAC = np.zeros((W, L.NLAY, NDUST))                                      # :5106-5114
+        pos = TAUSCAT > 0.0
+        FRAC[pos] = TAUCLSCAT[pos] / TAUSCAT[pos][:, None]
+        FRAC = np.ascontiguousarray(np.transpose(FRAC, (0, 2, 1)))
+        THETA = np.asarray(Sc.THETA, dtype=np.float64)
+        PHASE = np.zeros((NDUST, W, 2, THETA.size))                              # :5125-5137
+        if int(Sc.IMIE) == 0:                                                    # Henyey-Greenstein: f, g1, g2
+            for i in range(NDUST):
+                PHASE[i, :, 0, -1] = np.interp(WAVE, Sc.WAVE, Sc.F.T[i])
+                PHASE[i, :, 0, -2] = np.interp(WAVE, Sc.WAVE, Sc.G1.T[i])
+                PHASE[i, :, 0, -3] = np.interp(WAVE, Sc.WAVE, Sc.G2.T[i])
+        else:
+            PHASE[:, :, 0, :] = np.transpose(Sc.calc_phase(THETA, WAVE), (2, 0, 1))
+        PHASE[:, :, 1, :] = np.cos(THETA * np.pi / 180)
+        return eng.cirsrad_ck_scatter(
+            ISPACE, np.asarray(L.PRESS, dtype=np.float64), np.asarray(L.TEMP, dtype=np.float64), f_gas, TAUCIA, TAUDUST,
+            TAURAY, TAUSCAT, np.ascontiguousarray(PHASE[:, :, :, ::-1]), FRAC, RADGROUND, P.SOL_ANG, P.EMISS_ANG, P.AZI_ANG,
+            solar, int(Su.LOWBC), BRDF, Sc.MU, Sc.WTMU, int(Sc.NF), int(Sc.NPHI), int(Sc.IRAY), int(Sc.IMIE))
+
     # ---- the seam ---------------------------------------------------------------------------------
     def CIRSrad(self, return_grad=False):
         if not self._ansfm_supported(return_grad):
@@ -232,6 +309,12 @@ class CIRSradGPU:
         TAUCIA, TAUDUST, TAURAY, dTAUCON = self._ansfm_continuum(return_grad)
         taucont = TAUCIA + TAUDUST + TAURAY                                  # :3989 (g-independent part)
         f_gas = self._ansfm_layer_inputs()
+        if self._ansfm_scatter_branch(int(np.unique(np.asarray(P.IMOD).astype(int))[0])):
+            SPECOUT = self._ansfm_cirsrad_scatter(eng, TAUCIA, TAUDUST, TAURAY, f_gas)
+            if self.ansfm_keep_side_products:
+                L.TAUGAS = eng.get_taugas(L.NLAY, 0)                         # :3925
+                L.TAUTOT = self._ansfm_total_opacity(L.TAUGAS, TAUCIA, TAUDUST, TAURAY)
+            return SPECOUT
         xfac, emissivity = self._ansfm_units_and_surface()
         NPATH = int(P.NPATH) if hasattr(P, "NPATH") else np.asarray(P.LAYINC).shape[1]
         LAYINC = np.asarray(P.LAYINC, dtype=np.int32).reshape(-1, NPATH)
@@ -256,7 +339,7 @@ class CIRSradGPU:
                 EMISS_ANG=np.asarray(P.EMISS_ANG, dtype=np.float64).reshape(NPATH), xfac=xfac)
         if self.ansfm_keep_side_products:
             L.TAUGAS = eng.get_taugas(L.NLAY, 0)                             # :3925
-            L.TAUTOT = L.TAUGAS + TAUCIA[:, None, :] + TAUDUST[:, None, :] + TAURAY[:, None, :]   # :3989,:3997
+            L.TAUTOT = self._ansfm_total_opacity(L.TAUGAS, TAUCIA, TAUDUST, TAURAY)
         if return_grad:
             return SPECOUT, dSPECOUT, dTSURF          # (NWAVE,NPATH), (NWAVE,NPAR,NLAYINmax,NPATH), (NWAVE,NPATH)
         return SPECOUT                                                        # (NWAVE, NPATH)

@@ -54,6 +54,128 @@ def torch_ktable(torch, dev, W, G, NP, NT, S, seed):
     return PRESS.cpu().numpy(), TEMP.cpu().numpy(), K
 
 
+def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, delg, do_cpu):
+    """Numbers for the other BASELINE configs and the north-star variant, OUTSIDE the timed region of the headline
+    metric (rank 0, one GPU).  Each entry says what it timed; profiles/README.md names the rocprofv3 run it can be
+    reproduced from."""
+    ex = {}
+    W, G, S, L, NP, NT = 10000, 20, 8, 100, 20, 15
+    rng = np.random.default_rng(5)
+
+    def med(f, n=3):
+        """median wall time of n calls after one warm-up call"""
+        f()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    # ---- analytic-gradient CIRSrad at C2 (nemesisfmg's RT call): SPECOUT + dSPECOUT (1e4, 10, 100, 1) + dTSURF -------
+    NVMR, NPAR = S, S + 2
+    ig = np.arange(S, dtype=np.int32)
+    fg = lambda: eng.cirsradg_ck_thermal(0, atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0], None, None, NVMR, NPAR,
+                                         ig, NLAYIN, LAYINC, SCALE, EMTEMP[0], -1.0)
+    t = med(fg)
+    k = eng.last_kernel_ms()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # the engine runs on torch's stream here
+    e0.record(); fg(); e1.record(); torch.cuda.synchronize()
+    k2 = eng.last_kernel_ms()
+    ex["cirsradg_c2"] = {"gpu_ms_whole_call": e0.elapsed_time(e1), "overlapg_kernel_ms_second_reading": k2["overlap_ms"],"what": "CIRSrad(return_grad=True) at C2: k_ck_overlapg + k_thermal_rtg, host arrays in / out "
+                                 "(80 MB of dSPECOUT cross PCIe inside wall_s)", "wall_s": t,
+                         "overlapg_kernel_ms": k["overlap_ms"], "rtg_kernel_ms": k["rt_ms"]}
+
+    # ---- C4: CIRSrad scattering branch at full size on the C2 table: 1e4 nu x G 20 x 100 layers, 16 streams, NF = 8 ---
+    NMU, NF = 16, 8
+    x, w = np.polynomial.legendre.leggauss(NMU)
+    MU, WT = 0.5 * (x + 1.0), 0.5 * w
+    TH = np.linspace(0.0, 180.0, 41); c = np.cos(np.deg2rad(TH))
+    leg = np.polynomial.legendre.legval(c, 0.6 ** np.arange(36) * (2 * np.arange(36) + 1)) / (4 * np.pi)   # 36 phase moments (HG g = 0.6)
+    ph = np.zeros((1, W, 2, TH.size)); ph[0, :, 0, :] = leg[None, :]; ph[0, :, 1, :] = c[None, :]
+    ph = np.ascontiguousarray(ph[:, :, :, ::-1])
+    lay_p, lay_t, am = atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0]
+    wv = np.linspace(0, 1, W)[:, None]; lv = np.linspace(0, 1, L)[None, :]
+    TAURAY = 1e-3 * np.exp(-5.0 * lv) * (1.0 + 0.3 * wv)
+    TAUSCAT = 2e-2 * np.exp(-((lv - 0.35) / 0.1) ** 2) * (1.0 + 0.5 * np.sin(7.0 * wv))
+    TAUDUST = 1.1 * TAUSCAT
+    c1, c2 = 1.1911e-12, 1.439
+    radg = np.repeat((c1 * WAVE ** 3 / (np.exp(c2 * WAVE / lay_t[0]) - 1.0))[:, None], NMU, 1)
+    fs = lambda: eng.cirsrad_ck_scatter(0, lay_p, lay_t, am, None, TAUDUST, TAURAY, TAUSCAT, ph, np.ones((W, 1, L)), radg,
+                                        [30.0], [20.0], [45.0], np.full(W, 1e-8), 0, np.zeros((W, NMU, NMU, NF + 1)), MU, WT,
+                                        NF, 101, 1, 1)
+    t = med(fs, 2)
+    ex["c4_scatter"] = {"what": "CIRSrad, multiple-scattering branch (ansfm_cirsrad_ck_scatter) at BASELINE configs[3] size: 1e4 "
+                                "wavenumbers x 20 g x 100 layers, 16 streams, 36 phase moments, NF = 8, Rayleigh on, 1 limb-free path; "
+                                "gas opacities + TAUTOT/OMEGA/BB formed on the device", "wall_s": t, "ms_per_1000_nu": t * 1e2,
+                        "chains_per_s": W * G * (NF + 1) / t}
+
+    # ---- C5: runtime line-by-line, 1e6 wavenumbers x 50 layers x 1e5 lines (Voigt, windows 25 / 75 cm-1) --------------
+    nw, N, Ll = 1000000, 100000, 50
+    wn = 2000.0 + 1e-3 * np.arange(nw)
+    span = nw * 1e-3
+    nu = np.sort(rng.uniform(2000.0 - 75.0, 2000.0 + span + 75.0, N)); sw = 10.0 ** rng.uniform(-28, -19, N)
+    el = rng.uniform(0, 3000, N)
+    bp = np.zeros((3, N)); bp[0] = rng.uniform(0.02, 0.1, N); bp[1] = rng.uniform(0.5, 0.8, N); bp[2] = rng.uniform(-0.01, 0.01, N)
+    sr = 1 - np.exp(-(2.99792458E10 * 6.62607015E-27 / 1.380649E-16) * nu / 296.0)
+    tt = np.linspace(150, 300, Ll); pp = np.logspace(-4, 0, Ll); qq = np.ones(Ll)
+    o = np.zeros((Ll, nw))
+    fl = lambda: eng.add_line_set_monochromatic_absorption(wn, 0, tt, 296.0, pp, 1.0, qq, 1.0, 28.0, np.array([1.0]), bp, nu, sw,
+                                                           el, sr, o)
+    t = med(fl, 2)
+    evals = float(N) * (150.0 / 1e-3) * Ll * (span / (span + 150.0))
+    ex["c5_lbl"] = {"what": "add_line_set_monochromatic_absorption at BASELINE configs[4] size (k_lbl_line_params + "
+                            "k_lbl_accumulate), host arrays in / out (800 MB of PCIe inside wall_s)", "wall_s": t,
+                    "profile_evaluations": evals, "Gevals_per_s": evals / t / 1e9}
+    del o
+
+    # ---- north-star variant: C2 with 20 gases (replaces the table in HBM: last) ----------------------------------------
+    S2 = 20
+    PRESS, TEMP, Kdev = torch_ktable(torch, dev, W, G, NP, NT, S2, seed=20260705)
+    PRESS, TEMP = PRESS.astype(np.float32), TEMP.astype(np.float32)
+    eng.upload_ktable(Kdev, PRESS, TEMP, WAVE, delg)
+    Wc = 2000
+    K_sample = Kdev[:Wc].cpu().numpy() if do_cpu else None
+    del Kdev
+    torch.cuda.empty_cache()
+    a2 = syn.synth_atmosphere(L, S2, seed=7)
+    cont = syn.synth_continuum(W, L)
+    f8 = torch.float64
+    td = lambda a, dt=f8: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    d = [td(a2["lay_press_pa"][0]), td(a2["lay_temp"][0]), td(a2["amount"][0]), td(cont), td(NLAYIN, torch.int32),
+         td(LAYINC, torch.int32), td(SCALE), td(EMTEMP[0]), td(np.full(1, -1.0))]
+    out = torch.empty((1, W, 1), dtype=f8, device=dev)
+    step = lambda: eng.cirsrad_ck_thermal_dev(0, 1, L, d[0], d[1], d[2], d[3], 1, L, d[4], d[5], d[6], d[7], d[8], None, None,
+                                              None, None, None, None, out)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / 10
+    k = eng.last_kernel_ms()
+    e = {"what": "the C2 forward model with 20 gases (north_star target variant), inputs resident in HBM", "value": 1.0 / t,
+         "unit": "forward-models/s", "ms_per_step": t * 1e3, "overlap_kernel_ms": k["overlap_ms"],
+         "algorithmic_bytes": algorithmic_bytes(W, G, S2, L, NP, NT, 1), }
+    e["hbm_frac"] = e["algorithmic_bytes"] / (k["overlap_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if do_cpu:
+        from oracle import oracle as orc
+        cores = orc.num_threads()
+        t0 = time.perf_counter()
+        ref = orc.cirsrad_ck_thermal(0, K_sample, PRESS, TEMP, WAVE[:Wc], delg, a2["lay_press_pa"][0], a2["lay_temp"][0],
+                                     a2["amount"][0], cont[0][:Wc], NLAYIN, LAYINC, SCALE, EMTEMP[0], -1.0)
+        ct = time.perf_counter() - t0
+        got = out[0, :Wc].cpu().numpy()
+        e["cpu_baseline"] = {"value": (Wc / W) / ct, "unit": "forward-models/s", "cores": int(cores), "kind": "port",
+                             "sample": f"first {Wc} of {W} wavenumbers, {ct:.2f} s wall, value scaled by {Wc}/{W}",
+                             "gpu_vs_oracle_max_rel_err_on_sample": float(np.max(np.abs(got - ref) / np.abs(ref)))}
+        e["gpu_over_cpu"] = e["value"] / e["cpu_baseline"]["value"]
+    ex["c2_20_gases"] = e
+    return ex
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +189,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-jacobian", action="store_true")
     ap.add_argument("--cpu-sample-waves", type=int, default=10000)
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (S=20 variant, gradients, C4, C5)")
     args = ap.parse_args()
 
     import torch
@@ -278,6 +401,10 @@ def main():
         jac["oracle_sample"] = (f"columns {cols.tolist()} of KK ({len(cols) + 1} oracle forward models at "
                                 f"{Wc} wavenumbers, {time.perf_counter() - t0:.1f} s); error relative to each column's maximum")
 
+    extras = None
+    if world == 1 and not args.no_extras and (W, G, S, L) == (10000, 20, 8, 100):
+        extras = run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, delg, do_cpu)
+
     line = {
         "metric": "forward-models/sec (10k nu x 100 layers)", "value": value, "unit": "forward-models/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -287,7 +414,7 @@ def main():
                    "forward_models_per_step_per_gpu": 1, "parallelism": f"replicas x{world} (independent forward models)"},
         "roofline": roof, "cpu_baseline": cpu, "jacobian": jac,
         "table_relayout_s": table_relayout_s,
-        "merge_reruns": eng.merge_redo_count(),
+        "extras": extras,
     }
     print(json.dumps(line))
     if use_dist:

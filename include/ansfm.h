@@ -231,6 +231,23 @@ int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const
                             const double *taus, const double *tauray, const double *omegas_s,
                             int nphi, int iray, int imie, const double *lfrac, double *rad);
 
+/* CIRSrad, scattering branch (ILBL = K_TABLES, IMOD & MULTIPLE_SCATTERING; ForwardModel_0.py:4478-4501 ->
+ * calculate_multiple_scattering_spectrum :4343 -> scloud11wave :5018-5165) with everything that has a g axis on the
+ * device: calc_k + k_overlap give the VERTICAL gas opacities (not LAYINC-scaled: scloud11wave reads LayerX.TAUTOT),
+ * TAUTOT = TAUGAS + TAUCIA + TAUDUST + TAURAY (:3989), OMEGA = (TAURAY + TAUSCAT) / TAUTOT and BB = planck(TEMP) (:5099-5119)
+ * are formed in HBM and feed the doubling / adding kernels directly; the g-quadrature with DELG (:4504) ends the call.
+ * Host pointers, reference layouts: taucia / taudust (summed over populations) / tauray / tauscat [W][L] (NULL = zeros),
+ * lfrac[W][ncont][L] = TAUCLSCAT / TAUSCAT, the remaining scloud11wave_core arguments as above (W = the table's wavenumber
+ * grid, ng = its g-ordinates), xfac[W] or NULL -> SPECOUT[W][ngeom]; SPEC_G[W][G][ngeom] (what scloud11wave returns, before
+ * the quadrature) when not NULL.  ansfm_get_taugas returns the TAUGAS side product afterwards. */
+int ansfm_cirsrad_ck_scatter(ansfm_ctx *ctx, int ISPACE, int L, const double *lay_press_pa, const double *lay_temp,
+                             const double *amount, const double *taucia, const double *taudust, const double *tauray,
+                             const double *tauscat, int ncont, int nth, const double *phasarr, const double *lfrac,
+                             const double *radg, int ngeom, const double *sol_angs, const double *emiss_angs,
+                             const double *aphis, const double *solar, int lowbc, const double *brdf_matrix, int nmu,
+                             const double *mu1, const double *wt1, int nf, int nphi, int iray, int imie, const double *xfac,
+                             double *SPECOUT, double *SPEC_G);
+
 /* ---- runtime line-by-line (ILBL = LINE_BY_LINE_RUNTIME) -------------------------------------------
  * LineData_0.add_line_set_monochromatic_absorption (LineData_0.py:280-357), batched over L (T,p) points
  * (L = 1 is the reference's signature).  lineshape_id = SpectroscopicLineProfileEnum value: 0 VOIGT

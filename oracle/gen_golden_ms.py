@@ -74,6 +74,14 @@ def make_case(ans, name, seed, NMU, NWAVE, NG, NLAY, NCONT, NF, NPHI, imie, iray
 
 def main():
     ans = import_reference()
+    if "--deep-only" in sys.argv:
+        # BASELINE configs[3] depth: 16 streams, NF = 8 (9 Fourier orders), 60 layers -- a few (wavenumber, g) points of
+        # the un-jitted reference core (minutes), to hold the MFMA chain kernel's inverse products over deep stacks
+        make_case(ans, "ms_nmu16_deep", 7, NMU=16, NWAVE=2, NG=2, NLAY=60, NCONT=1, NF=8, NPHI=101, imie=1, iray=1, lowbc=0,
+                  geoms=[(30.0, 20.0, 45.0), (65.0, 50.0, 120.0)])
+        make_case(ans, "ms_nmu16_deep_lambert", 8, NMU=16, NWAVE=1, NG=2, NLAY=50, NCONT=2, NF=8, NPHI=101, imie=0, iray=1,
+                  lowbc=1, geoms=[(20.0, 35.0, 60.0)])
+        return
     # upward-looking geometry (emission angle > 90, :900-903, :927-942): without a surface in the stack (lowbc = 0) and
     # with the internal-field formula `idown` (lowbc > 0)
     gu = [(30.0, 160.0, 45.0), (120.0, 130.0, 0.0)]

@@ -55,6 +55,26 @@ class OracleEngineDouble:
                                               return_taugas=True)[1]
         return r
 
+    def cirsrad_ck_scatter(self, ISPACE, lp, lt, am, TAUCIA, TAUDUST, TAURAY, TAUSCAT, phasarr, lfrac, radg, sol, emi, aph,
+                           solar, lowbc, brdf, mu1, wt1, nf, nphi, iray, imie, xfac=None, return_spec_g=False):
+        """ansfm_cirsrad_ck_scatter answered by the oracle's pieces in the reference's order (:3989, :5099-5119, :4504)."""
+        K, P, T, W, D = self.t
+        self.scatter_calls = getattr(self, "scatter_calls", 0) + 1
+        k = self.orc.calc_k(K, P, T, np.asarray(lp) / 101325.0, lt)
+        self.tg = self.orc.k_overlap(D, k, am)
+        z = np.zeros((len(W), len(lp)))
+        TAUCIA, TAUDUST, TAURAY, TAUSCAT = (z if a is None else np.asarray(a) for a in (TAUCIA, TAUDUST, TAURAY, TAUSCAT))
+        tautot = self.tg + TAUCIA[:, None, :] + TAUDUST[:, None, :] + TAURAY[:, None, :]
+        omega = np.zeros_like(tautot)
+        pos = tautot > 0
+        omega[pos] = np.broadcast_to((TAURAY + TAUSCAT)[:, None, :], tautot.shape)[pos] / tautot[pos]
+        bnu = np.stack([self.orc.planck(ISPACE, W, t) for t in lt], axis=1)
+        rad = self.orc.scloud11wave_core(phasarr, radg, sol, emi, solar, aph, lowbc, brdf, mu1, wt1, nf, W, bnu, tautot, TAURAY,
+                                         omega, nphi, iray, imie, lfrac)
+        spec = np.transpose(rad, (2, 1, 0))
+        out = np.tensordot(spec, np.asarray(D, dtype=float), axes=([1], [0]))
+        return (out, spec) if return_spec_g else out
+
     def layer_average(self, *a, **k):
         self.lay_calls = getattr(self, "lay_calls", 0) + 1
         return self.orc.layer_average(*a, **k)
@@ -154,6 +174,61 @@ def c1_run(oracle):
     finally:
         os.chdir(cwd)
         shutil.rmtree(work, ignore_errors=True)
+
+
+def test_scattering_nemesisfm_through_the_adapter_matches_the_reference(oracle, golden_dir, monkeypatch):
+    """ISCAT = 1: the reference's nemesisfm on its own multiple-scattering test inputs (Jupiter CIRS, haze + Rayleigh,
+    sunlight) through the adapter -- CIRSrad's scattering branch lands on ansfm_cirsrad_ck_scatter (here: the double)
+    with the host-prepared arguments of scloud11wave, and the convolved spectrum is the reference's
+    (oracle/gen_golden_c4.py ran the same inputs through the unmodified reference)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle.ref_import import import_reference
+    from oracle.gen_golden_c1 import GASES
+    from oracle.gen_golden_c4 import NKEEP
+    ans = import_reference()
+    sp_mod = sys.modules["archnemesis.Spectroscopy_0"]
+    import archnemesis_dist_amd.forward_model as fmod
+    src = os.path.join(REF, "tests", "files", "Jupiter_CIRS_angled_thermal_emission_scattering")
+    work = tempfile.mkdtemp(prefix="ansfm_dropin_ms_")
+    cwd = os.getcwd()
+    try:
+        for f in os.listdir(src):
+            shutil.copy(os.path.join(src, f), os.path.join(work, f))
+            os.chmod(os.path.join(work, f), 0o644)
+        rng = np.random.default_rng(4)
+        x, w = np.polynomial.legendre.leggauss(10)
+        PRESS = np.logspace(-7, 1.2, 12); TEMP = np.linspace(70.0, 400.0, 8)
+        names = []
+        for name, gid, iso in GASES:
+            base = 10.0 ** rng.uniform(-26, -22, size=(599, 1, 1, 1))
+            gs = np.sort(10.0 ** rng.uniform(-2, 2, size=(599, 10, 1, 1)), axis=1)
+            k = base * gs * PRESS[None, None, :, None] ** 0.1 * (TEMP[None, None, None, :] / 200.0)
+            fn = os.path.join(work, f"{name}_synth.kta")
+            sp_mod.write_ktable(fn, gid, iso, 0.5 * (x + 1.0), 0.5 * w, PRESS, TEMP, 599, 5.0, 2.5, 0.0, k)
+            names.append(fn)
+        with open(os.path.join(work, "cirstest.kls"), "w") as f:
+            f.write("\n".join(names) + "\n")
+        os.chdir(work)
+        double = OracleEngineDouble(oracle)
+        monkeypatch.setattr(fmod, "get_engine", lambda device=0: double)
+        fmod.set_strict(True)                        # a delegation to the reference's CIRSrad would raise
+        FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+        Atm, Meas, Spec, Scat, Stel, Surf, CIA, Lay, Var, Ret = ans.Files.read_input_files("cirstest")
+        Meas.NCONV = np.array([NKEEP], dtype="int32")
+        Meas.VCONV = Meas.VCONV[:NKEEP]; Meas.MEAS = Meas.MEAS[:NKEEP]; Meas.ERRMEAS = Meas.ERRMEAS[:NKEEP]
+        Meas.NY = NKEEP
+        fm = FMGPU(runname="cirstest", Atmosphere=Atm, Surface=Surf, Measurement=Meas, Spectroscopy=Spec, Stellar=Stel,
+                   Scatter=Scat, CIA=CIA, Layer=Lay, Variables=Var)
+        SPECONV = fm.nemesisfm()
+    finally:
+        fmod.set_strict(False)
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+    assert double.scatter_calls == 1
+    z = np.load(os.path.join(golden_dir, "c4_cirsrad_scatter.npz"))
+    np.testing.assert_allclose(SPECONV, z["SPECONV"], rtol=1e-8)
+    np.testing.assert_allclose(fm.LayerX.TAUGAS, z["TAUGAS"], rtol=2e-7)
+    np.testing.assert_allclose(fm.LayerX.TAUTOT, z["TAUTOT"], rtol=2e-7)
 
 
 def test_nemesisfm_through_the_adapter_matches_the_reference(c1_run, oracle, golden_dir, monkeypatch):
