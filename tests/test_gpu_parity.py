@@ -1194,3 +1194,38 @@ def test_c4_full_depth_conservative_scattering_returns_the_sunlight(eng):
     # the scheme's own accuracy, not rounding: a phase function tabulated at 41 angles, renormalised by Hansen's single
     # factor per stream, first-order starting layers of optical depth 2^-12 -- measured 1e-4 .. 5e-4 over 256 wavenumbers
     assert np.max(np.abs(flux_up / (MU[k0] * solar) - 1.0)) < 1e-3
+
+
+def test_c5_full_size_lbl_properties_and_slab_vs_oracle(eng, oracle):
+    """BASELINE configs[4] at full size -- 1e6 grid points x 50 layers x 1e5 lines (Voigt, windows 25 / 75 cm-1): the
+    spectrum of the list is the sum of the spectra of its halves (same additions in the same ascending-line order: bit
+    for bit), doubles with the isotopic abundance, is non-negative; and a slab of 2000 grid points x 3 layers of the
+    SAME launch agrees with the oracle's line loop (every line whose +-75 cm-1 window reaches the slab)."""
+    rng = np.random.default_rng(56)
+    nw, N, L = 1000000, 100000, 50
+    wn = 2000.0 + 1e-3 * np.arange(nw)
+    nu = np.sort(rng.uniform(1925.0, 3075.0, N))
+    sw = 10.0 ** rng.uniform(-28, -19, N); el = rng.uniform(0, 3000, N)
+    sr = 1.0 - np.exp(-1.4387769 * nu / 296.0)
+    bp = np.stack([rng.uniform(0.02, 0.1, N), rng.uniform(0.5, 0.8, N), rng.uniform(-0.01, 0.01, N)])
+    mmf = np.array([1.0])
+    t = np.linspace(150.0, 300.0, L); p = np.logspace(-4, 0, L); q = np.linspace(2.0, 0.95, L)
+    run = lambda sel, out, iso=0.9: eng.add_line_set_monochromatic_absorption(
+        wn, 0, t, 296.0, p, 1.0, q, iso, 28.0, mmf, bp[:, sel], nu[sel], sw[sel], el[sel], sr[sel], out)
+    full = np.zeros((L, nw)); run(slice(None), full)
+    assert full.min() >= 0.0 and full.max() > 0.0 and np.all(np.isfinite(full))
+    parts = np.zeros((L, nw)); run(slice(0, N // 2), parts); run(slice(N // 2, N), parts)
+    assert np.array_equal(full, parts)
+    del parts
+    twice = np.zeros((L, nw)); run(slice(None), twice, iso=1.8)
+    np.testing.assert_allclose(twice, 2.0 * full, rtol=1e-14)
+    del twice
+    # slab vs the oracle
+    i0, ns, layers = 431000, 2000, [0, 24, 49]
+    grid = wn[i0:i0 + ns]
+    near = (nu > grid[0] - 75.0 - 0.5) & (nu < grid[-1] + 75.0 + 0.5)      # +- the pressure shift, generously
+    for l in layers:
+        ref = np.zeros(ns)
+        oracle.add_line_set_monochromatic_absorption(grid, 0, t[l], 296.0, p[l], 1.0, q[l], 0.9, 28.0, mmf, bp[:, near], nu[near],
+                                                     sw[near], el[near], sr[near], ref)
+        np.testing.assert_allclose(full[l, i0:i0 + ns], ref, rtol=1e-9)

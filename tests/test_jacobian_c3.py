@@ -148,3 +148,130 @@ def test_c3_numerical_jacobian_vs_oracle(oracle, pointing, f32):
     scale = np.max(np.abs(kk), axis=0)
     scale = np.maximum(scale, 1.0e-6 * scale.max())
     assert np.max(np.abs(KK - kk) / scale) < 1e-6
+
+
+# ---- multi-GPU plumbing of the other shardable path: one line-by-line model split by wavenumber ---------------
+def _lbl_case(seed=3, nw=4000, N=900):
+    rng = np.random.default_rng(seed)
+    wn = 2100.0 + 0.05 * np.arange(nw)
+    nu = np.sort(rng.uniform(wn[0] - 90.0, wn[-1] + 90.0, N))
+    sw = 10.0 ** rng.uniform(-26, -20, N); el = rng.uniform(0, 2000, N)
+    sr = 1.0 - np.exp(-1.4387769 * nu / 296.0)
+    bp = np.stack([rng.uniform(0.02, 0.1, N), rng.uniform(0.5, 0.8, N), rng.uniform(-0.05, 0.05, N)])
+    return wn, nu, sw, el, sr, bp
+
+
+def _oracle_kernel(orc):
+    def kernel(wn, shape, t, t_ref, p, p_ref, q, iso, mass, mmf, bp, nu, sw, el, sr, out, s_floor=0.0, wn_calc_window=25.0,
+               wn_approx_window=75.0):
+        for l in range(len(t)):
+            orc.add_line_set_monochromatic_absorption(wn, shape, t[l], t_ref, p[l], p_ref, q[l], iso, mass, mmf, bp, nu, sw, el,
+                                                      sr, out[l], s_floor=s_floor, wn_calc_window=wn_calc_window,
+                                                      wn_approx_window=wn_approx_window)
+    return kernel
+
+
+def test_lbl_wavenumber_split_is_bit_identical(oracle):
+    """Every rank's slab (its grid points, the lines whose window reaches them) equals the same rows of the unsplit
+    result bit for bit -- ragged split (3 ranks over 4000 points), halo including the pressure shift."""
+    from archnemesis_dist_amd import lbl_shard
+    wn, nu, sw, el, sr, bp = _lbl_case()
+    t = np.array([180.0, 260.0]); p = np.array([0.05, 1.5]); q = np.array([1.4, 1.0]); mmf = np.array([1.0])
+    kern = _oracle_kernel(oracle)
+    full = np.zeros((2, wn.size))
+    kern(wn, 0, t, 296.0, p, 1.0, q, 0.9, 28.0, mmf, bp, nu, sw, el, sr, full)
+    seen = np.zeros(wn.size, bool)
+    for r in range(3):
+        slab, (i0, i1) = lbl_shard.add_line_set_sharded(kern, wn, 0, t, 296.0, p, 1.0, q, 0.9, 28.0, mmf, bp, nu, sw, el, sr,
+                                                       rank=r, world_size=3, gather=False)
+        assert np.array_equal(slab, full[:, i0:i1])
+        seen[i0:i1] = True
+    assert seen.all()
+    sel = lbl_shard.lines_reaching(nu, wn[0], wn[1300], 75.0, lbl_shard.max_pressure_shift(bp, p, 1.0))
+    assert isinstance(sel, slice) and 0 < sel.stop - sel.start < nu.size     # a real subset, found by bisection
+
+
+def test_lbl_wavenumber_split_gloo_world2(tmp_path):
+    script = textwrap.dedent(f'''
+        import os, sys
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+        import numpy as np, torch.distributed as dist
+        from archnemesis_dist_amd import lbl_shard
+        from oracle import oracle as orc
+        from test_jacobian_c3 import _lbl_case, _oracle_kernel
+        orc.build()
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        wn, nu, sw, el, sr, bp = _lbl_case(nw=1501, N=400)
+        t = np.array([200.0]); p = np.array([0.3]); q = np.array([1.2]); mmf = np.array([1.0])
+        kern = _oracle_kernel(orc)
+        full = np.zeros((1, wn.size))
+        kern(wn, 0, t, 296.0, p, 1.0, q, 0.9, 28.0, mmf, bp, nu, sw, el, sr, full)
+        out, (i0, i1) = lbl_shard.add_line_set_sharded(kern, wn, 0, t, 296.0, p, 1.0, q, 0.9, 28.0, mmf, bp, nu, sw, el, sr,
+                                                      rank=rank, world_size=world)
+        assert out.shape == full.shape and np.array_equal(out, full), rank
+        dist.destroy_process_group()
+        print("rank", rank, "ok", i0, i1)
+    ''')
+    f = tmp_path / "ls.py"
+    f.write_text(script)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29623", str(f)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_under_a_one_rank_nccl_group(tmp_path):
+    """The RCCL path of the Jacobian gather and of the wavenumber split, on the one GPU of this box: a fresh process
+    initialises a 1-rank `nccl` process group BEFORE any other GPU call, then runs jacobian_nemesis_batched with the
+    collective forced and the line-by-line split's all_gather on device tensors."""
+    script = textwrap.dedent(f'''
+        import os, sys
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+        import numpy as np, torch, torch.distributed as dist
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        import archnemesis_dist_amd as pkg
+        from archnemesis_dist_amd import synthetic as syn, lbl_shard
+        from archnemesis_dist_amd.jacobian import jacobian_nemesis_batched, gather_columns
+        from archnemesis_dist_amd.profile_state import ContinuousProfileState, BatchedCKThermalModel
+        x = torch.arange(12, dtype=torch.float64, device=dev).reshape(3, 4)
+        y = gather_columns(x, 3, 0, 1, force=True)
+        assert torch.equal(x, y) and y.is_cuda
+        W, G, S, NPRO, NLAY = 128, 8, 3, 10, 8
+        PRESS, TEMP, K = syn.synth_ktable(W, G, 6, 5, S, seed=9)
+        _, delg = syn.gauss_legendre_01(G)
+        eng = pkg.AnsfmEngine(0)
+        eng.upload_ktable(K, PRESS, TEMP, 500.0 + np.arange(W), delg)
+        pr = syn.synth_profiles(NPRO, 5, seed=2)
+        st = ContinuousProfileState(pr["H"], pr["P"], pr["T"], pr["VMR"], ["T"])
+        model = BatchedCKThermalModel(eng, st, pr["RADIUS"], pr["ID"], pr["ISO"], [2, 3, 4], layering_args=dict(NLAY=NLAY), IRAY=4)
+        YN1, KK1 = jacobian_nemesis_batched(model)
+        YN2, KK2 = jacobian_nemesis_batched(model, force_collective=True)       # all_gather_into_tensor through RCCL
+        assert np.array_equal(KK1, KK2) and np.array_equal(YN1, YN2) and np.abs(KK1).max() > 0
+        # wavenumber split of a line-by-line model: world 1, the gather still goes through the collective path
+        from test_jacobian_c3 import _lbl_case
+        wn, nu, sw, el, sr, bp = _lbl_case(nw=3000, N=500)
+        t = np.array([200.0, 250.0]); p = np.array([0.3, 1.0]); q = np.array([1.2, 1.0]); mmf = np.array([1.0])
+        ref = np.zeros((2, wn.size))
+        eng.add_line_set_monochromatic_absorption(wn, 0, t, 296.0, p, 1.0, q, 0.9, 28.0, mmf, bp, nu, sw, el, sr, ref)
+        slab, rng_ = lbl_shard.add_line_set_sharded(eng.add_line_set_monochromatic_absorption, wn, 0, t, 296.0, p, 1.0, q, 0.9, 28.0,
+                                                   mmf, bp, nu, sw, el, sr, rank=0, world_size=1, device=dev)
+        assert np.array_equal(slab, ref)
+        pad = torch.as_tensor(slab, device=dev)
+        out = torch.empty_like(pad)
+        dist.all_gather_into_tensor(out, pad)
+        assert torch.equal(out, pad)
+        eng.close()
+        dist.destroy_process_group()
+        print("nccl ok")
+    ''')
+    f = tmp_path / "nccl1.py"
+    f.write_text(script)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    r = subprocess.run([sys.executable, str(f)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "nccl ok" in r.stdout
