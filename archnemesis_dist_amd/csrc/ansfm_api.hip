@@ -57,6 +57,7 @@ struct ansfm_ctx {
     int monotone = 0;
     std::vector<double> h_wave, h_press, h_temp;   // host copies of the grids of the table in HBM
     int force_generic = 0;   // rerun of a call whose k-distributions turned out not to be sorted in g
+    int rt_mode = 0;         // 1: the next cirsrad_ck_thermal call returns the path transmission (ansfm_cirsrad_ck_transmission)
     int merge_keys = 64;     // 32: run the forward merge on k_ck_overlap32's float32 keys (ansfm_set_merge_keys)
     bool have_table = false;
     int grid_f32 = 0, delg_f32 = 0;
@@ -679,6 +680,7 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
     r.sol_ang = SOL_ANG; r.emiss_ang = EMISS_ANG;
     r.out = SPECOUT;
     r.W = W; r.Wpad = Wpad; r.G = G; r.L = L; r.P = P; r.LIMAX = LIMAX; r.ispace = ISPACE; r.per_g = 0;
+    r.mode = ctx->rt_mode;
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     rc = launch_rt(ctx, r, n_models);
     if (rc != ANSFM_OK) return rc;
@@ -810,6 +812,22 @@ int ansfm_cirsrad_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L, co
     return ANSFM_OK;
 }
 
+int ansfm_cirsrad_ck_transmission(ansfm_ctx *ctx, int n_models, int L, const double *lay_press_pa, const double *lay_temp,
+                                  const double *amount, const double *taucont, int P, int LIMAX, const int32_t *NLAYIN,
+                                  const int32_t *LAYINC, const double *SCALE, const double *xfac, double *SPECOUT)
+{
+    CHECK_CTX(ctx);
+    if (n_models <= 0 || !SCALE) FAIL(ANSFM_ERR_INVALID, "cirsrad_ck_transmission: bad argument");
+    std::vector<double> tsurf((size_t)n_models, -1.0);
+    ctx->rt_mode = 1;
+    // the emission temperatures are not used by the transmission epilogue: SCALE stands in for the array
+    const int rc = ansfm_cirsrad_ck_thermal(ctx, 0, n_models, L, lay_press_pa, lay_temp, amount, taucont, P, LIMAX, NLAYIN,
+                                            LAYINC, SCALE, SCALE, tsurf.data(), nullptr, nullptr, nullptr, nullptr, nullptr, xfac,
+                                            SPECOUT);
+    ctx->rt_mode = 0;
+    return rc;
+}
+
 int ansfm_get_taugas(ansfm_ctx *ctx, int model, double *TAUGAS)
 {
     CHECK_CTX(ctx);
@@ -900,6 +918,36 @@ int ansfm_k_overlap(ansfm_ctx *ctx, int W, int G, int L, int S, const double *de
                        ctx->tmp_out.as<double>(), W, Wpad, L, G, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(tau, ctx->tmp_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+int ansfm_thermal_emission_g(ansfm_ctx *ctx, int ISPACE, int W, int G, int NPAR, int NLAYIN, const double *WAVE,
+                             const double *TAUTOT_PATH, const double *dTAUTOT_PATH, int NVMR, const double *TEMP,
+                             const double *PRESS, double TSURF, const double *EMISSIVITY, double *SPECOUT, double *dSPECOUT,
+                             double *dTSURF)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || G <= 0 || NPAR <= 0 || NLAYIN <= 0 || !WAVE || !TAUTOT_PATH || !dTAUTOT_PATH || !TEMP || !PRESS || !SPECOUT ||
+        !dSPECOUT || !dTSURF || (ISPACE != 0 && ISPACE != 1) || (TSURF > 0.0 && !EMISSIVITY))
+        FAIL(ANSFM_ERR_INVALID, "thermal_emission_g: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t D = sizeof(double), WG = (size_t)W * G, Li = NLAYIN;
+    const void *d[6];
+    int rc, i = 0;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(WAVE, (size_t)W * D); UP(TAUTOT_PATH, WG * Li * D); UP(dTAUTOT_PATH, WG * NPAR * Li * D);
+    UP(TEMP, Li * D); UP(PRESS, Li * D); UP(EMISSIVITY, (size_t)W * D);
+#undef UP
+    HIPCHK(ctx->tmp_out.reserve(WG * (2 + (size_t)NPAR * Li) * D));
+    double *o_spec = ctx->tmp_out.as<double>(), *o_dts = o_spec + WG, *o_dspec = o_dts + WG;
+    hipLaunchKernelGGL(k_thermal_emission_g_seam, dim3(nblk(WG, 128)), dim3(128), 0, ctx->stream, ISPACE, W, G, NPAR, NLAYIN, NVMR,
+                       (const double *)d[0], (const double *)d[1], (const double *)d[2], (const double *)d[3],
+                       (const double *)d[4], TSURF, (const double *)d[5], o_spec, o_dspec, o_dts);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(SPECOUT, o_spec, WG * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dTSURF, o_dts, WG * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dSPECOUT, o_dspec, WG * NPAR * Li * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ANSFM_OK;
 }

@@ -1287,6 +1287,7 @@ struct RtParams {
     const double *sol_ang, *emiss_ang;                        // [P] or nullptr
     double *out;            // per_g ? [n][W][G] : [n][W][P]
     int W, Wpad, G, L, P, LIMAX, ispace, per_g;
+    int mode;               // 0 thermal emission; 1 transmission exp(-sum tau) of the path (calculate_transmission_spectrum :4110)
 };
 
 __device__ __forceinline__ double planck_bb(double a, double c2y, double T)
@@ -1400,8 +1401,11 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
         const int g = gy + k * kGY;
         if (g < G) {
             double s = spec[k];
-            if (ground) s += trold[k] * radground;
-            if (solar_on) s += trold[k] * exp(-taud[k] * muratio) * solterm;  // :6368-6373
+            if (p.mode == 1) s = exp(-taud[k]);                               // :4116, xfac = solar flux when IFORM = 4 (:4119-4127)
+            else {
+                if (ground) s += trold[k] * radground;
+                if (solar_on) s += trold[k] * exp(-taud[k] * muratio) * solterm;  // :6368-6373
+            }
             s = s * xf;                                                       // :4244
             if (p.per_g) {
                 if (nu < p.W) p.out[((size_t)m * p.W + nu) * G + g] = s;
@@ -1611,6 +1615,73 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
             if (v != v) v = 0.0;                                   // nan_to_num :4507
             dsp[((size_t)kpar * p.LIMAX + mm) * p.Wpad] = v;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Array-level seam of calc_thermal_emission_spectrumg (ForwardModel_0.py:6380-6504) on the reference's layouts: one
+// thread per (wavenumber, g).  The reference carries d tr / dq for every (parameter, layer) pair through the layer loop,
+// O(NPAR Li^2); the recursion is linear in dTAU, so (as in k_thermal_rtg)
+//     dspec[k][m] = dTAU[k][m] * (tr_m B_m - R_m) + [k == NVMR] (trold_m - tr_m) dB/dT_m ,
+//     R_m = sum_{j > m} (trold_j - tr_j) B_j + tr_N * radground
+// -- a forward pass that parks trold_j in the output's parameter-0 row and one backward sweep.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_thermal_emission_g_seam(int ispace, int W, int G, int NPAR, int Li, int NVMR,
+                                                                  const double *__restrict__ wave,
+                                                                  const double *__restrict__ tau,      // [W][G][Li]
+                                                                  const double *__restrict__ dtau,     // [W][G][NPAR][Li]
+                                                                  const double *__restrict__ temp,     // [Li]
+                                                                  const double *__restrict__ press,    // [Li]
+                                                                  double tsurf, const double *__restrict__ emissivity,
+                                                                  double *__restrict__ spec,           // [W][G]
+                                                                  double *__restrict__ dspec,          // [W][G][NPAR][Li]
+                                                                  double *__restrict__ dtsurf)         // [W][G]
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)W * G) return;
+    const int w = (int)(idx / G);
+    const double wv = wave[w];
+    const double y = (ispace == 0) ? wv : 1.0e4 / wv;
+    const double *t = tau + idx * Li;
+    const double *dt = dtau + idx * (size_t)NPAR * Li;
+    double *ds = dspec + idx * (size_t)NPAR * Li;
+    double trold = 1.0, sp = 0.0;
+    for (int j = 0; j < Li; ++j) {                       // :6446-6452, product form of the transmission
+        double bb, dB;
+        planckg_dev(ispace, y, temp[j], bb, dB);
+        const double tr = trold * exp(-t[j]);
+        sp += (trold - tr) * bb;
+        ds[j] = trold;                                   // parked: read back (then overwritten) by the sweep
+        trold = tr;
+    }
+    int i1 = (int)(Li / 2.0) - 1;                        // python index int(NLAYIN/2)-1, -1 wraps to the last layer
+    if (i1 < 0) i1 += Li;
+    double radground = 0.0, dradground = 0.0, R = 0.0;
+    if (press[Li - 1] > press[i1]) {                     // not a limb path: the lower boundary contributes (:6479-6496)
+        if (tsurf <= 0.0) planckg_dev(ispace, y, temp[Li - 1], radground, dradground);
+        else {
+            planckg_dev(ispace, y, tsurf, radground, dradground);
+            radground *= emissivity[w];
+            dradground *= emissivity[w];
+        }
+        sp += trold * radground;
+        R = trold * radground;
+    }
+    spec[idx] = sp;
+    dtsurf[idx] = (press[Li - 1] > press[i1]) ? trold * dradground : 0.0;
+    double trn = trold;                                  // tr_m = trold_{m+1}
+    for (int m = Li - 1; m >= 0; --m) {
+        double bb, dB;
+        planckg_dev(ispace, y, temp[m], bb, dB);
+        const double to = ds[m];
+        const double c = trn * bb - R;
+        for (int k = 0; k < NPAR; ++k) {
+            double v = dt[(size_t)k * Li + m] * c;
+            if (k == NVMR) v += (to - trn) * dB;         // :6467-6468
+            ds[(size_t)k * Li + m] = v;
+        }
+        R += (to - trn) * bb;
+        trn = to;
     }
 }
 

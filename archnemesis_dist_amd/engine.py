@@ -199,6 +199,20 @@ class AnsfmEngine:
         return out
 
     # ---- fused CIRSrad (batch) ----------------------------------------------------------------
+    def calc_thermal_emission_spectrumg(self, ISPACE, WAVE, TAUTOT_PATH, dTAUTOT_PATH, NVMR, TEMP, PRESS, TSURF, EMISSIVITY):
+        """ForwardModel_0.calc_thermal_emission_spectrumg (:6380), same arguments -> SPECOUT (NWAVE, NG),
+        dSPECOUT (NWAVE, NG, NPAR, NLAYIN), dTSURF (NWAVE, NG)."""
+        TAU = _np(TAUTOT_PATH); dTAU = _np(dTAUTOT_PATH)
+        W, G, NPAR, Li = dTAU.shape
+        if TAU.shape != (W, G, Li):
+            raise ValueError("TAUTOT_PATH must be (NWAVE, NG, NLAYIN) and dTAUTOT_PATH (NWAVE, NG, NPAR, NLAYIN)")
+        spec = np.empty((W, G)); dspec = np.empty((W, G, NPAR, Li)); dts = np.empty((W, G))
+        rc = self._lib.ansfm_thermal_emission_g(self._ctx, int(ISPACE), W, G, NPAR, Li, _ptr(_np(WAVE)), _ptr(TAU), _ptr(dTAU),
+                                                int(NVMR), _ptr(_np(TEMP)), _ptr(_np(PRESS)), float(TSURF), _ptr(_np(EMISSIVITY)),
+                                                _ptr(spec), _ptr(dspec), _ptr(dts))
+        self._check(rc, "thermal_emission_g")
+        return spec, dspec, dts
+
     def cirsrad_ck_thermal(self, ISPACE, lay_press_pa, lay_temp, amount, taucont, NLAYIN, LAYINC, SCALE, EMTEMP,
                            TSURF, EMISSIVITY=None, SOLFLUX=None, REFLECTANCE=None, SOL_ANG=None, EMISS_ANG=None,
                            xfac=None):
@@ -224,6 +238,27 @@ class AnsfmEngine:
             _ptr(_np(REFLECTANCE)), _ptr(None if SOL_ANG is None else _np(np.atleast_1d(SOL_ANG))),
             _ptr(None if EMISS_ANG is None else _np(np.atleast_1d(EMISS_ANG))), _ptr(_np(xfac)), _ptr(out))
         self._check(rc, "cirsrad_ck_thermal")
+        return out[0] if single else out
+
+    def cirsrad_ck_transmission(self, lay_press_pa, lay_temp, amount, taucont, NLAYIN, LAYINC, SCALE, xfac=None):
+        """CIRSrad, pure-transmission branch (calculate_transmission_spectrum :4110): SPECOUT (n, W, P) (or (W, P)) =
+        xfac * sum_g DELG exp(-sum over the path's layers of TAUTOT_LAYINC)."""
+        W, G, NP, NT, S = self.dims
+        lay_press_pa = _np(lay_press_pa)
+        single = lay_press_pa.ndim == 1
+        lp = np.atleast_2d(lay_press_pa); n, L = lp.shape
+        lt = _np(np.atleast_2d(_np(lay_temp)))
+        am = _np(amount).reshape(n, S, L)
+        tc = None if taucont is None else _np(taucont).reshape(n, W, L)
+        LAYINC = _np(LAYINC, np.int32); NLAYIN = _np(np.atleast_1d(NLAYIN), np.int32)
+        if LAYINC.ndim == 1:
+            LAYINC = LAYINC[:, None]
+        LIMAX, P = LAYINC.shape
+        SC = _np(np.broadcast_to(_np(SCALE).reshape(-1, LIMAX, P), (n, LIMAX, P)))
+        out = np.empty((n, W, P))
+        rc = self._lib.ansfm_cirsrad_ck_transmission(self._ctx, n, L, _ptr(lp), _ptr(lt), _ptr(am), _ptr(tc), P, LIMAX, _ptr(NLAYIN),
+                                                     _ptr(LAYINC), _ptr(SC), _ptr(_np(xfac)), _ptr(out))
+        self._check(rc, "cirsrad_ck_transmission")
         return out[0] if single else out
 
     def cirsradg_ck_thermal(self, ISPACE, lay_press_pa, lay_temp, amount, taucont, dtaucon, NVMR, NPAR, igas_map,

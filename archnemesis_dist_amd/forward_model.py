@@ -26,6 +26,7 @@ IMOD_DOWNWARD_FLUX = 16
 IMOD_SINGLE_SCATTERING_PLANE_PARALLEL = 1024
 IMOD_ABSORBTION = 4096
 IFORM_FLUXRATIO = 1                    # SpectraUnitEnum.FluxRatio
+IFORM_ATMOSPHERIC_TRANSMISSION = 4     # SpectraUnitEnum.Atmospheric_transmission
 ATM_TO_PASCAL = 101325.0               # ForwardModel_0.py:61
 SQ_CM_TO_SQ_METER = 1.0e-4             # ForwardModel_0.py:66
 
@@ -148,13 +149,21 @@ class CIRSradGPU:
         imod = int(imod[0])
         # dispatch order of CIRSrad :4478-4501: transmission / absorption come before thermal emission, thermal emission
         # before single scattering, the downward-flux variant before plain multiple scattering
+        if self._ansfm_transmission_branch(imod):
+            return not return_grad
         if imod & IMOD_ABSORBTION:
-            return False
+            return False           # calculate_absorption_spectrum (:4133) lacks `self` in the reference: never callable
         if imod & IMOD_THERMAL_EMISSION:
             return True
         if self._ansfm_scatter_branch(imod):
             return (not return_grad) and int(S.ILBL) == ILBL_K_TABLES      # the reference has no gradients there either
         return False
+
+    @staticmethod
+    def _ansfm_transmission_branch(imod):
+        """the first test of CIRSrad's dispatch (:4478-4483): none of the four flags -> exp(-tau)"""
+        return not (imod & (IMOD_ABSORBTION | IMOD_THERMAL_EMISSION | IMOD_MULTIPLE_SCATTERING |
+                            IMOD_SINGLE_SCATTERING_PLANE_PARALLEL))
 
     @staticmethod
     def _ansfm_scatter_branch(imod):
@@ -313,6 +322,22 @@ class CIRSradGPU:
             SPECOUT = self._ansfm_cirsrad_scatter(eng, TAUCIA, TAUDUST, TAURAY, f_gas)
             if self.ansfm_keep_side_products:
                 L.TAUGAS = eng.get_taugas(L.NLAY, 0)                         # :3925
+                L.TAUTOT = self._ansfm_total_opacity(L.TAUGAS, TAUCIA, TAUDUST, TAURAY)
+            return SPECOUT
+        imod0 = int(np.unique(np.asarray(P.IMOD).astype(int))[0])
+        if self._ansfm_transmission_branch(imod0):
+            import scipy.interpolate
+            xf = None
+            if int(self.MeasurementX.IFORM) == IFORM_ATMOSPHERIC_TRANSMISSION:   # :4119-4127: times the solar flux
+                self.StellarX.calc_solar_flux()
+                xf = scipy.interpolate.interp1d(self.StellarX.WAVE, self.StellarX.SOLFLUX)(S.WAVE)
+            NPATH = np.asarray(P.LAYINC).shape[1]
+            SPECOUT = eng.cirsrad_ck_transmission(
+                np.asarray(L.PRESS, dtype=np.float64), np.asarray(L.TEMP, dtype=np.float64), f_gas, taucont,
+                np.asarray(P.NLAYIN, dtype=np.int32).reshape(NPATH), np.asarray(P.LAYINC, dtype=np.int32).reshape(-1, NPATH),
+                np.asarray(P.SCALE, dtype=np.float64).reshape(-1, NPATH), xfac=xf)
+            if self.ansfm_keep_side_products:
+                L.TAUGAS = eng.get_taugas(L.NLAY, 0)
                 L.TAUTOT = self._ansfm_total_opacity(L.TAUGAS, TAUCIA, TAUDUST, TAURAY)
             return SPECOUT
         xfac, emissivity = self._ansfm_units_and_surface()

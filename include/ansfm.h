@@ -148,6 +148,15 @@ int ansfm_thermal_emission(ansfm_ctx *ctx, int ISPACE, int W, int G, int NLAYIN,
                            const double *REFLECTANCE, double SOL_ANG, double EMISS_ANG,
                            double *SPECOUT);
 
+/* ForwardModel_0.calc_thermal_emission_spectrumg (ForwardModel_0.py:6380-6504), array level: TAUTOT_PATH[W][G][Li],
+ * dTAUTOT_PATH[W][G][NPAR][Li], NVMR = index of the temperature parameter, TEMP / PRESS[Li], EMISSIVITY[W] (needed
+ * when TSURF > 0) -> SPECOUT[W][G], dSPECOUT[W][G][NPAR][Li], dTSURF[W][G].  The reference's O(NPAR Li^2) recursion is
+ * evaluated as one backward sweep (the fused CIRSrad entry below does the same, with the g-quadrature folded in). */
+int ansfm_thermal_emission_g(ansfm_ctx *ctx, int ISPACE, int W, int G, int NPAR, int NLAYIN, const double *WAVE,
+                             const double *TAUTOT_PATH, const double *dTAUTOT_PATH, int NVMR, const double *TEMP,
+                             const double *PRESS, double TSURF, const double *EMISSIVITY, double *SPECOUT,
+                             double *dSPECOUT, double *dTSURF);
+
 /* ---- fused seam: CIRSrad, ILBL=K_TABLES, IMOD=THERMAL_EMISSION ------------------------------
  * ForwardModel_0.CIRSrad (ForwardModel_0.py:4376-4511) =
  *   calculate_gaseous_line_opacity (:3850-3877: calc_k -> k_overlap)
@@ -181,6 +190,15 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
                                  const double *EMISSIVITY, const double *SOLFLUX,
                                  const double *REFLECTANCE, const double *SOL_ANG,
                                  const double *EMISS_ANG, const double *xfac, double *SPECOUT);
+
+/* CIRSrad, pure-transmission branch (IMOD without ABSORBTION / THERMAL_EMISSION / scattering flags; ForwardModel_0.py:
+ * 4478-4481 -> calculate_transmission_spectrum :4110-4131): SPECOUT[n][W][P] = xfac[W] * sum_g DELG[g] exp(-sum_layers
+ * TAUTOT_LAYINC) -- the same opacity assembly as the thermal branch, the RT kernel's epilogue switched.  xfac = the
+ * solar flux when IFORM = Atmospheric_transmission, else NULL.  (The reference's absorption branch,
+ * calculate_absorption_spectrum :4133, is declared without `self` and cannot be called; it has no counterpart.) */
+int ansfm_cirsrad_ck_transmission(ansfm_ctx *ctx, int n_models, int L, const double *lay_press_pa, const double *lay_temp,
+                                  const double *amount, const double *taucont, int P, int LIMAX, const int32_t *NLAYIN,
+                                  const int32_t *LAYINC, const double *SCALE, const double *xfac, double *SPECOUT);
 
 /* ---- analytic-gradient seams ---------------------------------------------------------------
  * ForwardModel_0.k_overlapg (ForwardModel_0.py:5842): + dkdT[W][G][L][S] -> tau[W][G][L],
