@@ -922,6 +922,160 @@ int ansfm_k_overlap(ansfm_ctx *ctx, int W, int G, int L, int S, const double *de
     return ANSFM_OK;
 }
 
+int ansfm_singlescatt_plane_spectrum(ansfm_ctx *ctx, int ISPACE, int W, int G, int NLAYIN, const double *WAVE,
+                                     const double *TAUTOT_PATH, const double *TEMP, const double *OMEGA, const double *PHASE,
+                                     double TSURF, const double *EMISSIVITY, const double *BRDF, const double *SOLFLUX,
+                                     double SOL_ANG, double EMISS_ANG, double *SPECOUT)
+{
+    CHECK_CTX(ctx);
+    if (W <= 0 || G <= 0 || G > ANSFM_MAX_NG || NLAYIN <= 0 || !WAVE || !TAUTOT_PATH || !TEMP || !OMEGA || !PHASE || !SPECOUT ||
+        !SOLFLUX || !BRDF || (ISPACE != 0 && ISPACE != 1) || (TSURF > 0.0 && !EMISSIVITY))
+        FAIL(ANSFM_ERR_INVALID, "singlescatt_plane_spectrum: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int Wpad = round_up(W, kWave), Li = NLAYIN;
+    const size_t D = sizeof(double);
+    const void *d[10];
+    int rc, i = 0;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(TAUTOT_PATH, (size_t)W * G * Li * D);  // 0
+    UP(OMEGA, (size_t)W * G * Li * D);        // 1
+    UP(PHASE, (size_t)W * Li * D);            // 2
+    UP(TEMP, (size_t)Li * D);                 // 3
+    UP(WAVE, (size_t)W * D);                  // 4
+    UP(EMISSIVITY, (size_t)W * D);            // 5
+    UP(SOLFLUX, (size_t)W * D);               // 6
+    UP(BRDF, (size_t)W * D);                  // 7
+#undef UP
+    std::vector<int32_t> hi(1 + Li);
+    hi[0] = Li;
+    for (int j = 0; j < Li; ++j) hi[1 + j] = j;
+    std::vector<double> hd(Li + 3, 1.0);
+    hd[Li] = TSURF; hd[Li + 1] = SOL_ANG; hd[Li + 2] = EMISS_ANG;
+    const void *di, *dd;
+    if ((rc = h2d(ctx, ctx->hb[8], hi.data(), hi.size() * sizeof(int32_t), &di))) return rc;
+    if ((rc = h2d(ctx, ctx->hb[9], hd.data(), hd.size() * D, &dd))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const size_t ntau = (size_t)Li * G * Wpad;
+    HIPCHK(ctx->misc.reserve(2 * ntau * D));
+    HIPCHK(ctx->cont_t.reserve((size_t)Li * Wpad * D));
+    double *tau_t = ctx->misc.as<double>(), *om_t = tau_t + ntau;
+    hipLaunchKernelGGL(k_w_to_last, dim3(nblk(ntau, 256)), dim3(256), 0, ctx->stream, (const double *)d[0], tau_t, W, Wpad, G, Li,
+                       1, 0.0);
+    hipLaunchKernelGGL(k_w_to_last, dim3(nblk(ntau, 256)), dim3(256), 0, ctx->stream, (const double *)d[1], om_t, W, Wpad, G, Li,
+                       1, 0.0);
+    hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)Li * Wpad, 256)), dim3(256), 0, ctx->stream, (const double *)d[2],
+                       ctx->cont_t.as<double>(), W, Wpad, 1, Li, 0, 0.0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(ctx->tmp_out.reserve((size_t)W * G * D));
+    RtParams r;
+    memset(&r, 0, sizeof r);
+    r.tau = tau_t; r.omega = om_t; r.phase = ctx->cont_t.as<double>();
+    r.wave = (const double *)d[4];
+    r.nlayin = (const int32_t *)di; r.layinc = (const int32_t *)di + 1;
+    r.scale = (const double *)dd; r.emtemp = (const double *)d[3]; r.lay_press = (const double *)d[3];
+    r.tsurf = (const double *)dd + Li;
+    r.emissivity = (const double *)d[5]; r.solflux = (const double *)d[6]; r.brdf = (const double *)d[7];
+    r.sol_ang = (const double *)dd + Li + 1; r.emiss_ang = (const double *)dd + Li + 2;
+    r.out = ctx->tmp_out.as<double>();
+    r.W = W; r.Wpad = Wpad; r.G = G; r.L = Li; r.P = 1; r.LIMAX = Li; r.ispace = ISPACE; r.per_g = 1; r.mode = 2;
+    rc = launch_rt(ctx, r, 1);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(SPECOUT, ctx->tmp_out.p, (size_t)W * G * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+int ansfm_cirsrad_ck_singlescatt(ansfm_ctx *ctx, int ISPACE, int L, const double *lay_press_pa, const double *lay_temp,
+                                 const double *amount, const double *taucont, const double *tausca, const double *phase, int P,
+                                 int LIMAX, const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE,
+                                 const double *EMTEMP, double TSURF, const double *EMISSIVITY, const double *BRDF,
+                                 const double *SOLFLUX, const double *SOL_ANG, const double *EMISS_ANG, const double *xfac,
+                                 double *SPECOUT)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "cirsrad_ck_singlescatt: upload a k-table first");
+    if (ctx->is_lbl) FAIL(ANSFM_ERR_UNSUPPORTED, "cirsrad_ck_singlescatt: k-tables only (ILBL = K_TABLES)");
+    if (L <= 0 || P <= 0 || LIMAX <= 0 || !lay_press_pa || !lay_temp || !amount || !tausca || !phase || !NLAYIN || !LAYINC ||
+        !SCALE || !EMTEMP || !SOLFLUX || !SOL_ANG || !EMISS_ANG || !SPECOUT || (ISPACE != 0 && ISPACE != 1) ||
+        (TSURF > 0.0 && !EMISSIVITY))
+        FAIL(ANSFM_ERR_INVALID, "cirsrad_ck_singlescatt: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, S = ctx->S;
+    const size_t D = sizeof(double), WL = (size_t)W * L;
+    const void *d[18];
+    int i = 0, rc;
+    const double tsurf1 = TSURF;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(lay_press_pa, (size_t)L * D);                 // 0
+    UP(lay_temp, (size_t)L * D);                     // 1
+    UP(amount, (size_t)S * L * D);                   // 2
+    UP(taucont, WL * D);                             // 3
+    UP(tausca, WL * D);                              // 4
+    UP(phase, (size_t)P * WL * D);                   // 5
+    UP(NLAYIN, (size_t)P * sizeof(int32_t));         // 6
+    UP(LAYINC, (size_t)LIMAX * P * sizeof(int32_t)); // 7
+    UP(SCALE, (size_t)LIMAX * P * D);                // 8
+    UP(EMTEMP, (size_t)LIMAX * P * D);               // 9
+    UP(&tsurf1, D);                                  // 10
+    UP(EMISSIVITY, (size_t)W * D);                   // 11
+    UP(BRDF, (size_t)W * P * D);                     // 12
+    UP(SOLFLUX, (size_t)W * D);                      // 13
+    UP(SOL_ANG, (size_t)P * D);                      // 14
+    UP(EMISS_ANG, (size_t)P * D);                    // 15
+    UP(xfac, (size_t)W * D);                         // 16
+#undef UP
+    HIPCHK(hipStreamSynchronize(ctx->stream));       // tsurf1 is a stack variable
+    HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx->li.reserve((size_t)L * sizeof(LayerInterp)));
+    HIPCHK(ctx->tau.reserve((size_t)L * G * Wpad * D));
+    for (int pass = 0; pass < 2; ++pass) {
+        ctx->force_generic = pass;
+        hipLaunchKernelGGL(k_layer_prep, dim3(nblk((size_t)L, 128)), dim3(128), 0, ctx->stream, L, (const double *)d[0],
+                           (const double *)d[1], ctx->NP, ctx->d_press.as<double>(), ctx->NT, ctx->d_temp.as<double>(),
+                           101325.0, ctx->grid_f32, ctx->li.as<LayerInterp>());
+        HIPCHK(hipGetLastError());
+        if (pass) HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+        rc = launch_overlap(ctx, false, nullptr, W, Wpad, G, S, L, 1, ctx->li.as<LayerInterp>(), (const double *)d[2],
+                            ctx->d_delg.as<double>(), ctx->h_delg.data(), ctx->tau.as<double>());
+        ctx->force_generic = 0;
+        if (rc) return rc;
+        int flag = 0;
+        if ((rc = read_unsorted(ctx, &flag))) return rc;
+        if (!flag) break;
+    }
+    ctx->last_n = 1; ctx->last_L = L; ctx->last_rows = L; ctx->last_dedup = 0;
+    // reference layouts [W][L] -> [L][Wpad] (continuum, scattering opacity) and [P][W][L] -> [P][L][Wpad] (phase)
+    HIPCHK(ctx->cont_t.reserve((size_t)L * Wpad * D));
+    HIPCHK(ctx->misc.reserve((size_t)(1 + P) * L * Wpad * D));
+    double *sca_t = ctx->misc.as<double>(), *ph_t = sca_t + (size_t)L * Wpad;
+    const double *cont_t = nullptr;
+    if (d[3]) {
+        hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256)), dim3(256), 0, ctx->stream, (const double *)d[3],
+                           ctx->cont_t.as<double>(), W, Wpad, 1, L, 0, 0.0);
+        cont_t = ctx->cont_t.as<double>();
+    }
+    hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256)), dim3(256), 0, ctx->stream, (const double *)d[4], sca_t, W,
+                       Wpad, 1, L, 0, 0.0);
+    hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256), (unsigned)P), dim3(256), 0, ctx->stream, (const double *)d[5],
+                       ph_t, W, Wpad, 1, L, 0, 0.0, WL, (size_t)L * Wpad);
+    HIPCHK(hipGetLastError());
+    HIPCHK(ctx->tmp_out.reserve((size_t)W * P * D));
+    RtParams r;
+    memset(&r, 0, sizeof r);
+    r.tau = ctx->tau.as<double>(); r.cont = cont_t; r.sca = sca_t; r.phase = ph_t;
+    r.wave = ctx->d_wave.as<double>(); r.delg = ctx->d_delg.as<double>();
+    r.nlayin = (const int32_t *)d[6]; r.layinc = (const int32_t *)d[7]; r.scale = (const double *)d[8];
+    r.emtemp = (const double *)d[9]; r.lay_press = (const double *)d[0]; r.tsurf = (const double *)d[10];
+    r.emissivity = (const double *)d[11]; r.brdf = (const double *)d[12]; r.solflux = (const double *)d[13];
+    r.sol_ang = (const double *)d[14]; r.emiss_ang = (const double *)d[15]; r.xfac = (const double *)d[16];
+    r.out = ctx->tmp_out.as<double>();
+    r.W = W; r.Wpad = Wpad; r.G = G; r.L = L; r.P = P; r.LIMAX = LIMAX; r.ispace = ISPACE; r.per_g = 0; r.mode = 2;
+    if ((rc = launch_rt(ctx, r, 1))) return rc;
+    HIPCHK(hipMemcpyAsync(SPECOUT, ctx->tmp_out.p, (size_t)W * P * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
 int ansfm_thermal_emission_g(ansfm_ctx *ctx, int ISPACE, int W, int G, int NPAR, int NLAYIN, const double *WAVE,
                              const double *TAUTOT_PATH, const double *dTAUTOT_PATH, int NVMR, const double *TEMP,
                              const double *PRESS, double TSURF, const double *EMISSIVITY, double *SPECOUT, double *dSPECOUT,

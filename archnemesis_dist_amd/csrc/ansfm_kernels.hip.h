@@ -1287,7 +1287,14 @@ struct RtParams {
     const double *sol_ang, *emiss_ang;                        // [P] or nullptr
     double *out;            // per_g ? [n][W][G] : [n][W][P]
     int W, Wpad, G, L, P, LIMAX, ispace, per_g;
-    int mode;               // 0 thermal emission; 1 transmission exp(-sum tau) of the path (calculate_transmission_spectrum :4110)
+    int mode;               // 0 thermal emission; 1 transmission exp(-sum tau) of the path (calculate_transmission_spectrum :4110);
+                            // 2 single scattering, plane parallel (calc_singlescatt_plane_spectrum :6509-6600)
+    // mode 2: single-scattering albedo of every layer, either given per g (array-level seam) or formed from the vertical
+    // opacities as (TAURAY + TAUSCAT) / TAUTOT where TAUTOT > 0 (:4276-4283); layer-mean phase function per path; BRDF
+    const double *omega;    // [Li][G][Wpad] along the path, or nullptr
+    const double *sca;      // [L][Wpad] TAURAY + TAUSCAT of the layers, or nullptr
+    const double *phase;    // [P][L][Wpad] (by layer; the array-level seam passes L = Li, identity LAYINC)
+    const double *brdf;     // [W][P] or nullptr
 };
 
 __device__ __forceinline__ double planck_bb(double a, double c2y, double T)
@@ -1345,6 +1352,28 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
             tv[k] = (g < G) ? trow[(size_t)g * p.Wpad] : 0.0;
         }
     };
+    // mode 2 (single scattering): ssfac = mu0 / (mu0 + mu) and the solar flux over 4 pi, wave-uniform per path (:6557-6559)
+    const double PI_ = 3.141592653589793;
+    double ssfac = 0.0, mu0s = 0.0, sflux = 0.0;
+    if (p.mode == 2) {
+        const double mu = cos(p.emiss_ang[ip] / 180. * PI_);
+        mu0s = cos(p.sol_ang[ip] / 180. * PI_);
+        ssfac = mu0s / (mu0s + mu);
+        sflux = p.solflux ? p.solflux[nuc] : 0.0;
+    }
+    auto scatter_term = [&](int j, int k, double tvk, double tc, double dtr) -> double {
+        // (trold - tr) * ssfac * omega * phase * SOLFLUX / (4 pi), in the reference's order of operations (:6577)
+        const int lay = (int)m_lay[j];
+        const int g = gy + k * kGY;
+        double om;
+        if (p.omega) om = p.omega[((size_t)j * G + g) * p.Wpad + nu];
+        else {
+            const double tt = tvk + tc;                                   // vertical TAUTOT of the layer (:3989)
+            om = (tt > 0.0) ? p.sca[(size_t)lay * p.Wpad + nu] / tt : 0.0;
+        }
+        const double ph = p.phase[((size_t)ip * p.L + lay) * p.Wpad + nu];
+        return dtr * ssfac * om * ph * sflux / (4. * PI_);
+    };
     double tvA[kGPer], tvB[kGPer], tcA = 0.0, tcB = 0.0, emA = 0.0, emB = 0.0;
     auto integrate = [&](int j, const double tv[kGPer], double tc, double em) {
         const double sc = m_sc[j];
@@ -1356,6 +1385,7 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
                 const double t = (tv[k] + tc) * sc;  // :3989, :4006
                 taud[k] += t;
                 const double tr = exp(-taud[k]);
+                if (p.mode == 2) spec[k] += scatter_term(j, k, tv[k], tc, trold[k] - tr);   // before the thermal term (:6577-6581)
                 spec[k] += (trold[k] - tr) * bb;  // :6345-6348
                 if (p.emi) spec[k] += em * tr;
                 trold[k] = tr;
@@ -1402,7 +1432,14 @@ __global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
         if (g < G) {
             double s = spec[k];
             if (p.mode == 1) s = exp(-taud[k]);                               // :4116, xfac = solar flux when IFORM = 4 (:4119-4127)
-            else {
+            else if (p.mode == 2) {                                           // :6585-6596: lower boundary whatever the geometry
+                const double ts = p.tsurf[m];
+                double rg;
+                if (ts <= 0.0) rg = planck_bb(a, c2y, p.emtemp[pathbase + (size_t)(nl - 1) * p.P]);
+                else rg = planck_bb(a, c2y, ts) * (p.emissivity ? p.emissivity[nuc] : 0.0);
+                s += trold[k] * rg;
+                s += trold[k] * sflux * mu0s * (p.brdf ? p.brdf[(size_t)nuc * p.P + ip] : 0.0);
+            } else {
                 if (ground) s += trold[k] * radground;
                 if (solar_on) s += trold[k] * exp(-taud[k] * muratio) * solterm;  // :6368-6373
             }

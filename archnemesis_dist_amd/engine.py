@@ -240,6 +240,38 @@ class AnsfmEngine:
         self._check(rc, "cirsrad_ck_thermal")
         return out[0] if single else out
 
+    def calc_singlescatt_plane_spectrum(self, ISPACE, WAVE, TAUTOT_PATH, TEMP, OMEGA, PHASE, TSURF, EMISSIVITY, BRDF, SOLFLUX,
+                                        SOL_ANG, EMISS_ANG):
+        """ForwardModel_0.calc_singlescatt_plane_spectrum (:6509), same arguments -> SPECOUT (NWAVE, NG)."""
+        TAU = _np(TAUTOT_PATH); W, G, Li = TAU.shape
+        out = np.empty((W, G))
+        rc = self._lib.ansfm_singlescatt_plane_spectrum(
+            self._ctx, int(ISPACE), W, G, Li, _ptr(_np(WAVE)), _ptr(TAU), _ptr(_np(TEMP)), _ptr(_np(OMEGA).reshape(W, G, Li)),
+            _ptr(_np(PHASE).reshape(W, Li)), float(TSURF), _ptr(_np(EMISSIVITY)), _ptr(_np(BRDF)), _ptr(_np(SOLFLUX)),
+            float(SOL_ANG), float(EMISS_ANG), _ptr(out))
+        self._check(rc, "singlescatt_plane_spectrum")
+        return out
+
+    def cirsrad_ck_singlescatt(self, ISPACE, lay_press_pa, lay_temp, amount, taucont, tausca, phase, NLAYIN, LAYINC, SCALE, EMTEMP,
+                               TSURF, EMISSIVITY, BRDF, SOLFLUX, SOL_ANG, EMISS_ANG, xfac=None):
+        """CIRSrad, single-scattering branch (:4251-4336) on the uploaded k-table: taucont / tausca (NWAVE, NLAY), phase
+        (NPATH, NWAVE, NLAY), BRDF (NWAVE, NPATH) -> SPECOUT (NWAVE, NPATH)."""
+        W, G, NP, NT, S = self.dims
+        lp = _np(lay_press_pa); L = lp.shape[0]
+        LAYINC = _np(LAYINC, np.int32); NLAYIN = _np(np.atleast_1d(NLAYIN), np.int32)
+        if LAYINC.ndim == 1:
+            LAYINC = LAYINC[:, None]
+        LIMAX, P = LAYINC.shape
+        out = np.empty((W, P))
+        rc = self._lib.ansfm_cirsrad_ck_singlescatt(
+            self._ctx, int(ISPACE), L, _ptr(lp), _ptr(_np(lay_temp)), _ptr(_np(amount).reshape(S, L)),
+            _ptr(None if taucont is None else _np(taucont).reshape(W, L)), _ptr(_np(tausca).reshape(W, L)),
+            _ptr(_np(phase).reshape(P, W, L)), P, LIMAX, _ptr(NLAYIN), _ptr(LAYINC), _ptr(_np(SCALE).reshape(LIMAX, P)),
+            _ptr(_np(EMTEMP).reshape(LIMAX, P)), float(TSURF), _ptr(_np(EMISSIVITY)), _ptr(_np(BRDF).reshape(W, P)),
+            _ptr(_np(SOLFLUX)), _ptr(_np(np.atleast_1d(SOL_ANG))), _ptr(_np(np.atleast_1d(EMISS_ANG))), _ptr(_np(xfac)), _ptr(out))
+        self._check(rc, "cirsrad_ck_singlescatt")
+        return out
+
     def cirsrad_ck_transmission(self, lay_press_pa, lay_temp, amount, taucont, NLAYIN, LAYINC, SCALE, xfac=None):
         """CIRSrad, pure-transmission branch (calculate_transmission_spectrum :4110): SPECOUT (n, W, P) (or (W, P)) =
         xfac * sum_g DELG exp(-sum over the path's layers of TAUTOT_LAYINC)."""

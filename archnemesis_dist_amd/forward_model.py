@@ -155,6 +155,8 @@ class CIRSradGPU:
             return False           # calculate_absorption_spectrum (:4133) lacks `self` in the reference: never callable
         if imod & IMOD_THERMAL_EMISSION:
             return True
+        if imod & IMOD_SINGLE_SCATTERING_PLANE_PARALLEL:
+            return (not return_grad) and int(S.ILBL) == ILBL_K_TABLES
         if self._ansfm_scatter_branch(imod):
             return (not return_grad) and int(S.ILBL) == ILBL_K_TABLES      # the reference has no gradients there either
         return False
@@ -259,6 +261,51 @@ class CIRSradGPU:
             f_gas[i, :] = L.AMOUNT[:, IGAS] * SQ_CM_TO_SQ_METER             # :3861
         return f_gas
 
+    # ---- single-scattering branch: host preparation of :4251-4336 for what has no g axis ---------------------------
+    def _ansfm_cirsrad_singlescatt(self, eng, taucont, TAURAY, f_gas):
+        """calculate_single_scattering_plane_parallel_spectrum (:4251-4336): scattering angle, phase functions of the aerosols
+        and of Rayleigh scattering, their opacity-weighted mean per layer, solar flux, units, emissivity and BRDF on the host;
+        OMEGA and the layer loop (calc_singlescatt_plane_spectrum :6509) on the device.  -> SPECOUT (NWAVE, NPATH)."""
+        import scipy.interpolate
+        S, L, P, Sc, Su, M = self.SpectroscopyX, self.LayerX, self.PathX, self.ScatterX, self.SurfaceX, self.MeasurementX
+        WAVE = np.asarray(S.WAVE, dtype=np.float64)
+        W, ND = WAVE.size, int(Sc.NDUST)
+        sol, emi, azi = (np.asarray(a, dtype=np.float64) for a in (P.SOL_ANG, P.EMISS_ANG, P.AZI_ANG))
+        rad = np.pi / 180.
+        calpha = np.sin(sol * rad) * np.sin(emi * rad) * np.cos(azi * rad - np.pi) - np.cos(emi * rad) * np.cos(sol * rad)   # :4267
+        alpha = np.arccos(calpha) / np.pi * 180.
+        pf = np.zeros((W, len(sol), ND + 1))                                     # :4271-4274
+        pf[:, :, 0:ND] = Sc.calc_phase(alpha, WAVE)
+        pf[:, :, ND] = Sc.calc_phase_ray(alpha)
+        TAUSCAT, TAUCLSCAT = L.TAUSCAT, L.TAUCLSCAT
+        tsca = TAURAY + TAUSCAT
+        # layer-mean phase function of every path: sum_c P_c(alpha) tau_c / (TAURAY + TAUSCAT) where that is > 0 (:4314-4322)
+        num = np.einsum("wpc,wlc->pwl", pf[:, :, 0:ND], TAUCLSCAT) + pf[:, :, ND].T[:, :, None] * TAURAY[None, :, :]
+        phase = np.where(num > 0, num / np.where(num > 0, tsca[None], 1.0), num)
+        if self.StellarX.SOLEXIST is True:                                       # :4286-4290
+            self.StellarX.calc_solar_flux()
+            solar = np.interp(WAVE, self.StellarX.WAVE, self.StellarX.SOLFLUX)
+        else:
+            solar = np.zeros(W)
+        xfac = np.ones(W)
+        if int(M.IFORM) == IFORM_FLUXRATIO:                                      # :4293-4298 (the power spectrum on VCONV)
+            xfac *= np.pi * 4. * np.pi * ((self.AtmosphereX.RADIUS) * 1.0e2) ** 2.
+            xfac = xfac / scipy.interpolate.interp1d(self.StellarX.VCONV, self.StellarX.SOLSPEC)(WAVE)
+        if Su.TSURF > 0.0:
+            emissivity = scipy.interpolate.interp1d(Su.VEM, Su.EMISSIVITY)(WAVE)
+        else:
+            emissivity = np.zeros(W)
+        if int(Su.LOWBC) != 0:                                                   # :4308-4311 (0 = THERMAL)
+            BRDF = Su.calc_BRDF(WAVE, P.SOL_ANG, P.EMISS_ANG, P.AZI_ANG)
+        else:
+            BRDF = np.zeros((W, len(sol)))
+        NPATH = len(sol)
+        return eng.cirsrad_ck_singlescatt(
+            int(M.ISPACE), np.asarray(L.PRESS, dtype=np.float64), np.asarray(L.TEMP, dtype=np.float64), f_gas, taucont, tsca,
+            phase, np.asarray(P.NLAYIN, dtype=np.int32).reshape(NPATH), np.asarray(P.LAYINC, dtype=np.int32).reshape(-1, NPATH),
+            np.asarray(P.SCALE, dtype=np.float64).reshape(-1, NPATH), np.asarray(P.EMTEMP, dtype=np.float64).reshape(-1, NPATH),
+            float(Su.TSURF), emissivity, BRDF, solar, sol, emi, xfac=xfac)
+
     # ---- scattering branch: host preparation of scloud11wave (:5018-5165) for what has no g axis ----------------
     def _ansfm_cirsrad_scatter(self, eng, TAUCIA, TAUDUST, TAURAY, f_gas):
         """calculate_multiple_scattering_spectrum (:4343-4374) + scloud11wave (:5018-5165): the boundary vectors, phase
@@ -336,6 +383,12 @@ class CIRSradGPU:
                 np.asarray(L.PRESS, dtype=np.float64), np.asarray(L.TEMP, dtype=np.float64), f_gas, taucont,
                 np.asarray(P.NLAYIN, dtype=np.int32).reshape(NPATH), np.asarray(P.LAYINC, dtype=np.int32).reshape(-1, NPATH),
                 np.asarray(P.SCALE, dtype=np.float64).reshape(-1, NPATH), xfac=xf)
+            if self.ansfm_keep_side_products:
+                L.TAUGAS = eng.get_taugas(L.NLAY, 0)
+                L.TAUTOT = self._ansfm_total_opacity(L.TAUGAS, TAUCIA, TAUDUST, TAURAY)
+            return SPECOUT
+        if (imod0 & IMOD_SINGLE_SCATTERING_PLANE_PARALLEL) and not (imod0 & IMOD_THERMAL_EMISSION):   # dispatch order :4487-4493
+            SPECOUT = self._ansfm_cirsrad_singlescatt(eng, taucont, TAURAY, f_gas)
             if self.ansfm_keep_side_products:
                 L.TAUGAS = eng.get_taugas(L.NLAY, 0)
                 L.TAUTOT = self._ansfm_total_opacity(L.TAUGAS, TAUCIA, TAUDUST, TAURAY)

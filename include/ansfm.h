@@ -157,6 +157,27 @@ int ansfm_thermal_emission_g(ansfm_ctx *ctx, int ISPACE, int W, int G, int NPAR,
                              const double *PRESS, double TSURF, const double *EMISSIVITY, double *SPECOUT,
                              double *dSPECOUT, double *dTSURF);
 
+/* ForwardModel_0.calc_singlescatt_plane_spectrum (ForwardModel_0.py:6509-6600), array level: plane-parallel thermal
+ * emission + singly scattered sunlight (ssfac * omega * phase * SOLFLUX / 4 pi per layer) + lower boundary (always added) +
+ * sunlight reflected by the ground (BRDF).  TAUTOT_PATH / OMEGA[W][G][Li], PHASE[W][Li], TEMP[Li], EMISSIVITY / BRDF /
+ * SOLFLUX[W] -> SPECOUT[W][G]. */
+int ansfm_singlescatt_plane_spectrum(ansfm_ctx *ctx, int ISPACE, int W, int G, int NLAYIN, const double *WAVE,
+                                     const double *TAUTOT_PATH, const double *TEMP, const double *OMEGA, const double *PHASE,
+                                     double TSURF, const double *EMISSIVITY, const double *BRDF, const double *SOLFLUX,
+                                     double SOL_ANG, double EMISS_ANG, double *SPECOUT);
+
+/* CIRSrad, single-scattering branch (IMOD & SINGLE_SCATTERING_PLANE_PARALLEL; ForwardModel_0.py:4493 ->
+ * calculate_single_scattering_plane_parallel_spectrum :4251-4336) fused with the opacity assembly: the albedo
+ * OMEGA = (TAURAY + TAUSCAT) / TAUTOT of every (wavenumber, g, layer) is formed in the RT kernel from the vertical opacities.
+ * Host pointers: taucont[W][L] = TAUCIA + TAUDUST + TAURAY, tausca[W][L] = TAURAY + TAUSCAT, phase[P][W][L] = the layer-mean
+ * phase function at each path's scattering angle (:4318-4322), BRDF[W][P], SOLFLUX[W], angles [P] -> SPECOUT[W][P]. */
+int ansfm_cirsrad_ck_singlescatt(ansfm_ctx *ctx, int ISPACE, int L, const double *lay_press_pa, const double *lay_temp,
+                                 const double *amount, const double *taucont, const double *tausca, const double *phase, int P,
+                                 int LIMAX, const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE,
+                                 const double *EMTEMP, double TSURF, const double *EMISSIVITY, const double *BRDF,
+                                 const double *SOLFLUX, const double *SOL_ANG, const double *EMISS_ANG, const double *xfac,
+                                 double *SPECOUT);
+
 /* ---- fused seam: CIRSrad, ILBL=K_TABLES, IMOD=THERMAL_EMISSION ------------------------------
  * ForwardModel_0.CIRSrad (ForwardModel_0.py:4376-4511) =
  *   calculate_gaseous_line_opacity (:3850-3877: calc_k -> k_overlap)

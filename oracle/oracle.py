@@ -137,6 +137,31 @@ def calc_thermal_emission_spectrumg(ISPACE, WAVE, TAUTOT_PATH, dTAUTOT_PATH, NVM
     return spec, dspec, dts
 
 
+def calc_singlescatt_plane_spectrum(ISPACE, WAVE, TAUTOT_PATH, TEMP, OMEGA, PHASE, TSURF, EMISSIVITY, BRDF, SOLFLUX, SOL_ANG,
+                                    EMISS_ANG):
+    """ForwardModel_0.calc_singlescatt_plane_spectrum (:6509-6600), NumPy over (wavenumber, g), the layer loop sequential
+    with the reference's order of operations -> SPECOUT (NWAVE, NG)."""
+    WAVE = np.asarray(WAVE, float); TAU = np.asarray(TAUTOT_PATH, float); OMEGA = np.asarray(OMEGA, float)
+    PHASE = np.asarray(PHASE, float); SOLFLUX = np.asarray(SOLFLUX, float)
+    W, G, Li = TAU.shape
+    mu = np.cos(EMISS_ANG / 180. * np.pi); mu0 = np.cos(SOL_ANG / 180. * np.pi)
+    ssfac = mu0 / (mu0 + mu)
+    taud = np.zeros((W, G)); trold = np.ones((W, G)); spec = np.zeros((W, G))
+    for j in range(Li):
+        taud = taud + TAU[:, :, j]
+        tr = np.exp(-taud)
+        spec = spec + (trold - tr) * ssfac * OMEGA[:, :, j] * PHASE[:, j][:, None] * SOLFLUX[:, None] / (4. * np.pi)
+        spec = spec + (trold - tr) * planck(ISPACE, WAVE, TEMP[j])[:, None]
+        trold = tr
+    if TSURF <= 0.0:
+        radground = planck(ISPACE, WAVE, TEMP[Li - 1])
+    else:
+        radground = planck(ISPACE, WAVE, TSURF) * np.asarray(EMISSIVITY, float)
+    spec = spec + trold * radground[:, None]
+    spec = spec + trold * SOLFLUX[:, None] * mu0 * np.asarray(BRDF, float)[:, None]
+    return spec
+
+
 def cirsrad_ck_thermal(ISPACE, K, TPRESS, TTEMP, WAVE, DELG, lay_press_pa, lay_temp, amount,
                        TAUCONT, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None, SOLFLUX=None,
                        REFLECTANCE=None, SOL_ANG=None, EMISS_ANG=None, xfac=None, return_taugas=False):

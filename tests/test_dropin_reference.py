@@ -75,6 +75,27 @@ class OracleEngineDouble:
         out = np.tensordot(spec, np.asarray(D, dtype=float), axes=([1], [0]))
         return (out, spec) if return_spec_g else out
 
+    def cirsrad_ck_singlescatt(self, ISPACE, lp, lt, am, taucont, tausca, phase, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMIS,
+                               BRDF, SOLF, sol, emi, xfac=None):
+        """ansfm_cirsrad_ck_singlescatt answered by the oracle's pieces (:3989, :4276-4283, :4006, :6509, :4504)."""
+        K, P, T, W, D = self.t
+        self.ss_calls = getattr(self, "ss_calls", 0) + 1
+        k = self.orc.calc_k(K, P, T, np.asarray(lp) / 101325.0, lt)
+        self.tg = self.orc.k_overlap(D, k, am)
+        tautot = self.tg + np.asarray(taucont)[:, None, :]
+        omega = np.where(tautot > 0, np.asarray(tausca)[:, None, :] / np.where(tautot > 0, tautot, 1.0), 0.0)
+        NP_ = len(np.atleast_1d(sol))
+        out = np.zeros((len(W), NP_))
+        xf = np.ones(len(W)) if xfac is None else np.asarray(xfac)
+        for ip in range(NP_):
+            n = int(NLAYIN[ip]); li = np.asarray(LAYINC)[:n, ip]
+            sp = self.orc.calc_singlescatt_plane_spectrum(ISPACE, W, tautot[:, :, li] * np.asarray(SCALE)[:n, ip],
+                                                          np.asarray(EMTEMP)[:n, ip], omega[:, :, li], np.asarray(phase)[ip][:, li],
+                                                          TSURF, EMIS, np.asarray(BRDF)[:, ip], SOLF, np.atleast_1d(sol)[ip],
+                                                          np.atleast_1d(emi)[ip])
+            out[:, ip] = np.tensordot(sp * xf[:, None], np.asarray(D, dtype=float), axes=([1], [0]))
+        return out
+
     def layer_average(self, *a, **k):
         self.lay_calls = getattr(self, "lay_calls", 0) + 1
         return self.orc.layer_average(*a, **k)
@@ -229,6 +250,62 @@ def test_scattering_nemesisfm_through_the_adapter_matches_the_reference(oracle, 
     np.testing.assert_allclose(SPECONV, z["SPECONV"], rtol=1e-8)
     np.testing.assert_allclose(fm.LayerX.TAUGAS, z["TAUGAS"], rtol=2e-7)
     np.testing.assert_allclose(fm.LayerX.TAUTOT, z["TAUTOT"], rtol=2e-7)
+
+
+def test_single_scattering_nemesisfm_through_the_adapter_matches_the_reference(oracle, monkeypatch):
+    """ISCAT = SINGLE_SCATTERING_PLANE_PARALLEL on the same inputs: the unmodified reference's nemesisfm against the
+    adapter's (CIRSrad's single-scattering branch -> ansfm_cirsrad_ck_singlescatt, here the double), in one process."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle.ref_import import import_reference
+    from oracle.gen_golden_c1 import GASES
+    ans = import_reference()
+    sp_mod = sys.modules["archnemesis.Spectroscopy_0"]
+    import archnemesis_dist_amd.forward_model as fmod
+    src = os.path.join(REF, "tests", "files", "Jupiter_CIRS_angled_thermal_emission_scattering")
+    work = tempfile.mkdtemp(prefix="ansfm_dropin_ss_")
+    cwd = os.getcwd()
+    NKEEP = 12
+    try:
+        for f in os.listdir(src):
+            shutil.copy(os.path.join(src, f), os.path.join(work, f))
+            os.chmod(os.path.join(work, f), 0o644)
+        rng = np.random.default_rng(6)
+        x, w = np.polynomial.legendre.leggauss(10)
+        PRESS = np.logspace(-7, 1.2, 12); TEMP = np.linspace(70.0, 400.0, 8)
+        names = []
+        for name, gid, iso in GASES:
+            base = 10.0 ** rng.uniform(-26, -22, size=(599, 1, 1, 1))
+            gs = np.sort(10.0 ** rng.uniform(-2, 2, size=(599, 10, 1, 1)), axis=1)
+            k = base * gs * PRESS[None, None, :, None] ** 0.1 * (TEMP[None, None, None, :] / 200.0)
+            fn = os.path.join(work, f"{name}_synth.kta")
+            sp_mod.write_ktable(fn, gid, iso, 0.5 * (x + 1.0), 0.5 * w, PRESS, TEMP, 599, 5.0, 2.5, 0.0, k)
+            names.append(fn)
+        with open(os.path.join(work, "cirstest.kls"), "w") as f:
+            f.write("\n".join(names) + "\n")
+        os.chdir(work)
+
+        def run(cls):
+            Atm, Meas, Spec, Scat, Stel, Surf, CIA, Lay, Var, Ret = ans.Files.read_input_files("cirstest")
+            Scat.ISCAT = 3                                   # ScatteringCalculationModeEnum.SINGLE_SCATTERING_PLANE_PARALLEL
+            Meas.NCONV = np.array([NKEEP], dtype="int32")
+            Meas.VCONV = Meas.VCONV[:NKEEP]; Meas.MEAS = Meas.MEAS[:NKEEP]; Meas.ERRMEAS = Meas.ERRMEAS[:NKEEP]
+            Meas.NY = NKEEP
+            fm = cls(runname="cirstest", Atmosphere=Atm, Surface=Surf, Measurement=Meas, Spectroscopy=Spec, Stellar=Stel,
+                     Scatter=Scat, CIA=CIA, Layer=Lay, Variables=Var)
+            return fm, fm.nemesisfm()
+
+        _, ref = run(ans.ForwardModel_0)
+        double = OracleEngineDouble(oracle)
+        monkeypatch.setattr(fmod, "get_engine", lambda device=0: double)
+        fmod.set_strict(True)
+        fm, got = run(fmod.make_gpu_forward_model(ans.ForwardModel_0))
+    finally:
+        fmod.set_strict(False)
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+    assert double.ss_calls == 1 and int(np.asarray(fm.PathX.IMOD)[0]) & 1024
+    assert np.all(ref > 0)
+    np.testing.assert_allclose(got, ref, rtol=1e-9)
 
 
 def test_nemesisfm_through_the_adapter_matches_the_reference(c1_run, oracle, golden_dir, monkeypatch):

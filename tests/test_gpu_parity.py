@@ -1286,3 +1286,57 @@ def test_cirsrad_transmission_vs_oracle(eng, oracle):
         path = np.sum(tautot[:, :, LAYINC] * SCALE, axis=2)                         # TAUTOT_PATH (:4006-4009)
         ref = np.tensordot(np.exp(-path) * solflux[:, None, None], delg, axes=([1], [0]))
         np.testing.assert_allclose(got[m], ref, rtol=1e-11)
+
+
+def test_singlescatt_plane_spectrum_golden(eng, golden_dir):
+    """Array-level calc_singlescatt_plane_spectrum (:6509-6600) vs the reference (golden): both spectral units, without /
+    with a surface, a grazing geometry."""
+    z = _load(golden_dir, "singlescatt")
+    for ispace, tag in ((0, "wn"), (1, "wl")):
+        for cn in ("nosurf", "surf", "graze"):
+            TSURF, sa, ea = z[f"{tag}_{cn}_args"]
+            s = eng.calc_singlescatt_plane_spectrum(ispace, z[f"{tag}_WAVE"], z[f"{tag}_TAU"], z[f"{tag}_TEMP"], z[f"{tag}_OMEGA"],
+                                                    z[f"{tag}_PHASE"], TSURF, z[f"{tag}_EMIS"], z[f"{tag}_BRDF"], z[f"{tag}_SOL"], sa, ea)
+            np.testing.assert_allclose(s, z[f"{tag}_{cn}_spec"], rtol=1e-11, err_msg=f"{tag} {cn}")
+
+
+def test_cirsrad_singlescatt_vs_oracle(eng, oracle):
+    """CIRSrad's single-scattering branch fused with the opacity assembly (ansfm_cirsrad_ck_singlescatt) vs the reference's
+    recipe on the oracle's pieces: calc_k + k_overlap, TAUTOT (:3989), OMEGA (:4276-4283), LAYINC x SCALE (:4006),
+    calc_singlescatt_plane_spectrum per path, xfac, g-quadrature (:4504).  Two paths of different length and geometry."""
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(88)
+    W, G, S, L = 100, 10, 3, 9
+    PRESS, TEMP, K = syn.synth_ktable(W, G, 8, 6, S, seed=31)
+    _, delg = syn.gauss_legendre_01(G)
+    WAVE = 2000.0 + 3.0 * np.arange(W)
+    eng.upload_ktable(K, PRESS, TEMP, WAVE, delg)
+    lp = np.logspace(5.0, 1.0, L); lt = np.linspace(230.0, 150.0, L)
+    am = 10.0 ** rng.uniform(17, 19.5, (S, L)) * (lp[None, :] / lp[0])
+    TAURAY = 10.0 ** rng.uniform(-4, -2, (W, L)); TAUSCAT = 10.0 ** rng.uniform(-3, -1, (W, L)); TAUSCAT[:, 4] = 0.0
+    TAUDUST = TAUSCAT * 1.2; TAUCIA = 10.0 ** rng.uniform(-5, -3, (W, L))
+    cont = TAUCIA + TAUDUST + TAURAY
+    P = 2
+    phase = 10.0 ** rng.uniform(-1.5, 0.3, (P, W, L))
+    LAYINC = np.zeros((L, P), dtype=np.int32)
+    LAYINC[:, 0] = np.arange(L - 1, -1, -1); LAYINC[:L - 2, 1] = np.arange(L - 1, 1, -1)
+    NLAYIN = np.array([L, L - 2], dtype=np.int32)
+    sol = np.array([30.0, 55.0]); emi = np.array([10.0, 40.0])
+    SCALE = np.where(np.arange(L)[:, None] < NLAYIN[None, :], 1.0 / np.cos(np.deg2rad(emi))[None, :], 0.0)
+    EMTEMP = np.where(np.arange(L)[:, None] < NLAYIN[None, :], lt[LAYINC], 0.0)
+    EMIS = rng.uniform(0.7, 1.0, W); BRDF = rng.uniform(0.0, 0.15, (W, P)); SOLF = 10.0 ** rng.uniform(-8, -7, W)
+    xfac = rng.uniform(0.5, 2.0, W)
+    for TSURF in (-1.0, 260.0):
+        got = eng.cirsrad_ck_singlescatt(0, lp, lt, am, cont, TAURAY + TAUSCAT, phase, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMIS,
+                                         BRDF, SOLF, sol, emi, xfac=xfac)
+        k = oracle.calc_k(K, PRESS, TEMP, lp / 101325.0, lt)
+        tautot = oracle.k_overlap(delg, k, am) + cont[:, None, :]
+        omega = np.where(tautot > 0, (TAURAY + TAUSCAT)[:, None, :] / np.where(tautot > 0, tautot, 1.0), 0.0)
+        ref = np.zeros((W, P))
+        for ip in range(P):
+            n = NLAYIN[ip]; li = LAYINC[:n, ip]
+            tpath = tautot[:, :, li] * SCALE[:n, ip]
+            sp = oracle.calc_singlescatt_plane_spectrum(0, WAVE, tpath, EMTEMP[:n, ip], omega[:, :, li], phase[ip][:, li], TSURF,
+                                                        EMIS, BRDF[:, ip], SOLF, sol[ip], emi[ip])
+            ref[:, ip] = np.tensordot(sp * xfac[:, None], delg, axes=([1], [0]))
+        np.testing.assert_allclose(got, ref, rtol=1e-11)

@@ -96,3 +96,15 @@ def test_calc_klbl(oracle, golden_dir, name):
     kg, dk = oracle.calc_klbl(z["K"], z["TPRESS"], z["TTEMP"], z["press"], z["temp"], grad=True)
     np.testing.assert_allclose(kg, z["kg"], rtol=1e-12, atol=0)
     np.testing.assert_allclose(dk, z["dkdT"], rtol=1e-10, atol=0)
+
+
+def test_singlescatt_plane_spectrum_oracle_vs_reference_golden(oracle, golden_dir):
+    """calc_singlescatt_plane_spectrum (:6509-6600): the oracle's NumPy restatement vs the reference's own function."""
+    z = np.load(os.path.join(golden_dir, "singlescatt.npz"))
+    for ispace, tag in ((0, "wn"), (1, "wl")):
+        for cn in ("nosurf", "surf", "graze"):
+            TSURF, sa, ea = z[f"{tag}_{cn}_args"]
+            s = oracle.calc_singlescatt_plane_spectrum(ispace, z[f"{tag}_WAVE"], z[f"{tag}_TAU"], z[f"{tag}_TEMP"], z[f"{tag}_OMEGA"],
+                                                       z[f"{tag}_PHASE"], TSURF, z[f"{tag}_EMIS"], z[f"{tag}_BRDF"], z[f"{tag}_SOL"],
+                                                       sa, ea)
+            np.testing.assert_allclose(s, z[f"{tag}_{cn}_spec"], rtol=1e-13, err_msg=f"{tag} {cn}")
