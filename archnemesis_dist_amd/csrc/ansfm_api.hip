@@ -78,6 +78,9 @@ struct ansfm_ctx {
     DevBuf hb[24];  // staging buffers of the host-pointer entry points
     int last_n = 0, last_L = 0;
 
+    // scattering core: the Hansen walk of g-ordinate g + 1 runs on a second stream beside the chains of g
+    hipStream_t ms_stream = nullptr;
+    std::vector<hipEvent_t> ms_ev;
     // timing of the last cirsrad call
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double overlap_ms = 0, rt_ms = 0;
@@ -148,6 +151,8 @@ void ansfm_destroy(ansfm_ctx *ctx)
     for (auto *b : bufs) b->release();
     for (auto &b : ctx->hb) b.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ms_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->ms_stream) (void)hipStreamDestroy(ctx->ms_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -2044,6 +2049,7 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     p.drad = ctx->tmp_in2.as<double>();
     p.rad = ctx->tmp_out.as<double>();
     const int ncomp_run = ncont + (iray > 0 ? 1 : 0);
+    p.ig0 = 0; p.ng_launch = ng;
     if (ncomp_run > 0) {
         // Rayleigh lives in slot ncont even when there are no aerosols
         if (ncont > 0)
@@ -2054,21 +2060,57 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
             hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, 1), dim3(256), 0, ctx->stream, pr);
         }
         HIPCHK(hipGetLastError());
-        // one sequential walk per scatterer, all scatterers side by side (Rayleigh = slot ncont)
-        p.hansen_comp0 = 0;
-        if (nmu == 16) hipLaunchKernelGGL(k_ms_hansen_seq<16>, dim3((unsigned)ncomp_run), dim3(64), 0, ctx->stream, p);
-        else hipLaunchKernelGGL(k_ms_hansen_seq<0>, dim3((unsigned)ncomp_run), dim3(64), 0, ctx->stream, p);
+    }
+    p.hansen_comp0 = 0;
+    if (nmu == 16) {
+        // matrix-core products (v_mfma_f64_16x16x4_f64), 7 LDS matrices with leading dimension 17; one block per (wavenumber,
+        // g) works through the Fourier orders and stops at the reference's convergence break (writes rad itself).
+        // The Hansen walk is sequential over (g, wave) -- two waves on the whole chip -- so it is cut into one launch per
+        // g-ordinate on a second stream and the chains of g start as soon as its factors exist: the walk of g + 1 hides
+        // behind them (it was 11-18 % of a call when it ran ahead of all chains).
+        const size_t lds16 = (7 * 16 * 17 + 4 * 16) * D;
+        if (ncomp_run > 0) {
+            if (!ctx->ms_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->ms_stream, hipStreamNonBlocking));
+            while ((int)ctx->ms_ev.size() < ng + 2) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ctx->ms_ev.push_back(e);
+            }
+            HIPCHK(hipEventRecord(ctx->ms_ev[ng], ctx->stream));                    // phase matrices (and every input) ready
+            HIPCHK(hipStreamWaitEvent(ctx->ms_stream, ctx->ms_ev[ng], 0));
+            for (int g = 0; g < ng; ++g) {
+                MsParams ph = p;
+                ph.ig0 = g; ph.ng_launch = 1;
+                hipLaunchKernelGGL(k_ms_hansen_seq<16>, dim3((unsigned)ncomp_run), dim3(64), 0, ctx->ms_stream, ph);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(ctx->ms_ev[g], ctx->ms_stream));
+            }
+            for (int g = 0; g < ng; ++g) {
+                MsParams pc = p;
+                pc.ig0 = g; pc.ng_launch = 1;
+                HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ms_ev[g], 0));
+                hipLaunchKernelGGL(k_ms_chain16, dim3((unsigned)nwave), dim3(64), lds16, ctx->stream, pc);
+                HIPCHK(hipGetLastError());
+            }
+            // the second stream must not run into the next call's buffers: it rejoins the main one here
+            HIPCHK(hipEventRecord(ctx->ms_ev[ng + 1], ctx->ms_stream));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ms_ev[ng + 1], 0));
+        } else {
+            hipLaunchKernelGGL(k_ms_chain16, dim3((unsigned)((size_t)nwave * ng)), dim3(64), lds16, ctx->stream, p);
+            HIPCHK(hipGetLastError());
+        }
+    } else {
+        if (ncomp_run > 0) {
+            hipLaunchKernelGGL(k_ms_hansen_seq<0>, dim3((unsigned)ncomp_run), dim3(64), 0, ctx->stream, p);
+            HIPCHK(hipGetLastError());
+        }
+        const dim3 cgrid((unsigned)((size_t)nwave * ng * (nf + 1)));
+        hipLaunchKernelGGL(k_ms_chain, cgrid, dim3(64), (12 * nn + 6 * kMsMaxMu + 2) * D, ctx->stream, p);
+        HIPCHK(hipGetLastError());
+        const size_t tot = (size_t)nwave * ng * ngeom;
+        hipLaunchKernelGGL(k_ms_fourier, dim3(nblk(tot, 128)), dim3(128), 0, ctx->stream, p);
         HIPCHK(hipGetLastError());
     }
-    const dim3 cgrid((unsigned)((size_t)nwave * ng * (nf + 1)));
-    if (nmu == 16)   // matrix-core products (v_mfma_f64_16x16x4_f64), 7 LDS matrices with leading dimension 17
-        hipLaunchKernelGGL(k_ms_chain16, cgrid, dim3(64), (7 * 16 * 17 + 4 * 16) * D, ctx->stream, p);
-    else
-        hipLaunchKernelGGL(k_ms_chain, cgrid, dim3(64), (12 * nn + 6 * kMsMaxMu + 2) * D, ctx->stream, p);
-    HIPCHK(hipGetLastError());
-    const size_t tot = (size_t)nwave * ng * ngeom;
-    hipLaunchKernelGGL(k_ms_fourier, dim3(nblk(tot, 128)), dim3(128), 0, ctx->stream, p);
-    HIPCHK(hipGetLastError());
     return ANSFM_OK;
 }
 

@@ -49,6 +49,7 @@ struct MsParams {
     double xfac;
     int hansen_comp0, phase_comp0;
     int lookup;              // all emission angles > 90: layers top to bottom, surface brought in with idown (:366-420)
+    int ig0, ng_launch;      // k_ms_hansen_seq / k_ms_chain16: the g-ordinates [ig0, ig0 + ng_launch) of this launch
 };
 
 __device__ __forceinline__ double ms_interp(double x, const double *xp, const double *fp, int n)
@@ -144,12 +145,18 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
             if (e < nn) { ppl_s[buf][e] = nppl[r]; pmi_s[buf][e] = npmi[r]; }
         }
     };
-    for (int e = tid; e < nn; e += 64) fc[e] = 1.0;
-    const long total = (long)p.ng * p.nwave;
+    // the walk of this launch: g-ordinates [ig0, ig0 + ng_launch), continuing from the factors the previous launch left
+    // for its last (g, wave) -- a launch per g-ordinate lets the chains of g run beside the walk of g + 1
+    if (p.ig0 == 0) { for (int e = tid; e < nn; e += 64) fc[e] = 1.0; }
+    else {
+        const double *pfc = p.fc + (((size_t)(p.ig0 - 1) * p.nwave + (p.nwave - 1)) * p.ncomp + comp) * nn;
+        for (int e = tid; e < nn; e += 64) fc[e] = pfc[e];
+    }
+    const long total = (long)p.ng_launch * p.nwave;
     fetch(0);
     stage(0);
     if (total > 1) fetch(1 % p.nwave);
-    int ig = 0, widx = 0;
+    int ig = p.ig0, widx = 0;
     for (long iter = 0; iter < total; ++iter) {
         const int buf = (int)(iter & 1);
         const double *ppl = ppl_s[buf], *pmi = pmi_s[buf];
@@ -629,17 +636,23 @@ __global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
     constexpr int n = 16, nn = 256, ld = 17, msz = 16 * 17;
     const Ms16 L{lane & 15, lane >> 4};
     const int c = L.c, q = L.q;
-    const int ic = blockIdx.x % (p.nf + 1);
-    const int ig = (blockIdx.x / (p.nf + 1)) % p.ng;
-    const int widx = blockIdx.x / ((p.nf + 1) * p.ng);
+    const int ig = p.ig0 + (int)(blockIdx.x % p.ng_launch);
+    const int widx = blockIdx.x / p.ng_launch;
     const double pi = 3.141592653589793;
     double *rc = sm, *tc = rc + msz, *r1 = tc + msz, *t1 = r1 + msz, *mA = t1 + msz, *mB = mA + msz, *mC = mB + msz;
     double *jc = mC + msz, *j1 = jc + 16, *v0 = j1 + 16, *radg = v0 + 16;
 #define MS_AT(M, i, j) M[(i) * ld + (j)]
 
     if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // radg[:, ::-1] :765
-    bool defined = false;
     const bool lookup = p.lookup != 0;
+    const double rmu_c = 1. / p.mu[c];
+    // Fourier sum of every path with the reference's early-out (:903-958), kept by lane `ipath`: the orders are worked
+    // through one after the other by this block, and it stops as soon as every path has converged -- the reference builds the
+    // operators of all NF + 1 orders first (:790) and never reads the ones beyond the break.
+    double frad = 0.0;
+    bool fconv1 = false, fdone = (lane >= p.ngeom);
+    for (int ic = 0; ic <= p.nf; ++ic) {
+    bool defined = false;
     if (p.lowbc > 0 && !lookup) {  // surface operator first :824-836
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -654,7 +667,6 @@ __global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
     const double *PPL = p.ppl + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
     const double *PMI = p.pmi + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
     const double *FC = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp) * nn;   // ppl *= fc (:232)
-    const double rmu_c = 1. / p.mu[c];
 
     for (int l = 0; l < p.nlay; ++l) {
         const int k = lookup ? p.nlay - 1 - l : l;  // look-down: bottom layer first (:842-845)
@@ -873,8 +885,17 @@ __global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
         double drad = ((1 - t) * (1 - u) * yx[0] + t * (1 - u) * yx[1] + t * u * yx[3] + (1 - t) * u * yx[2]) *
                       cos(ic * p.aphi[ipath] * pi / 180.0);
         if (ic > 0) drad *= 2;
-        p.drad[(((size_t)widx * p.ng + ig) * (p.nf + 1) + ic) * p.ngeom + ipath] = drad;
+        if (!fdone) {                                   // :945-958
+            frad += drad;
+            const double conv = fabs(drad / frad);
+            if (conv < 1e-5 && fconv1) fdone = true;
+            fconv1 = (conv < 1e-5);
+        }
     }
+    if (__builtin_amdgcn_ballot_w64(!fdone) == 0) break;
+    __syncthreads();                                    // the LDS matrices are rebuilt by the next order
+    }
+    if (lane < p.ngeom) p.rad[((size_t)lane * p.ng + ig) * p.nwave + widx] = frad;
 #undef MS_AT
 }
 
