@@ -1331,6 +1331,7 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
     r.emissivity = EMISSIVITY; r.xfac = xfac;
     r.out = SPECOUT;
     r.W = W; r.Wpad = Wpad; r.G = G; r.L = L; r.P = P; r.LIMAX = LIMAX; r.ispace = ISPACE; r.per_g = 0;
+    r.mode = ctx->rt_mode == 1 ? 1 : 0;      // 1: path transmission and its gradients (ansfm_cirsradg_ck_transmission)
     q.dk = ctx->dkbuf.as<double>();
     q.dcont = dcont_t;
     q.trold_ws = ctx->trold_ws.as<double>();
@@ -1417,6 +1418,24 @@ int ansfm_cirsradg_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L, c
     HIPCHK(hipMemcpyAsync(dSPECOUT, ctx->dspec_ref.p, ndsp * D, hipMemcpyDeviceToHost, ctx->stream));
     if (n_models == 1) { ctx->dspec_dims[0] = ctx->W; ctx->dspec_dims[1] = NPAR; ctx->dspec_dims[2] = LIMAX; ctx->dspec_dims[3] = P; }
     return check_unsorted(ctx);
+}
+
+int ansfm_cirsradg_ck_transmission(ansfm_ctx *ctx, int n_models, int L, const double *lay_press_pa,
+                                   const double *lay_temp, const double *amount, const double *taucont,
+                                   const double *dtaucon, int NVMR, int NPAR, const int32_t *igas_map, int P, int LIMAX,
+                                   const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE, const double *xfac,
+                                   double *SPECOUT, double *dSPECOUT)
+{
+    CHECK_CTX(ctx);
+    if (n_models <= 0 || P <= 0 || !SCALE || !SPECOUT || !dSPECOUT) FAIL(ANSFM_ERR_INVALID, "cirsradg_ck_transmission: bad argument");
+    std::vector<double> tsurf((size_t)n_models, -1.0), dts((size_t)n_models * ctx->W * P);
+    ctx->rt_mode = 1;
+    // no emission in this branch: SCALE stands in for the (unused) emission temperatures, dTSURF is identically zero
+    const int rc = ansfm_cirsradg_ck_thermal(ctx, 0, n_models, L, lay_press_pa, lay_temp, amount, taucont, dtaucon, NVMR, NPAR,
+                                             igas_map, P, LIMAX, NLAYIN, LAYINC, SCALE, SCALE, tsurf.data(), nullptr, xfac,
+                                             SPECOUT, dSPECOUT, dts.data());
+    ctx->rt_mode = 0;
+    return rc;
 }
 
 int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *del_g, const double *k,

@@ -1514,6 +1514,7 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
     const int nuc = nu < p.W ? nu : p.W - 1;
     const int ip = blockIdx.y, m = blockIdx.x;
     const int nl = p.nlayin[ip];
+    const bool transmission = p.mode == 1;   // calculate_transmission_spectrum with return_grad (:4110-4131)
     const int G = p.G, NP1 = q.NP1, NR = NP1 + 2;
     const double wv = p.wave[nuc];
     const double y = (p.ispace == 0) ? wv : 1.0e4 / wv;
@@ -1530,8 +1531,8 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
         const double sc = p.scale[pathbase + (size_t)j * p.P];
         const double T = p.emtemp[pathbase + (size_t)j * p.P];
         const double tc = p.cont ? p.cont[((size_t)m * p.L + lay) * p.Wpad + nu] : 0.0;
-        double bb, dB;
-        planckg_dev(p.ispace, y, T, bb, dB);
+        double bb = 0.0, dB = 0.0;
+        if (!transmission) planckg_dev(p.ispace, y, T, bb, dB);
         const double *trow = p.tau + (((size_t)m * p.L + lay) * G) * p.Wpad + nu;
 #pragma unroll
         for (int k = 0; k < kGPerG; ++k) {
@@ -1548,7 +1549,7 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
     int i1 = (int)(nl / 2.0) - 1;
     if (i1 < 0) i1 += nl;
     const double *lp = p.lay_press + (size_t)m * p.L;
-    const bool ground = lp[p.layinc[(size_t)(nl - 1) * p.P + ip]] > lp[p.layinc[(size_t)i1 * p.P + ip]];
+    const bool ground = !transmission && lp[p.layinc[(size_t)(nl - 1) * p.P + ip]] > lp[p.layinc[(size_t)i1 * p.P + ip]];
     double radground = 0.0, dradgrounddT = 0.0;
     if (ground) {
         const double ts = p.tsurf[m];
@@ -1569,7 +1570,7 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
             const int g = gy + k * GY;
             R[k] = 0.0;
             if (g < G) {
-                double sgl = spec[k];
+                double sgl = transmission ? trold[k] : spec[k];     // mode 1: exp(-tau of the path) (:4110)
                 if (ground) sgl += trold[k] * radground;
                 accs += (sgl * xf) * p.delg[g];
                 acct += ((ground ? trold[k] * dradgrounddT : 0.0) * xf) * p.delg[g];
@@ -1590,15 +1591,16 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
     }
     // ---- pass 2: backward sweep ------------------------------------------------------------------------
     double trnext[kGPerG];  // tr_m = trold_{m+1}
+    double trfin[kGPerG];   // transmission of the whole path
 #pragma unroll
-    for (int k = 0; k < kGPerG; ++k) trnext[k] = trold[k];
+    for (int k = 0; k < kGPerG; ++k) trnext[k] = trfin[k] = trold[k];
     double *dsp = q.dspec + (((size_t)m * p.P + ip) * q.NPAR) * (size_t)p.LIMAX * p.Wpad + nu;
     for (int mm = nl - 1; mm >= 0; --mm) {
         const int lay = p.layinc[(size_t)mm * p.P + ip];
         const double sc = p.scale[pathbase + (size_t)mm * p.P];
         const double T = p.emtemp[pathbase + (size_t)mm * p.P];
-        double bb, dB;
-        planckg_dev(p.ispace, y, T, bb, dB);
+        double bb = 0.0, dB = 0.0;
+        if (!transmission) planckg_dev(p.ispace, y, T, bb, dB);
         const double *dkl = q.dk + (((size_t)m * p.L + lay) * NP1) * GWp + nu;
         double X = 0.0, Z = 0.0;
         double *rb = red;
@@ -1611,7 +1613,7 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
             if (g < G) {
                 const double to = tws[(size_t)mm * GWp + (size_t)g * p.Wpad];
                 const double tr = trnext[k];
-                const double c = tr * bb - R[k];
+                const double c = transmission ? -trfin[k] : tr * bb - R[k];   // mode 1: d exp(-tau) / d tau_m (:4129)
                 const double dgk = p.delg[g];
                 cg[k] = c * dgk;
                 X += cg[k];
@@ -1647,7 +1649,7 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
             }
             if (q.dcont) v += q.dcont[(((size_t)m * q.NPAR + kpar) * p.L + lay) * p.Wpad + nu] * Xs;
             v *= sc;                                               // :4012
-            if (kpar == q.NVMR) v += Zs * dB;                      // :6467-6468
+            if (kpar == q.NVMR && !transmission) v += Zs * dB;     // :6467-6468
             v *= xf;                                               // :4247
             if (v != v) v = 0.0;                                   // nan_to_num :4507
             dsp[((size_t)kpar * p.LIMAX + mm) * p.Wpad] = v;

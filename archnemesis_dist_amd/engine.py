@@ -293,6 +293,36 @@ class AnsfmEngine:
         self._check(rc, "cirsrad_ck_transmission")
         return out[0] if single else out
 
+    def cirsradg_ck_transmission(self, lay_press_pa, lay_temp, amount, taucont, dtaucon, NVMR, NPAR, igas_map, NLAYIN,
+                                 LAYINC, SCALE, xfac=None):
+        """CIRSrad(return_grad=True), pure-transmission branch (:4110-4131, :4504-4507): SPECOUT (n, W, P) and
+        dSPECOUT (n, W, NPAR, LIMAX, P) = -sum_g DELG xfac exp(-tau_path) dTAUTOT_LAYINC (leading axis dropped for a
+        single model).  dTSURF of this branch is zero."""
+        W, G, NP, NT, S = self.dims
+        lay_press_pa = _np(lay_press_pa)
+        single = lay_press_pa.ndim == 1
+        lp = np.atleast_2d(lay_press_pa); n, L = lp.shape
+        lt = _np(np.atleast_2d(_np(lay_temp)))
+        am = _np(amount).reshape(n, S, L)
+        tc = None if taucont is None else _np(taucont).reshape(n, W, L)
+        dtc = None if dtaucon is None else _np(dtaucon).reshape(n, W, NPAR, L)
+        LAYINC = _np(LAYINC, np.int32); NLAYIN = _np(np.atleast_1d(NLAYIN), np.int32)
+        if LAYINC.ndim == 1:
+            LAYINC = LAYINC[:, None]
+        LIMAX, P = LAYINC.shape
+        SC = _np(np.broadcast_to(_np(SCALE).reshape(-1, LIMAX, P), (n, LIMAX, P)))
+        ig = _np(igas_map, np.int32)
+        spec = np.empty((n, W, P)); dspec = np.empty((n, W, NPAR, LIMAX, P))
+        rc = self._lib.ansfm_cirsradg_ck_transmission(
+            self._ctx, n, L, _ptr(lp), _ptr(lt), _ptr(am), _ptr(tc), _ptr(dtc), int(NVMR), int(NPAR), _ptr(ig), P, LIMAX,
+            _ptr(NLAYIN), _ptr(LAYINC), _ptr(SC), _ptr(_np(xfac)), _ptr(spec), _ptr(dspec))
+        self._check(rc, "cirsradg_ck_transmission")
+        self._chain_dspec = None
+        if n == 1:
+            dspec.flags.writeable = False
+            self._chain_dspec = _fingerprint(dspec[0])
+        return (spec[0], dspec[0]) if single else (spec, dspec)
+
     def cirsradg_ck_thermal(self, ISPACE, lay_press_pa, lay_temp, amount, taucont, dtaucon, NVMR, NPAR, igas_map,
                             NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None, xfac=None):
         """CIRSrad(return_grad=True): returns SPECOUT (n,W,P), dSPECOUT (n,W,NPAR,LIMAX,P), dTSURF (n,W,P)

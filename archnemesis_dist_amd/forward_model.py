@@ -150,7 +150,7 @@ class CIRSradGPU:
         # dispatch order of CIRSrad :4478-4501: transmission / absorption come before thermal emission, thermal emission
         # before single scattering, the downward-flux variant before plain multiple scattering
         if self._ansfm_transmission_branch(imod):
-            return not return_grad
+            return True
         if imod & IMOD_ABSORBTION:
             return False           # calculate_absorption_spectrum (:4133) lacks `self` in the reference: never callable
         if imod & IMOD_THERMAL_EMISSION:
@@ -379,13 +379,23 @@ class CIRSradGPU:
                 self.StellarX.calc_solar_flux()
                 xf = scipy.interpolate.interp1d(self.StellarX.WAVE, self.StellarX.SOLFLUX)(S.WAVE)
             NPATH = np.asarray(P.LAYINC).shape[1]
-            SPECOUT = eng.cirsrad_ck_transmission(
-                np.asarray(L.PRESS, dtype=np.float64), np.asarray(L.TEMP, dtype=np.float64), f_gas, taucont,
-                np.asarray(P.NLAYIN, dtype=np.int32).reshape(NPATH), np.asarray(P.LAYINC, dtype=np.int32).reshape(-1, NPATH),
-                np.asarray(P.SCALE, dtype=np.float64).reshape(-1, NPATH), xfac=xf)
+            geom = (np.asarray(P.NLAYIN, dtype=np.int32).reshape(NPATH), np.asarray(P.LAYINC, dtype=np.int32).reshape(-1, NPATH),
+                    np.asarray(P.SCALE, dtype=np.float64).reshape(-1, NPATH))
+            lp, lt = np.asarray(L.PRESS, dtype=np.float64), np.asarray(L.TEMP, dtype=np.float64)
+            if return_grad:                                                  # :4128-4131, then :4504-4508
+                A = self.AtmosphereX
+                NVMR = int(A.NVMR)
+                NPAR = NVMR + 2 + int(self.ScatterX.NDUST)
+                igas_map = np.array([A.locate_gas(S.ID[i], S.ISO[i]) for i in range(S.NGAS)], dtype=np.int32)
+                SPECOUT, dSPECOUT = eng.cirsradg_ck_transmission(lp, lt, f_gas, taucont, dTAUCON, NVMR, NPAR, igas_map, *geom,
+                                                                 xfac=xf)
+            else:
+                SPECOUT = eng.cirsrad_ck_transmission(lp, lt, f_gas, taucont, *geom, xfac=xf)
             if self.ansfm_keep_side_products:
                 L.TAUGAS = eng.get_taugas(L.NLAY, 0)
                 L.TAUTOT = self._ansfm_total_opacity(L.TAUGAS, TAUCIA, TAUDUST, TAURAY)
+            if return_grad:
+                return SPECOUT, dSPECOUT, np.zeros_like(SPECOUT)             # dTSURF: zeros through the g-quadrature
             return SPECOUT
         if (imod0 & IMOD_SINGLE_SCATTERING_PLANE_PARALLEL) and not (imod0 & IMOD_THERMAL_EMISSION):   # dispatch order :4487-4493
             SPECOUT = self._ansfm_cirsrad_singlescatt(eng, taucont, TAURAY, f_gas)

@@ -221,6 +221,16 @@ int ansfm_cirsrad_ck_transmission(ansfm_ctx *ctx, int n_models, int L, const dou
                                   const double *amount, const double *taucont, int P, int LIMAX, const int32_t *NLAYIN,
                                   const int32_t *LAYINC, const double *SCALE, const double *xfac, double *SPECOUT);
 
+/* The same branch with return_grad (calculate_transmission_spectrum :4128-4131 followed by CIRSrad's g-quadrature and
+ * nan_to_num :4507): dSPECOUT[n][W][NPAR][LIMAX][P] = - sum_g DELG[g] xfac exp(-tau_path(g)) dTAUTOT_LAYINC[g], with
+ * dTAUTOT_LAYINC assembled as in ansfm_cirsradg_ck_thermal (gas slots x 1e-4 through igas_map, temperature slot at NVMR,
+ * dtaucon, x SCALE).  dTSURF of this branch is identically zero and not returned. */
+int ansfm_cirsradg_ck_transmission(ansfm_ctx *ctx, int n_models, int L, const double *lay_press_pa,
+                                   const double *lay_temp, const double *amount, const double *taucont,
+                                   const double *dtaucon, int NVMR, int NPAR, const int32_t *igas_map, int P, int LIMAX,
+                                   const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE, const double *xfac,
+                                   double *SPECOUT, double *dSPECOUT);
+
 /* ---- analytic-gradient seams ---------------------------------------------------------------
  * ForwardModel_0.k_overlapg (ForwardModel_0.py:5842): + dkdT[W][G][L][S] -> tau[W][G][L],
  * dk[W][G][L][S+1] (slots 0..S-1 = d tau/d amount_gas, slot S = d tau/dT). */

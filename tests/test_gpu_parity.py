@@ -1288,6 +1288,53 @@ def test_cirsrad_transmission_vs_oracle(eng, oracle):
         np.testing.assert_allclose(got[m], ref, rtol=1e-11)
 
 
+def test_cirsradg_transmission_vs_oracle(eng, oracle):
+    """The same branch with return_grad (:4128-4131, then the g-quadrature and nan_to_num of :4504-4507):
+    dSPECOUT = -SPECOUT * dTAUTOT_LAYINC, the opacity gradients assembled as for thermal emission (gas slots x 1e-4 through
+    the gas map, temperature slot, continuum gradients, x SCALE).  Restated with the oracle's calc_kg + k_overlapg."""
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(78)
+    W, G, S, L = 130, 10, 3, 12
+    PRESS, TEMP, K = syn.synth_ktable(W, G, 8, 6, S, seed=22)
+    _, delg = syn.gauss_legendre_01(G)
+    WAVE = 900.0 + 0.7 * np.arange(W)
+    eng.upload_ktable(K, PRESS, TEMP, WAVE, delg)
+    lp = np.stack([np.logspace(4.5, 0.5, L), np.logspace(4.4, 0.6, L)]); lt = np.stack([np.linspace(200, 140, L), np.linspace(210, 150, L)])
+    am = 10.0 ** rng.uniform(17, 19.5, (2, S, L)) * (lp[:, None, :] / lp[:, None, :1])
+    cont = 10.0 ** rng.uniform(-4, -1, (2, W, L))
+    NVMR, NDUST = 4, 1
+    NPAR = NVMR + 2 + NDUST
+    igas_map = np.array([2, 0, 3], dtype=np.int32)
+    dcont = 10.0 ** rng.uniform(-24, -22, (2, W, NPAR, L))
+    LAYINC = np.zeros((2 * L, 2), dtype=np.int32)
+    LAYINC[:, 0] = np.concatenate([np.arange(L - 1, -1, -1), np.arange(L)])
+    LAYINC[:2 * (L - 4), 1] = np.concatenate([np.arange(L - 1, 3, -1), np.arange(4, L)])
+    NLAYIN = np.array([2 * L, 2 * (L - 4)], dtype=np.int32)
+    SCALE = np.where(np.arange(2 * L)[:, None] < NLAYIN[None, :], rng.uniform(1.0, 30.0, (2 * L, 2)), 0.0)
+    solflux = 10.0 ** rng.uniform(-8, -7, W)
+    spec, dspec = eng.cirsradg_ck_transmission(lp, lt, am, cont, dcont, NVMR, NPAR, igas_map, NLAYIN, LAYINC, SCALE, xfac=solflux)
+    fwd = eng.cirsrad_ck_transmission(lp, lt, am, cont, NLAYIN, LAYINC, SCALE, xfac=solflux)
+    np.testing.assert_allclose(spec, fwd, rtol=1e-13)
+    inside = (np.arange(2 * L)[:, None] < NLAYIN[None, :])
+    for m in range(2):
+        k, dkdT = oracle.calc_k(K, PRESS, TEMP, lp[m] / 101325.0, lt[m], grad=True)
+        tau, dk = oracle.k_overlapg(delg, k, dkdT, am[m])                        # (W,G,L), (W,G,L,S+1)
+        dtau = np.zeros((W, G, NPAR, L))
+        for i in range(S):
+            dtau[:, :, igas_map[i], :] = dk[:, :, :, i] * 1.0e-4                   # :3868-3870
+        dtau[:, :, NVMR, :] = dk[:, :, :, S]                                     # :3872
+        dtau += dcont[m][:, None, :, :]
+        tautot = tau + cont[m][:, None, :]
+        path = np.sum(tautot[:, :, LAYINC] * SCALE, axis=2)                       # (W,G,P)
+        sg = np.exp(-path) * solflux[:, None, None]
+        dlay = dtau[:, :, :, LAYINC] * SCALE                                      # (W,G,NPAR,LIMAX,P)
+        dref = np.nan_to_num(np.tensordot(-sg[:, :, None, None, :] * dlay, delg, axes=([1], [0])))
+        dref = dref * inside[None, None, :, :]
+        np.testing.assert_allclose(spec[m], np.tensordot(sg, delg, axes=([1], [0])), rtol=1e-11)
+        scale = np.max(np.abs(dref), axis=(0, 2), keepdims=True)
+        assert np.max(np.abs(dspec[m] - dref) / np.where(scale > 0, scale, 1.0)) < 1e-10
+
+
 def test_singlescatt_plane_spectrum_golden(eng, golden_dir):
     """Array-level calc_singlescatt_plane_spectrum (:6509-6600) vs the reference (golden): both spectral units, without /
     with a surface, a grazing geometry."""
