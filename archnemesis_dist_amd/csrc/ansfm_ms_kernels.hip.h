@@ -505,6 +505,35 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
 // the a-operand registers (4 FMAs + a reduction over q).  One wavefront per block: LDS is in-order per
 // wave, so a compiler fence replaces the barriers.
 #define MS16_FENCE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
+// Cross-lane sums without the LDS crossbar (__shfl_xor = ds_bpermute: an LDS round trip per stage, six dependent stages for a
+// norm, in front of every product that waits for the result).  Within a 16-lane row: DPP row rotations (VALU); across the
+// four rows: gfx950's v_permlane16_swap / v_permlane32_swap (vdst's odd rows / upper half <-> src's even rows / lower half;
+// with both operands the same register the two results are the partner values).  tools/calib/lane_reduce_check.hip.
+template <int CTRL> __device__ __forceinline__ double ms_dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ double ms_xor16_sum(double s)      // s[l] + s[l ^ 16]
+{
+    const long long b = __double_as_longlong(s);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __longlong_as_double(((long long)rh[0] << 32) | (unsigned long long)rl[0]) +
+           __longlong_as_double(((long long)rh[1] << 32) | (unsigned long long)rl[1]);
+}
+__device__ __forceinline__ double ms_xor32_sum(double s)      // s[l] + s[l ^ 32]
+{
+    const long long b = __double_as_longlong(s);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __longlong_as_double(((long long)rh[0] << 32) | (unsigned long long)rl[0]) +
+           __longlong_as_double(((long long)rh[1] << 32) | (unsigned long long)rl[1]);
+}
 struct Ms16 {
     int c, q;
     __device__ __forceinline__ void load_a(const double *M, double a[4]) const
@@ -537,16 +566,16 @@ struct Ms16 {
         double s = 0.0;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) s += a[kb] * x[q + 4 * kb];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        return s;
+        return ms_xor32_sum(ms_xor16_sum(s));
     }
     __device__ __forceinline__ static double frob(ms_v4f64 v)
     {
         double s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        return sqrt(s);
+        s += ms_dpp_f64<0x128>(s);      // row_ror:8, 4, 2, 1: every lane ends with its row's sum
+        s += ms_dpp_f64<0x124>(s);
+        s += ms_dpp_f64<0x122>(s);
+        s += ms_dpp_f64<0x121>(s);
+        return sqrt(ms_xor32_sum(ms_xor16_sum(s)));
     }
     __device__ __forceinline__ ms_v4f64 eye_plus(ms_v4f64 v, double sgn) const
     {   // E + sgn * v
@@ -629,7 +658,10 @@ __device__ __forceinline__ bool ms_inv16_series(const Ms16 &L, ms_v4f64 B, doubl
     return false;
 }
 
-__global__ __launch_bounds__(64) void k_ms_chain16(MsParams p)
+// Two waves per SIMD: without the cap the compiler takes 280 registers (256 + 24 AGPRs) and the SIMD is left with a single
+// wave, i.e. nothing to issue while a product waits on its LDS round trip (C4 at 2000 wavenumbers: 0.266 -> 0.196 s; three
+// waves per SIMD need 132 spilled registers and LDS holds ten blocks per CU anyway: 0.215 s).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ms_chain16(MsParams p)
 {
     extern __shared__ double sm[];
     const int lane = threadIdx.x;
