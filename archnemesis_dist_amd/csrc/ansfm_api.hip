@@ -80,6 +80,7 @@ struct ansfm_ctx {
 
     // scattering core: the Hansen walk of g-ordinate g + 1 runs on a second stream beside the chains of g
     hipStream_t ms_stream = nullptr;
+    hipStream_t ms_stream2 = nullptr;   // chains of the odd g-ordinates: consecutive chain launches overlap their tails
     std::vector<hipEvent_t> ms_ev;
     // timing of the last cirsrad call
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -153,6 +154,7 @@ void ansfm_destroy(ansfm_ctx *ctx)
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ms_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ms_stream) (void)hipStreamDestroy(ctx->ms_stream);
+    if (ctx->ms_stream2) (void)hipStreamDestroy(ctx->ms_stream2);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -2082,21 +2084,27 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     }
     p.hansen_comp0 = 0;
     if (nmu == 16) {
-        // matrix-core products (v_mfma_f64_16x16x4_f64), 7 LDS matrices with leading dimension 17; one block per (wavenumber,
+        // matrix-core products (v_mfma_f64_16x16x4_f64), 6 LDS matrices with leading dimension 17 and, when at most two
+        // scattering components are in use (aerosol types + Rayleigh), their phase matrices; one block per (wavenumber,
         // g) works through the Fourier orders and stops at the reference's convergence break (writes rad itself).
         // The Hansen walk is sequential over (g, wave) -- two waves on the whole chip -- so it is cut into one launch per
         // g-ordinate on a second stream and the chains of g start as soon as its factors exist: the walk of g + 1 hides
         // behind them (it was 11-18 % of a call when it ran ahead of all chains).
-        const size_t lds16 = (7 * 16 * 17 + 4 * 16) * D;
+        const int ncu = ncont + (iray > 0 ? 1 : 0);
+        p.phase_lds = (ncu >= 1 && ncu <= 2) ? 1 : 0;
+        if (const char *ev = getenv("ANSFM_MS_PHASE_LDS")) p.phase_lds = (p.phase_lds && atoi(ev) != 0) ? 1 : 0;   // measurement switch
+        const size_t lds16 = (6 * 16 * 17 + 6 * 16 + (p.phase_lds ? (size_t)ncu * 2 * 256 : 0)) * D;
         if (ncomp_run > 0) {
             if (!ctx->ms_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->ms_stream, hipStreamNonBlocking));
-            while ((int)ctx->ms_ev.size() < ng + 2) {
+            if (!ctx->ms_stream2) HIPCHK(hipStreamCreateWithFlags(&ctx->ms_stream2, hipStreamNonBlocking));
+            while ((int)ctx->ms_ev.size() < ng + 3) {
                 hipEvent_t e;
                 HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 ctx->ms_ev.push_back(e);
             }
             HIPCHK(hipEventRecord(ctx->ms_ev[ng], ctx->stream));                    // phase matrices (and every input) ready
             HIPCHK(hipStreamWaitEvent(ctx->ms_stream, ctx->ms_ev[ng], 0));
+            HIPCHK(hipStreamWaitEvent(ctx->ms_stream2, ctx->ms_ev[ng], 0));
             for (int g = 0; g < ng; ++g) {
                 MsParams ph = p;
                 ph.ig0 = g; ph.ng_launch = 1;
@@ -2107,13 +2115,19 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
             for (int g = 0; g < ng; ++g) {
                 MsParams pc = p;
                 pc.ig0 = g; pc.ng_launch = 1;
-                HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ms_ev[g], 0));
-                hipLaunchKernelGGL(k_ms_chain16, dim3((unsigned)nwave), dim3(64), lds16, ctx->stream, pc);
+                // even g on the main stream, odd g beside it (a third stream adds nothing): a launch of 1e4 blocks ends with a
+                // tail of half-empty CUs
+                // (chains differ in length with the optical depth), which the next g-ordinate's blocks fill
+                hipStream_t cs = (g & 1) ? ctx->ms_stream2 : ctx->stream;
+                HIPCHK(hipStreamWaitEvent(cs, ctx->ms_ev[g], 0));
+                hipLaunchKernelGGL(k_ms_chain16, dim3((unsigned)nwave), dim3(64), lds16, cs, pc);
                 HIPCHK(hipGetLastError());
             }
-            // the second stream must not run into the next call's buffers: it rejoins the main one here
+            // the side streams must not run into the next call's buffers: they rejoin the main one here
             HIPCHK(hipEventRecord(ctx->ms_ev[ng + 1], ctx->ms_stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ms_ev[ng + 1], 0));
+            HIPCHK(hipEventRecord(ctx->ms_ev[ng + 2], ctx->ms_stream2));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ms_ev[ng + 2], 0));
         } else {
             hipLaunchKernelGGL(k_ms_chain16, dim3((unsigned)((size_t)nwave * ng)), dim3(64), lds16, ctx->stream, p);
             HIPCHK(hipGetLastError());

@@ -50,6 +50,7 @@ struct MsParams {
     int hansen_comp0, phase_comp0;
     int lookup;              // all emission angles > 90: layers top to bottom, surface brought in with idown (:366-420)
     int ig0, ng_launch;      // k_ms_hansen_seq / k_ms_chain16: the g-ordinates [ig0, ig0 + ng_launch) of this launch
+    int phase_lds;           // k_ms_chain16: the phase matrices of the components in use fit in LDS beside the operators
 };
 
 __device__ __forceinline__ double ms_interp(double x, const double *xp, const double *fp, int n)
@@ -671,13 +672,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int ig = p.ig0 + (int)(blockIdx.x % p.ng_launch);
     const int widx = blockIdx.x / p.ng_launch;
     const double pi = 3.141592653589793;
-    double *rc = sm, *tc = rc + msz, *r1 = tc + msz, *t1 = r1 + msz, *mA = t1 + msz, *mB = mA + msz, *mC = mB + msz;
-    double *jc = mC + msz, *j1 = jc + 16, *v0 = j1 + 16, *radg = v0 + 16;
+    double *rc = sm, *tc = rc + msz, *r1 = tc + msz, *t1 = r1 + msz, *mA = t1 + msz, *mB = mA + msz;
+    double *jc = mB + msz, *j1 = jc + 16, *v0 = j1 + 16, *radg = v0 + 16, *mus = radg + 16, *wts = mus + 16;
+    // phase matrices of this Fourier order (P++ times the Hansen factor, P+-) by component, lane-private [comp][2][4][64]:
+    // they do not depend on the layer, and fetched per layer they were a third of the wave time (s_waitcnt on vmcnt)
+    double *phl = wts + 16;
 #define MS_AT(M, i, j) M[(i) * ld + (j)]
 
     if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // radg[:, ::-1] :765
+    // quadrature points / weights by lane: a kernel-argument array indexed per lane would be copied to scratch memory
+    for (int kk = 0; kk < n; ++kk)
+        if (lane == kk) { mus[kk] = p.mu[kk]; wts[kk] = p.wtmu[kk]; }
+    MS16_FENCE();
     const bool lookup = p.lookup != 0;
-    const double rmu_c = 1. / p.mu[c];
+    const double mu_c = mus[c], wt_c = wts[c];
+    const double rmu_c = 1. / mu_c;
+    double rmu_i[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rmu_i[r] = 1. / mus[q + 4 * r];
     // Fourier sum of every path with the reference's early-out (:903-958), kept by lane `ipath`: the orders are worked
     // through one after the other by this block, and it stops as soon as every path has converged -- the reference builds the
     // operators of all NF + 1 orders first (:790) and never reads the ones beyond the break.
@@ -689,7 +701,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = q + 4 * r, j = c;
-            MS_AT(rc, i, j) = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
+            MS_AT(rc, i, j) = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * mu_c * wt_c) * p.xfac;
             MS_AT(tc, i, j) = 0.0;
         }
         if (lane < n) jc[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];
@@ -699,16 +711,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double *PPL = p.ppl + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
     const double *PMI = p.pmi + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
     const double *FC = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp) * nn;   // ppl *= fc (:232)
+    const int ncu = p.ncont + (p.iray > 0 ? 1 : 0);      // components in use: the aerosols, then Rayleigh
+    if (p.phase_lds) {
+        for (int cc = 0; cc < ncu; ++cc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = (q + 4 * r) * 16 + c;
+                phl[((cc * 2 + 0) * 4 + r) * 64 + lane] = PPL[(size_t)cc * nn + e] * FC[(size_t)cc * nn + e];
+                phl[((cc * 2 + 1) * 4 + r) * 64 + lane] = PMI[(size_t)cc * nn + e];
+            }
+        MS16_FENCE();
+    }
 
+    // the layer's scalars are fetched one layer ahead
+    const double *taus_w = p.taus + ((size_t)widx * p.ng + ig) * p.nlay, *omegas_w = p.omegas + ((size_t)widx * p.ng + ig) * p.nlay;
+    const double *bnu_w = p.bnu + (size_t)widx * p.nlay, *tauray_w = p.tauray + (size_t)widx * p.nlay;
+    const int kfirst = lookup ? p.nlay - 1 : 0;
+    double n_taut = taus_w[kfirst], n_bc = bnu_w[kfirst], n_omega = omegas_w[kfirst], n_taur = tauray_w[kfirst];
     for (int l = 0; l < p.nlay; ++l) {
         const int k = lookup ? p.nlay - 1 - l : l;  // look-down: bottom layer first (:842-845)
-        const double taut = p.taus[((size_t)widx * p.ng + ig) * p.nlay + k];
-        const double bc = p.bnu[(size_t)widx * p.nlay + k];
-        double omega = p.omegas[((size_t)widx * p.ng + ig) * p.nlay + k];
+        const double taut = n_taut, bc = n_bc;
+        double omega = n_omega;
+        const double taur_l = n_taur;
+        if (l + 1 < p.nlay) {
+            const int k1 = lookup ? k - 1 : k + 1;
+            n_taut = taus_w[k1]; n_bc = bnu_w[k1]; n_omega = omegas_w[k1]; n_taur = tauray_w[k1];
+        }
         if (omega < 0) omega = 0.0;
         if (omega > 1) omega = 1.0;
         double tauscat = taut * omega;
-        const double taur = p.tauray[(size_t)widx * p.nlay + k];
+        const double taur = taur_l;
         tauscat = tauscat - taur;
         if (tauscat < 0) tauscat = 0.0;
         // ---- calc_rtj_matrix :566-647 -> (r1, t1, j1), iscl ------------------------------------------------
@@ -738,16 +770,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = q + 4 * r, j = c, e = i * 16 + j;
-                double a = (p.iray > 0) ? fr * (PPL[(size_t)p.ncont * nn + e] * FC[(size_t)p.ncont * nn + e]) : 0.0;
-                double b = (p.iray > 0) ? fr * PMI[(size_t)p.ncont * nn + e] : 0.0;
-                for (int cc = 0; cc < p.ncont; ++cc) {
-                    const double f = p.lfrac[((size_t)widx * p.ncont + cc) * p.nlay + k];
-                    a += fs * (PPL[(size_t)cc * nn + e] * FC[(size_t)cc * nn + e]) * f;
-                    b += fs * PMI[(size_t)cc * nn + e] * f;
+                double a, b;
+                if (p.phase_lds) {
+                    a = (p.iray > 0) ? fr * phl[((p.ncont * 2 + 0) * 4 + r) * 64 + lane] : 0.0;
+                    b = (p.iray > 0) ? fr * phl[((p.ncont * 2 + 1) * 4 + r) * 64 + lane] : 0.0;
+                    for (int cc = 0; cc < p.ncont; ++cc) {
+                        const double f = p.lfrac[((size_t)widx * p.ncont + cc) * p.nlay + k];
+                        a += fs * phl[((cc * 2 + 0) * 4 + r) * 64 + lane] * f;
+                        b += fs * phl[((cc * 2 + 1) * 4 + r) * 64 + lane] * f;
+                    }
+                } else {
+                    a = (p.iray > 0) ? fr * (PPL[(size_t)p.ncont * nn + e] * FC[(size_t)p.ncont * nn + e]) : 0.0;
+                    b = (p.iray > 0) ? fr * PMI[(size_t)p.ncont * nn + e] : 0.0;
+                    for (int cc = 0; cc < p.ncont; ++cc) {
+                        const double f = p.lfrac[((size_t)widx * p.ncont + cc) * p.nlay + k];
+                        a += fs * (PPL[(size_t)cc * nn + e] * FC[(size_t)cc * nn + e]) * f;
+                        b += fs * PMI[(size_t)cc * nn + e] * f;
+                    }
                 }
                 // Gamma++ = M^-1 (E - con P++ C) ;  Gamma+- = M^-1 con P+- C   (C, M^-1 diagonal)
-                const double gpp = (1. / p.mu[i]) * (((i == j) ? 1.0 : 0.0) - (a * p.wtmu[j]) * con);
-                const double gpm = (1. / p.mu[i]) * ((b * p.wtmu[j]) * con);
+                const double gpp = rmu_i[r] * (((i == j) ? 1.0 : 0.0) - (a * wt_c) * con);
+                const double gpm = rmu_i[r] * ((b * wt_c) * con);
                 bT[r] = ((i == j) ? 1.0 : 0.0) - tau0 * gpp;
                 bR[r] = tau0 * gpm;
             }
@@ -771,14 +814,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     acom = L.eye_plus(bcom, 1.0);
                 L.load_a(t1, aT);
                 const ms_v4f64 ccom = Ms16::mm(aT, acom);                     // t1 acom
-                L.store_d(mC, ccom);
+                L.store_d(mB, ccom);
                 double jcom = 0.0;
                 if (ic == 0) {
                     jcom = L.mv(aR, j1) + jv;                                 // r1 j1 + j1
                     if (q == 0) v0[c] = jcom;
                 }
                 MS16_FENCE();
-                L.load_a(mC, aC);
+                L.load_a(mB, aC);
                 const ms_v4f64 rans = Ms16::mm(aC, bR);                       // ccom r1
                 L.store_d(mA, rans);
                 const ms_v4f64 tans = Ms16::mm(aC, bT);                       // ccom t1
@@ -819,11 +862,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 acom = L.eye_plus(rsq, 1.0);
             L.load_a(t1, aT);
             const ms_v4f64 ccom = Ms16::mm(aT, acom);                         // t1 acom
-            L.store_d(mC, ccom);
+            L.store_d(mB, ccom);
             const double jcom = L.mv(aRc, j1) + jc[c];                        // rsub j1 + jsub
             if (q == 0) v0[c] = jcom;
             MS16_FENCE();
-            L.load_a(mC, aC);
+            L.load_a(mB, aC);
             const ms_v4f64 rans = Ms16::mm(aC, bRc);                          // ccom rsub
             L.store_d(mA, rans);
             const ms_v4f64 tans = Ms16::mm(aC, bTc);                          // ccom tsub
@@ -867,7 +910,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = q + 4 * r, j = c;
-            rs[r] = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
+            rs[r] = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * mu_c * wt_c) * p.xfac;
         }
         double aRc[4];
         L.load_a(rc, aRc);
@@ -888,16 +931,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         else { zmu0 = cos(sol_ang * pi / 180.0); solar1 = p.solar[widx]; }
         const double zmu = cos(emiss_ang * pi / 180.0);
         int isol = 0, iemm = 0;
-        for (int j = 0; j < n - 1; ++j) if (zmu0 <= p.mu[j] && zmu0 > p.mu[j + 1]) isol = j;
-        if (zmu0 <= p.mu[n - 1]) isol = n - 2;
-        for (int j = 0; j < n - 1; ++j) if (zmu <= p.mu[j] && zmu > p.mu[j + 1]) iemm = j;
-        if (zmu <= p.mu[n - 1]) iemm = n - 2;
-        const double u = (p.mu[isol] - zmu0) / (p.mu[isol] - p.mu[isol + 1]);
-        const double t = (p.mu[iemm] - zmu) / (p.mu[iemm] - p.mu[iemm + 1]);
+        for (int j = 0; j < n - 1; ++j) if (zmu0 <= mus[j] && zmu0 > mus[j + 1]) isol = j;
+        if (zmu0 <= mus[n - 1]) isol = n - 2;
+        for (int j = 0; j < n - 1; ++j) if (zmu <= mus[j] && zmu > mus[j + 1]) iemm = j;
+        if (zmu <= mus[n - 1]) iemm = n - 2;
+        const double u = (mus[isol] - zmu0) / (mus[isol] - mus[isol + 1]);
+        const double t = (mus[iemm] - zmu) / (mus[iemm] - mus[iemm + 1]);
         double yx[4];
         int ico = 0;
         for (int imu0 = isol; imu0 < isol + 2; ++imu0) {
-            const double s0 = solar1 / (2.0 * pi * p.wtmu[imu0]);
+            const double s0 = solar1 / (2.0 * pi * wts[imu0]);
             for (int imu = iemm; imu < iemm + 2; ++imu) {
                 if (!lookup) {
                     double bcom = 0.0;   // (T utmi)[imu], utmi = radg for ic == 0 else 0

@@ -19,9 +19,16 @@ acc=defaultdict(lambda: defaultdict(float)); n=defaultdict(int)
 for r in csv.DictReader(open(f)):
     if "k_ms_chain16" in r["Kernel_Name"]: acc["k_ms_chain16"][r["Counter_Name"]]+=float(r["Counter_Value"])
 c=dict(acc["k_ms_chain16"])
-tot_ns=float(st["ansfm::k_ms_chain16"]["TotalDurationNs"])
+# the chain launches of consecutive g-ordinates run on two streams and overlap: time = union of their intervals
+f=glob.glob("$OUT/trace/**/*kernel_trace.csv",recursive=True)[0]
+iv=sorted((int(r["Start_Timestamp"]),int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if "k_ms_chain16" in r["Kernel_Name"])
+tot_ns=0.0; cs,ce=iv[0]
+for a,b in iv[1:]:
+    if a>ce: tot_ns+=ce-cs; cs,ce=a,b
+    else: ce=max(ce,b)
+tot_ns+=ce-cs
 flops=c["SQ_INSTS_VALU_MFMA_MOPS_F64"]*512.0        # MOPS counts 512-flop units: one 16x16x4 f64 MFMA = 4
-out={"counters_summed_over_launches":c,"kernel_total_ms_trace_pass":tot_ns/1e6,"mfma_f64_flops":flops,
+out={"counters_summed_over_launches":c,"chain_kernels_union_ms_trace_pass":tot_ns/1e6,"chain_kernels_sum_ms":float(st["ansfm::k_ms_chain16"]["TotalDurationNs"])/1e6,"mfma_f64_flops":flops,
      "TFLOPs":flops/(tot_ns*1e-9)/1e12,"frac_of_78.6":flops/(tot_ns*1e-9)/78.6e12,
      "mfma_busy_over_simd_cycles":c["SQ_VALU_MFMA_BUSY_CYCLES"]/(4.0*c["SQ_BUSY_CYCLES"]) if c.get("SQ_BUSY_CYCLES") else None}
 json.dump(out,open("$OUT/summary.json","w"),indent=1); print(json.dumps(out,indent=1))
