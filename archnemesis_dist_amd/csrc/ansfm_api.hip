@@ -2071,14 +2071,17 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     p.rad = ctx->tmp_out.as<double>();
     const int ncomp_run = ncont + (iray > 0 ? 1 : 0);
     p.ig0 = 0; p.ng_launch = ng;
+    size_t phase_lds_bytes = (size_t)(nf + 2) * (nphi + 1) * D;       // cos(ic phi_k) for every order and azimuth point
+    p.phase_tab = phase_lds_bytes <= 48 * 1024 ? 1 : 0;
+    if (!p.phase_tab) phase_lds_bytes = 0;
     if (ncomp_run > 0) {
         // Rayleigh lives in slot ncont even when there are no aerosols
         if (ncont > 0)
-            hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, (unsigned)ncont), dim3(256), 0, ctx->stream, p);
+            hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, (unsigned)ncont), dim3(256), phase_lds_bytes, ctx->stream, p);
         if (iray > 0) {
             MsParams pr = p;
             pr.phase_comp0 = ncont;
-            hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, 1), dim3(256), 0, ctx->stream, pr);
+            hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, 1), dim3(256), phase_lds_bytes, ctx->stream, pr);
         }
         HIPCHK(hipGetLastError());
     }

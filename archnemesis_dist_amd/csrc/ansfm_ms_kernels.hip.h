@@ -50,6 +50,7 @@ struct MsParams {
     int hansen_comp0, phase_comp0;
     int lookup;              // all emission angles > 90: layers top to bottom, surface brought in with idown (:366-420)
     int ig0, ng_launch;      // k_ms_hansen_seq / k_ms_chain16: the g-ordinates [ig0, ig0 + ng_launch) of this launch
+    int phase_tab;           // k_ms_phase: the cos(ic phi) table fits in LDS (else the cosines are evaluated in place)
     int phase_lds;           // k_ms_chain16: the phase matrices of the components in use fit in LDS beside the operators
 };
 
@@ -64,9 +65,14 @@ __device__ __forceinline__ double ms_interp(double x, const double *xp, const do
 }
 
 // ---- phase matrices -----------------------------------------------------------------------------
-// raw azimuth integrals (phasint2 :141-197), one block per (wave, scatterer), all ic
+// raw azimuth integrals (phasint2 :141-197), one block per (wave, scatterer), all ic.
+// A thread owns matrix elements (i, j) and walks the azimuth grid ONCE for all Fourier orders: the phase function at
+// (i, j, phi) does not depend on the order (the first version evaluated it per (order, element): nf + 1 times), and
+// cos(ic phi) depends on neither i nor j -- a table in LDS, filled by the same expression.  Same sums in the same order.
+constexpr int kMsPhaseOrders = 9;     // Fourier orders accumulated per pass over the azimuth grid (nf = 8: one pass)
 __global__ __launch_bounds__(256) void k_ms_phase(MsParams p)
 {
+    extern __shared__ double ctab[];            // [nf + 2][nphi + 1]: cos(ic phi_k); the last row is cos(phi_k)
     const int widx = blockIdx.x, comp = blockIdx.y + p.phase_comp0;  // comp == ncont -> Rayleigh
     const int n = p.nmu, nn = n * n, tid = threadIdx.x;
     const double pi = 3.141592653589793;
@@ -75,41 +81,68 @@ __global__ __launch_bounds__(256) void k_ms_phase(MsParams p)
     const double *pfunc = p.phasarr + (((size_t)jc * p.nwave + widx) * 2 + 0) * p.nth;
     const double *xmu = p.phasarr + (((size_t)jc * p.nwave + widx) * 2 + 1) * p.nth;
     const int iscat = (comp == p.ncont) ? 0 : (p.imie == 0 ? 2 : 4);
-    for (int work = tid; work < nn * (p.nf + 1); work += blockDim.x) {
-        const int ic = work / nn, e = work % nn;
+    const int nk = p.nphi + 1;
+    const bool tab = p.phase_tab != 0;
+    if (tab) {
+        for (int t = tid; t < (p.nf + 2) * nk; t += blockDim.x) {
+            const int ic = t / nk, k = t % nk;
+            const double phi = k * dphi;
+            ctab[t] = (ic <= p.nf) ? cos(ic * phi) : cos(phi);
+        }
+        __syncthreads();
+    }
+    const double *cphi_row = ctab + (size_t)(p.nf + 1) * nk;
+    for (int e = tid; e < nn; e += blockDim.x) {
         const int i = e / n, j = e % n;
         const double sthi = sqrt(1.0 - p.mu[i] * p.mu[i]), sthj = sqrt(1.0 - p.mu[j] * p.mu[j]);
         const double ss = sthi * sthj, mmu = p.mu[i] * p.mu[j];
-        double spl = 0.0, smi = 0.0;
-        for (int k = 0; k <= p.nphi; ++k) {
-            const double phi = k * dphi;
-            const double cphi = cos(phi);
-            const double cpl = ss * cphi + mmu, cmi = ss * cphi - mmu;
-            double pl, pm;
-            if (iscat == 0) {
-                pl = 0.75 * (1.0 + cpl * cpl) / (4 * pi);
-                pm = 0.75 * (1.0 + cmi * cmi) / (4 * pi);
-            } else if (iscat == 2) {
-                const double f1 = pfunc[0], f2 = 1.0 - f1;
-                const double hg11 = 1.0 - pfunc[1] * pfunc[1], hg12 = 2.0 - hg11;
-                const double hg21 = 1.0 - pfunc[2] * pfunc[2], hg22 = 2.0 - hg21;
-                double s1 = sqrt(hg12 - 2.0 * pfunc[1] * cpl), s2 = sqrt(hg22 - 2.0 * pfunc[2] * cpl);
-                pl = f1 * hg11 / (s1 * s1 * s1) + f2 * hg21 / (s2 * s2 * s2);
-                s1 = sqrt(hg12 - 2.0 * pfunc[1] * cmi); s2 = sqrt(hg22 - 2.0 * pfunc[2] * cmi);
-                pm = f1 * hg11 / (s1 * s1 * s1) + f2 * hg21 / (s2 * s2 * s2);
-                pl /= 4 * pi; pm /= 4 * pi;
-            } else {
-                pl = ms_interp(cpl, xmu, pfunc, p.nth);
-                pm = ms_interp(cmi, xmu, pfunc, p.nth);
+        for (int ic0 = 0; ic0 <= p.nf; ic0 += kMsPhaseOrders) {
+            double spl[kMsPhaseOrders], smi[kMsPhaseOrders];
+#pragma unroll
+            for (int o = 0; o < kMsPhaseOrders; ++o) { spl[o] = 0.0; smi[o] = 0.0; }
+            for (int k = 0; k <= p.nphi; ++k) {
+                const double phi = k * dphi;
+                const double cphi = tab ? cphi_row[k] : cos(phi);
+                const double cpl = ss * cphi + mmu, cmi = ss * cphi - mmu;
+                double pl, pm;
+                if (iscat == 0) {
+                    pl = 0.75 * (1.0 + cpl * cpl) / (4 * pi);
+                    pm = 0.75 * (1.0 + cmi * cmi) / (4 * pi);
+                } else if (iscat == 2) {
+                    const double f1 = pfunc[0], f2 = 1.0 - f1;
+                    const double hg11 = 1.0 - pfunc[1] * pfunc[1], hg12 = 2.0 - hg11;
+                    const double hg21 = 1.0 - pfunc[2] * pfunc[2], hg22 = 2.0 - hg21;
+                    double s1 = sqrt(hg12 - 2.0 * pfunc[1] * cpl), s2 = sqrt(hg22 - 2.0 * pfunc[2] * cpl);
+                    pl = f1 * hg11 / (s1 * s1 * s1) + f2 * hg21 / (s2 * s2 * s2);
+                    s1 = sqrt(hg12 - 2.0 * pfunc[1] * cmi); s2 = sqrt(hg22 - 2.0 * pfunc[2] * cmi);
+                    pm = f1 * hg11 / (s1 * s1 * s1) + f2 * hg21 / (s2 * s2 * s2);
+                    pl /= 4 * pi; pm /= 4 * pi;
+                } else {
+                    pl = ms_interp(cpl, xmu, pfunc, p.nth);
+                    pm = ms_interp(cmi, xmu, pfunc, p.nth);
+                }
+                const double w = (k == 0 || k == p.nphi) ? 0.5 * dphi : dphi;
+                const double w0 = w / (2.0 * pi), w1 = w / pi;
+#pragma unroll
+                for (int o = 0; o < kMsPhaseOrders; ++o) {
+                    const int ic = ic0 + o;
+                    if (ic <= p.nf) {
+                        const double wphi = (ic == 0) ? w0 : w1;
+                        const double cic = tab ? ctab[(size_t)ic * nk + k] : cos(ic * phi);
+                        spl[o] += wphi * (pl * cic);
+                        smi[o] += wphi * (pm * cic);
+                    }
+                }
             }
-            double wphi = (k == 0 || k == p.nphi) ? 0.5 * dphi : dphi;
-            if (ic == 0) wphi /= (2.0 * pi); else wphi /= pi;
-            const double cic = cos(ic * phi);
-            spl += wphi * (pl * cic);
-            smi += wphi * (pm * cic);
+#pragma unroll
+            for (int o = 0; o < kMsPhaseOrders; ++o) {
+                const int ic = ic0 + o;
+                if (ic <= p.nf) {
+                    p.ppl[(((size_t)widx * (p.nf + 1) + ic) * p.ncomp + comp) * nn + e] = spl[o];
+                    p.pmi[(((size_t)widx * (p.nf + 1) + ic) * p.ncomp + comp) * nn + e] = smi[o];
+                }
+            }
         }
-        p.ppl[(((size_t)widx * (p.nf + 1) + ic) * p.ncomp + comp) * nn + e] = spl;
-        p.pmi[(((size_t)widx * (p.nf + 1) + ic) * p.ncomp + comp) * nn + e] = smi;
     }
 }
 
