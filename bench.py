@@ -343,11 +343,13 @@ def main():
 
         run_jac(True)                                   # warm-up: buffers of the batch sizes
         jt_all, rows_all, YN_a, KK_a = run_jac(False)
-        jt, rows, YN_j, KK_j = run_jac(True)
+        reps = [run_jac(True) for _ in range(3)]        # median of three: a single call varies 0.06 - 0.12 s with the host side
+        jts = sorted(r[0] for r in reps)
+        jt, rows, YN_j, KK_j = jts[1], reps[-1][1], reps[-1][2], reps[-1][3]
         eng.set_layer_dedup(True)
         jac = {"forward_models": st.NX + 1, "state_vector": f"T and ln(VMR) of one absorber at {npro} levels (NX = {st.NX}), "
                "through layer_average (Curtis-Godson, NINT 101) and the Rayleigh continuum",
-               "wall_s": jt, "fm_per_s": (st.NX + 1) / jt, "wall_s_all_layers": jt_all,
+               "wall_s": jt, "wall_s_three_calls": jts, "fm_per_s": (st.NX + 1) / jt, "wall_s_all_layers": jt_all,
                "layer_opacities_computed_rank0": int(rows[0]), "layer_opacities_all_rank0": int(rows_all[0]),
                "dedup_bit_identical": bool(np.array_equal(KK_a, KK_j) and np.array_equal(YN_a, YN_j)),
                "kk_shape": list(KK_j.shape),
