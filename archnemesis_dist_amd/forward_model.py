@@ -69,6 +69,10 @@ def set_strict(on=True):
 def _delegate(what):
     if STRICT:
         raise NotImplementedError("ansfm (strict): %s is outside the GPU path and delegation to the reference is off" % what)
+    if what not in DELEGATED:            # said once per kind of case, counted every time (DELEGATED)
+        import warnings
+        warnings.warn("ansfm: %s is outside the GPU path; handed to the reference's own CPU implementation "
+                      "(set_strict(True) turns this into an error)" % what, RuntimeWarning, stacklevel=3)
     DELEGATED[what] = DELEGATED.get(what, 0) + 1
 
 

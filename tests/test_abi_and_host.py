@@ -167,13 +167,19 @@ def test_jacobian_nemesis_sharded_gloo_world2(tmp_path):
 
 
 def test_strict_switch_turns_delegations_into_errors():
-    """forward_model.set_strict: a case outside the GPU path is counted (default) or refused (strict)."""
+    """forward_model.set_strict: a case outside the GPU path is announced once and counted (default) or refused (strict)."""
     import archnemesis_dist_amd.forward_model as fmod
     before = dict(fmod.DELEGATED)
     try:
         fmod.set_strict(False)
-        fmod._delegate("unit-test case")
-        assert fmod.DELEGATED["unit-test case"] == before.get("unit-test case", 0) + 1
+        fmod.DELEGATED.pop("unit-test case", None)
+        with pytest.warns(RuntimeWarning, match="outside the GPU path"):      # said aloud the first time ...
+            fmod._delegate("unit-test case")
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                                      # ... counted silently afterwards
+            fmod._delegate("unit-test case")
+        assert fmod.DELEGATED["unit-test case"] == 2
         fmod.set_strict(True)
         with pytest.raises(NotImplementedError):
             fmod._delegate("unit-test case")
