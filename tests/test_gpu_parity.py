@@ -1103,7 +1103,9 @@ def _scatter_oracle(oracle, z, sol, emi, azi, lowbc, NF, nphi, iray, imie):
 
 
 @pytest.mark.parametrize("NMU,NF,ncont,imie,iray,lowbc,up", [(5, 2, 2, 0, 1, 0, False), (16, 3, 1, 1, 1, 1, False),
-                                                             (5, 1, 1, 1, 0, 0, True), (16, 2, 0, 0, 1, 0, False)])
+                                                             (5, 1, 1, 1, 0, 0, True), (16, 2, 0, 0, 1, 0, False),
+                                                             (16, 2, 2, 0, 1, 0, False),      # three components: phase matrices stay in HBM
+                                                             (16, 1, 2, 1, 0, 1, True)])
 def test_cirsrad_scatter_vs_oracle(eng, oracle, NMU, NF, ncont, imie, iray, lowbc, up):
     """ansfm_cirsrad_ck_scatter (gas opacities, TAUTOT, OMEGA, BB formed on the device, straight into the doubling /
     adding kernels) vs the same chain through the oracle: radiances before and after the g-quadrature and TAUGAS."""
@@ -1121,6 +1123,21 @@ def test_cirsrad_scatter_vs_oracle(eng, oracle, NMU, NF, ncont, imie, iray, lowb
     np.testing.assert_allclose(eng.get_taugas(L, 0), taugas, rtol=1e-11, atol=0)
     scale = np.max(np.abs(ref_g))
     assert np.max(np.abs(spec_g - ref_g)) / scale < 1e-8
+    assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) < 1e-8
+
+
+def test_cirsrad_scatter_fine_azimuth_grid_vs_oracle(eng, oracle):
+    """NPHI = 701 with NF = 8: the cos(ic phi) table of k_ms_phase (56 KB) does not fit its LDS budget, the cosines are
+    evaluated in place -- same sums as the table path and as the oracle."""
+    rng = np.random.default_rng(4242)
+    W, G, L, S, NMU, NF, nphi = 6, 3, 5, 2, 16, 8, 701
+    z = _scatter_inputs(rng, W, G, L, S, NMU, NF, 1, 1, 1, 0)
+    sol = np.array([30.0]); emi = np.array([20.0]); azi = np.array([45.0])
+    eng.upload_ktable(z["K"], z["TPRESS"], z["TTEMP"], z["WAVE"], z["DELG"])
+    out = eng.cirsrad_ck_scatter(0, z["lay_p"], z["lay_t"], z["amount"], z["TAUCIA"], z["TAUDUST"], z["TAURAY"], z["TAUSCAT"],
+                                 z["phasarr"], z["lfrac"], z["radg"], sol, emi, azi, z["solar"], 0, z["brdf"], z["MU"], z["WT"],
+                                 NF, nphi, 1, 1)
+    ref, _, _ = _scatter_oracle(oracle, z, sol, emi, azi, 0, NF, nphi, 1, 1)
     assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) < 1e-8
 
 
