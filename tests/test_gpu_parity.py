@@ -1352,6 +1352,40 @@ def test_cirsradg_transmission_vs_oracle(eng, oracle):
         assert np.max(np.abs(dspec[m] - dref) / np.where(scale > 0, scale, 1.0)) < 1e-10
 
 
+def test_transmission_with_lbl_tables_vs_oracle(eng, oracle):
+    """The transmission branch on line-by-line tables (ILBL = LINE_BY_LINE_TABLES, NG = 1: the solar-occultation case),
+    forward and with gradients, against calc_klbl / calc_klblg composed as calculate_gaseous_line_opacity does (:3795-3817)."""
+    rng = np.random.default_rng(31)
+    W, NP, NT, S, L = 260, 7, 6, 3, 14
+    PRESS = np.logspace(-6, 1.1, NP); TEMP = np.linspace(80.0, 420.0, NT)
+    K = 10.0 ** rng.uniform(-27, -21, size=(W, NP, NT, S))
+    WAVE = 2500.0 + 0.005 * np.arange(W)
+    lp = np.logspace(4.0, -0.5, L); lt = np.linspace(230.0, 150.0, L)
+    am = 10.0 ** rng.uniform(20.5, 23.0, (S, 1)) * (lp[None, :] / lp[0])
+    cont = 10.0 ** rng.uniform(-4, -1.5, (W, L))
+    LAYINC = np.concatenate([np.arange(L - 1, 2, -1), np.arange(3, L)]).astype(np.int32)[:, None]    # limb path, tangent layer 3
+    NLAYIN = np.array([LAYINC.shape[0]], dtype=np.int32)
+    SCALE = rng.uniform(1.0, 40.0, LAYINC.shape)
+    eng.upload_lbltable(K, PRESS, TEMP, WAVE)
+    NVMR, NPAR = S + 1, S + 3
+    igas_map = np.array([1, 3, 0], dtype=np.int32)
+    fwd = eng.cirsrad_ck_transmission(lp, lt, am, cont, NLAYIN, LAYINC, SCALE)
+    spec, dspec = eng.cirsradg_ck_transmission(lp, lt, am, cont, None, NVMR, NPAR, igas_map, NLAYIN, LAYINC, SCALE)
+    k, dkdT = oracle.calc_klbl(K, PRESS, TEMP, lp / 101325.0, lt, grad=True)              # (W,L,S)
+    tau = cont.copy()
+    dtau = np.zeros((W, NPAR, L))
+    for i in range(S):
+        tau = tau + k[:, :, i] * am[i][None, :]
+        dtau[:, igas_map[i], :] = k[:, :, i] * 1.0e-4
+        dtau[:, NVMR, :] += dkdT[:, :, i] * am[i][None, :]
+    tr = np.exp(-np.sum(tau[:, LAYINC[:, 0]] * SCALE[:, 0], axis=1))
+    np.testing.assert_allclose(fwd[:, 0], tr, rtol=1e-11)
+    np.testing.assert_allclose(spec[:, 0], tr, rtol=1e-11)
+    dref = -tr[:, None, None] * dtau[:, :, LAYINC[:, 0]] * SCALE[None, None, :, 0]
+    scale = np.max(np.abs(dref), axis=(0, 2), keepdims=True)
+    assert np.max(np.abs(dspec[:, :, :, 0] - dref) / np.where(scale > 0, scale, 1.0)) < 1e-10
+
+
 def test_singlescatt_plane_spectrum_golden(eng, golden_dir):
     """Array-level calc_singlescatt_plane_spectrum (:6509-6600) vs the reference (golden): both spectral units, without /
     with a surface, a grazing geometry."""
