@@ -2087,16 +2087,23 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     }
     p.hansen_comp0 = 0;
     if (nmu == 16) {
-        // matrix-core products (v_mfma_f64_16x16x4_f64), 6 LDS matrices with leading dimension 17 and, when at most two
-        // scattering components are in use (aerosol types + Rayleigh), their phase matrices; one block per (wavenumber,
+        // matrix-core products (v_mfma_f64_16x16x4_f64), 6 LDS matrices with leading dimension 17; one block per (wavenumber,
         // g) works through the Fourier orders and stops at the reference's convergence break (writes rad itself).
         // The Hansen walk is sequential over (g, wave) -- two waves on the whole chip -- so it is cut into one launch per
         // g-ordinate on a second stream and the chains of g start as soon as its factors exist: the walk of g + 1 hides
         // behind them (it was 11-18 % of a call when it ran ahead of all chains).
         const int ncu = ncont + (iray > 0 ? 1 : 0);
+        // two builds of the chain kernel.  <true>: the phase matrices of the Fourier order in LDS (at most two scattering
+        // components; 22 KB, seven blocks per CU, 163 registers).  <false>: phase matrices read from HBM / L2 every layer, 13.7 KB
+        // of LDS and a register cap for three waves per SIMD -- 46 spilled registers, 10 % slower at C4 (0.67 against 0.61 s),
+        // the path for three and more components.  ANSFM_MS_PHASE_LDS=0 forces the second.
         p.phase_lds = (ncu >= 1 && ncu <= 2) ? 1 : 0;
-        if (const char *ev = getenv("ANSFM_MS_PHASE_LDS")) p.phase_lds = (p.phase_lds && atoi(ev) != 0) ? 1 : 0;   // measurement switch
-        const size_t lds16 = (6 * 16 * 17 + 6 * 16 + (p.phase_lds ? (size_t)ncu * 2 * 256 : 0)) * D;
+        if (const char *ev = getenv("ANSFM_MS_PHASE_LDS")) p.phase_lds = (p.phase_lds && atoi(ev) != 0) ? 1 : 0;
+        const size_t lds16 = (6 * 16 * 17 + 5 * 16 + (p.phase_lds ? (size_t)ncu * 2 * 256 : 0)) * D;
+        auto launch_chain = [&](unsigned grid, hipStream_t st, const MsParams &pp) {
+            if (pp.phase_lds) hipLaunchKernelGGL(k_ms_chain16<true>, dim3(grid), dim3(64), lds16, st, pp);
+            else hipLaunchKernelGGL(k_ms_chain16<false>, dim3(grid), dim3(64), lds16, st, pp);
+        };
         if (ncomp_run > 0) {
             if (!ctx->ms_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->ms_stream, hipStreamNonBlocking));
             if (!ctx->ms_stream2) HIPCHK(hipStreamCreateWithFlags(&ctx->ms_stream2, hipStreamNonBlocking));
@@ -2123,7 +2130,7 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
                 // (chains differ in length with the optical depth), which the next g-ordinate's blocks fill
                 hipStream_t cs = (g & 1) ? ctx->ms_stream2 : ctx->stream;
                 HIPCHK(hipStreamWaitEvent(cs, ctx->ms_ev[g], 0));
-                hipLaunchKernelGGL(k_ms_chain16, dim3((unsigned)nwave), dim3(64), lds16, cs, pc);
+                launch_chain((unsigned)nwave, cs, pc);
                 HIPCHK(hipGetLastError());
             }
             // the side streams must not run into the next call's buffers: they rejoin the main one here
@@ -2132,7 +2139,7 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
             HIPCHK(hipEventRecord(ctx->ms_ev[ng + 2], ctx->ms_stream2));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ms_ev[ng + 2], 0));
         } else {
-            hipLaunchKernelGGL(k_ms_chain16, dim3((unsigned)((size_t)nwave * ng)), dim3(64), lds16, ctx->stream, p);
+            launch_chain((unsigned)((size_t)nwave * ng), ctx->stream, p);
             HIPCHK(hipGetLastError());
         }
     } else {

@@ -621,8 +621,10 @@ struct Ms16 {
 };
 
 // inverse of the 16x16 matrix in LDS A (ld 17) -> Ainv; Gauss-Jordan, partial pivoting (first largest |.|).
-// A is destroyed.  Lane (c0,q) updates rows q+4r of column c0 in both matrices.
-__device__ __forceinline__ void ms_inv16(double *A, double *Ainv, int lane)
+// A is destroyed.  Lane (c0,q) updates rows q+4r of column c0 in both matrices.  Out of line (it is the rare fallback of
+// the series inverse; inlined three times it cost the chain kernel 11 registers), pointers in the LDS address space.
+typedef __attribute__((address_space(3))) double ms_lds_double;
+__device__ __attribute__((noinline)) void ms_inv16_lds(ms_lds_double *A, ms_lds_double *Ainv, int lane)
 {
     const int c0 = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -664,6 +666,10 @@ __device__ __forceinline__ void ms_inv16(double *A, double *Ainv, int lane)
         MS16_FENCE();
     }
 }
+__device__ __forceinline__ void ms_inv16(double *A, double *Ainv, int lane)
+{
+    ms_inv16_lds((ms_lds_double *)A, (ms_lds_double *)Ainv, lane);
+}
 
 // (E - B)^-1 for a 16x16 B given in D layout, on the matrix cores: the product form of the Neumann series,
 //     (E - B)^-1 = (E + B)(E + B^2)(E + B^4)...,
@@ -692,10 +698,22 @@ __device__ __forceinline__ bool ms_inv16_series(const Ms16 &L, ms_v4f64 B, doubl
     return false;
 }
 
-// Two waves per SIMD: without the cap the compiler takes 280 registers (256 + 24 AGPRs) and the SIMD is left with a single
-// wave, i.e. nothing to issue while a product waits on its LDS round trip (C4 at 2000 wavenumbers: 0.266 -> 0.196 s; three
-// waves per SIMD need 132 spilled registers and LDS holds ten blocks per CU anyway: 0.215 s).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ms_chain16(MsParams p)
+// libm calls of the chain kernel, kept out of line: inlined, their polynomial constants and temporaries count towards the
+// kernel's register allocation (log2 / exp2: 14 registers, exp: 14, cos: more) and it is the allocation, not the pressure inside
+// the product loops, that decides how many waves share a SIMD.
+__device__ __attribute__((noinline)) double ms_log2_ni(double x) { return log2(x); }
+__device__ __attribute__((noinline)) double ms_exp2_ni(double x) { return exp2(x); }
+__device__ __attribute__((noinline)) double ms_exp_ni(double x) { return exp(x); }
+__device__ __attribute__((noinline)) double ms_cos_ni(double x) { return cos(x); }
+
+// Register allocation decides how many waves share a SIMD, and a wave of this kernel spends half of its time waiting to
+// issue (dependent products on a shared MFMA pipe).  History: 280 registers after the Fourier-order loop moved into the
+// block = ONE wave per SIMD; capped at 256 = two (C4 at 2000 wavenumbers 0.266 -> 0.196 s).  With the libm calls and the
+// Gauss-Jordan fallback out of line the PHASE_LDS = true build needs 163 -- but its 22 KB of LDS hold seven blocks per CU
+// anyway.  PHASE_LDS = false (phase matrices read from HBM / L2 in every layer, 13.7 KB of LDS: eleven blocks) is capped for
+// three waves per SIMD and spills 46 registers: slower (C4 0.67 against 0.61 s), kept for three and more components.
+template <bool PHASE_LDS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE_LDS ? 2 : 3, PHASE_LDS ? 2 : 3))) void k_ms_chain16(MsParams p)
 {
     extern __shared__ double sm[];
     const int lane = threadIdx.x;
@@ -706,14 +724,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int widx = blockIdx.x / p.ng_launch;
     const double pi = 3.141592653589793;
     double *rc = sm, *tc = rc + msz, *r1 = tc + msz, *t1 = r1 + msz, *mA = t1 + msz, *mB = mA + msz;
-    double *jc = mB + msz, *j1 = jc + 16, *v0 = j1 + 16, *radg = v0 + 16, *mus = radg + 16, *wts = mus + 16;
+    double *jc = mB + msz, *j1 = jc + 16, *v0 = j1 + 16, *mus = v0 + 16, *wts = mus + 16;
+    // radg[:, ::-1] (:765) sits in j1 once the layer loop is done
+    double *radg = j1;
     // phase matrices of this Fourier order (P++ times the Hansen factor, P+-) by component, lane-private [comp][2][4][64]:
-    // they do not depend on the layer, and fetched per layer they were a third of the wave time (s_waitcnt on vmcnt)
+    // they do not depend on the layer (PHASE_LDS only)
     double *phl = wts + 16;
 #define MS_AT(M, i, j) M[(i) * ld + (j)]
 
-    if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // radg[:, ::-1] :765
-    // quadrature points / weights by lane: a kernel-argument array indexed per lane would be copied to scratch memory
+    // quadrature points / weights for per-lane indexing: a kernel-argument array indexed per lane would be copied to scratch
+    // memory (and a second copy of this loop further down costs 64 registers: the scalar loads are hoisted and kept)
     for (int kk = 0; kk < n; ++kk)
         if (lane == kk) { mus[kk] = p.mu[kk]; wts[kk] = p.wtmu[kk]; }
     MS16_FENCE();
@@ -745,7 +765,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double *PMI = p.pmi + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
     const double *FC = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp) * nn;   // ppl *= fc (:232)
     const int ncu = p.ncont + (p.iray > 0 ? 1 : 0);      // components in use: the aerosols, then Rayleigh
-    if (p.phase_lds) {
+    if constexpr (PHASE_LDS) {
         for (int cc = 0; cc < ncu; ++cc)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             MS16_FENCE();
         } else if (omega == 0) {
             const double tex = -rmu_c * taut;
-            const double tt = (tex > -200.0) ? exp(tex) : 0.0;
+            const double tt = (tex > -200.0) ? ms_exp_ni(tex) : 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { MS_AT(r1, q + 4 * r, c) = 0.0; MS_AT(t1, q + 4 * r, c) = (q + 4 * r == c) ? tt : 0.0; }
             if (lane < n) j1[lane] = bc * (1.0 - tt);
@@ -797,14 +817,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // ---- double1 :321-362: starting (r,t,j) of the 2^-nd sub-layer, built straight in D layout -----
             double con = omega * pi;
             con *= (ic == 0) ? 2.0 : 1.0;
-            const int nd = (int)(log2(taut) + 12);   // python int(): truncation toward zero
-            const double tau0 = taut * ((nd >= 1) ? 1.0 / exp2((double)nd) : 1.0);
+            const int nd = (int)(ms_log2_ni(taut) + 12);   // python int(): truncation toward zero
+            const double tau0 = taut * ((nd >= 1) ? 1.0 / ms_exp2_ni((double)nd) : 1.0);
             ms_v4f64 bR, bT;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = q + 4 * r, j = c, e = i * 16 + j;
                 double a, b;
-                if (p.phase_lds) {
+                if constexpr (PHASE_LDS) {
                     a = (p.iray > 0) ? fr * phl[((p.ncont * 2 + 0) * 4 + r) * 64 + lane] : 0.0;
                     b = (p.iray > 0) ? fr * phl[((p.ncont * 2 + 1) * 4 + r) * 64 + lane] : 0.0;
                     for (int cc = 0; cc < p.ncont; ++cc) {
@@ -813,12 +833,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         b += fs * phl[((cc * 2 + 1) * 4 + r) * 64 + lane] * f;
                     }
                 } else {
-                    a = (p.iray > 0) ? fr * (PPL[(size_t)p.ncont * nn + e] * FC[(size_t)p.ncont * nn + e]) : 0.0;
-                    b = (p.iray > 0) ? fr * PMI[(size_t)p.ncont * nn + e] : 0.0;
+                    // one uniform base per array and component, 32-bit byte offsets: no 64-bit address pair per element
+                    const unsigned eo = (unsigned)e * 8u;
+                    auto at = [&](const double *base, int cc) {
+                        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base + (size_t)cc * nn) + eo);
+                    };
+                    a = (p.iray > 0) ? fr * (at(PPL, p.ncont) * at(FC, p.ncont)) : 0.0;
+                    b = (p.iray > 0) ? fr * at(PMI, p.ncont) : 0.0;
                     for (int cc = 0; cc < p.ncont; ++cc) {
                         const double f = p.lfrac[((size_t)widx * p.ncont + cc) * p.nlay + k];
-                        a += fs * (PPL[(size_t)cc * nn + e] * FC[(size_t)cc * nn + e]) * f;
-                        b += fs * PMI[(size_t)cc * nn + e] * f;
+                        a += fs * (at(PPL, cc) * at(FC, cc)) * f;
+                        b += fs * at(PMI, cc) * f;
                     }
                 }
                 // Gamma++ = M^-1 (E - con P++ C) ;  Gamma+- = M^-1 con P+- C   (C, M^-1 diagonal)
@@ -935,6 +960,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     }
     if (ic != 0 && lane < n) jc[lane] = 0.0;   // :881-882
+    if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // j1 is free until the next order's first layer
     __syncthreads();
     if (lookup && p.lowbc > 0) {
         // idown (:366-420) with rb = rs, tb = 0, jb = radg (js is set for every ic, :822):
@@ -960,9 +986,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const double sol_ang = p.sol_ang[ipath];
         const double emiss_ang = lookup ? 180. - p.emiss_ang[ipath] : p.emiss_ang[ipath];   // new_emi :900-903
         double zmu0, solar1;
-        if (sol_ang > 90.0) { zmu0 = cos((180 - sol_ang) * pi / 180.0); solar1 = p.solar[widx] * 0.0; }
-        else { zmu0 = cos(sol_ang * pi / 180.0); solar1 = p.solar[widx]; }
-        const double zmu = cos(emiss_ang * pi / 180.0);
+        if (sol_ang > 90.0) { zmu0 = ms_cos_ni((180 - sol_ang) * pi / 180.0); solar1 = p.solar[widx] * 0.0; }
+        else { zmu0 = ms_cos_ni(sol_ang * pi / 180.0); solar1 = p.solar[widx]; }
+        const double zmu = ms_cos_ni(emiss_ang * pi / 180.0);
         int isol = 0, iemm = 0;
         for (int j = 0; j < n - 1; ++j) if (zmu0 <= mus[j] && zmu0 > mus[j + 1]) isol = j;
         if (zmu0 <= mus[n - 1]) isol = n - 2;
@@ -991,7 +1017,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
         double drad = ((1 - t) * (1 - u) * yx[0] + t * (1 - u) * yx[1] + t * u * yx[3] + (1 - t) * u * yx[2]) *
-                      cos(ic * p.aphi[ipath] * pi / 180.0);
+                      ms_cos_ni(ic * p.aphi[ipath] * pi / 180.0);
         if (ic > 0) drad *= 2;
         if (!fdone) {                                   // :945-958
             frad += drad;
