@@ -2087,19 +2087,19 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     }
     p.hansen_comp0 = 0;
     if (nmu == 16) {
-        // matrix-core products (v_mfma_f64_16x16x4_f64), 6 LDS matrices with leading dimension 17; one block per (wavenumber,
+        // matrix-core products (v_mfma_f64_16x16x4_f64), 4 LDS matrices with leading dimension 17; one block per (wavenumber,
         // g) works through the Fourier orders and stops at the reference's convergence break (writes rad itself).
         // The Hansen walk is sequential over (g, wave) -- two waves on the whole chip -- so it is cut into one launch per
         // g-ordinate on a second stream and the chains of g start as soon as its factors exist: the walk of g + 1 hides
         // behind them (it was 11-18 % of a call when it ran ahead of all chains).
         const int ncu = ncont + (iray > 0 ? 1 : 0);
-        // two builds of the chain kernel.  <true>: the phase matrices of the Fourier order in LDS (at most two scattering
-        // components; 22 KB, seven blocks per CU, 163 registers).  <false>: phase matrices read from HBM / L2 every layer, 13.7 KB
-        // of LDS and a register cap for three waves per SIMD -- 46 spilled registers, 10 % slower at C4 (0.67 against 0.61 s),
-        // the path for three and more components.  ANSFM_MS_PHASE_LDS=0 forces the second.
-        p.phase_lds = (ncu >= 1 && ncu <= 2) ? 1 : 0;
-        if (const char *ev = getenv("ANSFM_MS_PHASE_LDS")) p.phase_lds = (p.phase_lds && atoi(ev) != 0) ? 1 : 0;
-        const size_t lds16 = (6 * 16 * 17 + 5 * 16 + (p.phase_lds ? (size_t)ncu * 2 * 256 : 0)) * D;
+        // two builds of the chain kernel, both capped for three waves per SIMD.  <false> (default): phase matrices read from
+        // HBM / L2 in every layer, 9.3 KB of LDS -- twelve blocks per CU; 65 registers spilled, reloaded in the layer set-up.
+        // <true> (ANSFM_MS_PHASE_LDS=1, at most two scattering components): the phase matrices of the Fourier order in LDS,
+        // 17.5 KB -- nine blocks per CU, no spills, a quarter of the vector-memory instructions; 2-4 % slower at C4.
+        p.phase_lds = 0;
+        if (const char *ev = getenv("ANSFM_MS_PHASE_LDS")) p.phase_lds = (ncu >= 1 && ncu <= 2 && atoi(ev) != 0) ? 1 : 0;
+        const size_t lds16 = (4 * 16 * 17 + 5 * 16 + (p.phase_lds ? (size_t)ncu * 2 * 256 : 0)) * D;
         auto launch_chain = [&](unsigned grid, hipStream_t st, const MsParams &pp) {
             if (pp.phase_lds) hipLaunchKernelGGL(k_ms_chain16<true>, dim3(grid), dim3(64), lds16, st, pp);
             else hipLaunchKernelGGL(k_ms_chain16<false>, dim3(grid), dim3(64), lds16, st, pp);

@@ -146,16 +146,73 @@ __global__ __launch_bounds__(256) void k_ms_phase(MsParams p)
     }
 }
 
+// Cross-lane sums without the LDS crossbar (__shfl_xor = ds_bpermute: an LDS round trip per stage, six dependent stages for a
+// norm, in front of every product that waits for the result).  Within a 16-lane row: DPP row rotations (VALU); across the
+// four rows: gfx950's v_permlane16_swap / v_permlane32_swap (vdst's odd rows / upper half <-> src's even rows / lower half;
+// with both operands the same register the two results are the partner values).  tools/calib/lane_reduce_check.hip.
+template <int CTRL> __device__ __forceinline__ double ms_dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ double ms_xor16_sum(double s)      // s[l] + s[l ^ 16]
+{
+    const long long b = __double_as_longlong(s);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __longlong_as_double(((long long)rh[0] << 32) | (unsigned long long)rl[0]) +
+           __longlong_as_double(((long long)rh[1] << 32) | (unsigned long long)rl[1]);
+}
+__device__ __forceinline__ double ms_xor32_sum(double s)      // s[l] + s[l ^ 32]
+{
+    const long long b = __double_as_longlong(s);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __longlong_as_double(((long long)rh[0] << 32) | (unsigned long long)rl[0]) +
+           __longlong_as_double(((long long)rh[1] << 32) | (unsigned long long)rl[1]);
+}
+// maximum over the 64 lanes, the same way (every lane gets it)
+__device__ __forceinline__ double ms_wave_max(double x)
+{
+    x = fmax(x, ms_dpp_f64<0x128>(x));
+    x = fmax(x, ms_dpp_f64<0x124>(x));
+    x = fmax(x, ms_dpp_f64<0x122>(x));
+    x = fmax(x, ms_dpp_f64<0x121>(x));
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    x = fmax(__longlong_as_double(((long long)rh[0] << 32) | (unsigned long long)rl[0]),
+             __longlong_as_double(((long long)rh[1] << 32) | (unsigned long long)rl[1]));
+    const long long b2 = __double_as_longlong(x);
+    const unsigned lo2 = (unsigned)b2, hi2 = (unsigned)(b2 >> 32);
+    const auto sl = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false);
+    const auto sh = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
+    return fmax(__longlong_as_double(((long long)sh[0] << 32) | (unsigned long long)sl[0]),
+                __longlong_as_double(((long long)sh[1] << 32) | (unsigned long long)sl[1]));
+}
+
 // Hansen renormalisation (hansen :200-233).  The reference keeps ONE fc array per scatterer for the whole
 // call and hansen() updates it in place, so the factor found for (g, wave) is the starting point of the
 // next (g, wave) in loop order (:780-815); the normalisation has no unique solution, so the result depends
 // on that history (a 1e-4 effect on the radiance).  Reproduced: one wavefront per scatterer walks the
 // (g outer, wave inner) sequence and stores fc[g][wave][comp][nmu*nmu].
+// One wavefront per block: LDS instructions of a wave execute in order, so a compiler fence orders the lanes' LDS accesses.
+// __syncthreads() also waits for every outstanding GLOBAL access (vmcnt(0)) -- here that is the prefetch of the matrices two
+// steps ahead and the store of the factors, i.e. a full memory round trip in every step of a walk that is nothing but latency.
+#define MS_WAVE_SYNC() __atomic_signal_fence(__ATOMIC_SEQ_CST)
 template <int NMU>   // NMU = 16: compile-time size (unrolled sums, all LDS reads in flight); 0: any nmu <= 20
 __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
 {
     __shared__ double ppl_s[2][kMsMaxMu * kMsMaxMu], pmi_s[2][kMsMaxMu * kMsMaxMu], fc[kMsMaxMu * kMsMaxMu];
-    __shared__ double rsum[kMsMaxMu], tsum[kMsMaxMu];
+    __shared__ double rsum[kMsMaxMu], tsum[kMsMaxMu], xs[kMsMaxMu];
+    // two waves on the whole chip walk while thousands of chain waves compute: the walk gates the chains of the next
+    // g-ordinate, so its waves issue first wherever they share a SIMD
+    __builtin_amdgcn_s_setprio(3);
     const int comp = blockIdx.x + p.hansen_comp0;
     const int n = NMU ? NMU : p.nmu, nn = n * n, tid = threadIdx.x;
     const double x1 = 2.0 * 3.141592653589793;
@@ -196,7 +253,7 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
         const double *ppl = ppl_s[buf], *pmi = pmi_s[buf];
         if (iter + 1 < total) stage(buf ^ 1);                   // data of iter+1 (its readers are two syncs away)
         if (iter + 2 < total) fetch((int)((iter + 2) % p.nwave));
-        __syncthreads();
+        MS_WAVE_SYNC();
         double rs = 0.0;
         if (tid < n) {
             double s = 0.0;
@@ -215,25 +272,26 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
                 tsum[tid] = ts;
                 dev = fabs(rs + ts - 1.0);
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) dev = fmax(dev, __shfl_xor(dev, off, 64));
-            __syncthreads();
+            dev = ms_wave_max(dev);                  // VALU lane exchanges (six dependent ds_bpermute stages before)
+            MS_WAVE_SYNC();
             if (dev < 1e-14) break;
+            if (tid < n) xs[tid] = (1.0 - rsum[tid]) / tsum[tid];   // one division per column instead of two per element
+            MS_WAVE_SYNC();
             for (int e = tid; e < nn; e += 64) {
                 const int i = e / n, j = e % n;
                 if (i <= j) {
-                    const double xj = (1.0 - rsum[j]) / tsum[j], xi = (1.0 - rsum[i]) / tsum[i];
+                    const double xj = xs[j], xi = xs[i];
                     const double v = 0.5 * (fc[i * n + j] * xj + fc[j * n + i] * xi);
                     fc[i * n + j] = v;
                     fc[j * n + i] = v;
                 }
             }
-            __syncthreads();
+            MS_WAVE_SYNC();
         }
         double *ofc = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp + comp) * nn;
         for (int e = tid; e < nn; e += 64) ofc[e] = fc[e];
         if (++widx == p.nwave) { widx = 0; ++ig; }
-        __syncthreads();
+        MS_WAVE_SYNC();
     }
 }
 
@@ -539,35 +597,6 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
 // the a-operand registers (4 FMAs + a reduction over q).  One wavefront per block: LDS is in-order per
 // wave, so a compiler fence replaces the barriers.
 #define MS16_FENCE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
-// Cross-lane sums without the LDS crossbar (__shfl_xor = ds_bpermute: an LDS round trip per stage, six dependent stages for a
-// norm, in front of every product that waits for the result).  Within a 16-lane row: DPP row rotations (VALU); across the
-// four rows: gfx950's v_permlane16_swap / v_permlane32_swap (vdst's odd rows / upper half <-> src's even rows / lower half;
-// with both operands the same register the two results are the partner values).  tools/calib/lane_reduce_check.hip.
-template <int CTRL> __device__ __forceinline__ double ms_dpp_f64(double v)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
-}
-__device__ __forceinline__ double ms_xor16_sum(double s)      // s[l] + s[l ^ 16]
-{
-    const long long b = __double_as_longlong(s);
-    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
-    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return __longlong_as_double(((long long)rh[0] << 32) | (unsigned long long)rl[0]) +
-           __longlong_as_double(((long long)rh[1] << 32) | (unsigned long long)rl[1]);
-}
-__device__ __forceinline__ double ms_xor32_sum(double s)      // s[l] + s[l ^ 32]
-{
-    const long long b = __double_as_longlong(s);
-    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
-    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __longlong_as_double(((long long)rh[0] << 32) | (unsigned long long)rl[0]) +
-           __longlong_as_double(((long long)rh[1] << 32) | (unsigned long long)rl[1]);
-}
 struct Ms16 {
     int c, q;
     __device__ __forceinline__ void load_a(const double *M, double a[4]) const
@@ -706,14 +735,15 @@ __device__ __attribute__((noinline)) double ms_exp2_ni(double x) { return exp2(x
 __device__ __attribute__((noinline)) double ms_exp_ni(double x) { return exp(x); }
 __device__ __attribute__((noinline)) double ms_cos_ni(double x) { return cos(x); }
 
-// Register allocation decides how many waves share a SIMD, and a wave of this kernel spends half of its time waiting to
-// issue (dependent products on a shared MFMA pipe).  History: 280 registers after the Fourier-order loop moved into the
-// block = ONE wave per SIMD; capped at 256 = two (C4 at 2000 wavenumbers 0.266 -> 0.196 s).  With the libm calls and the
-// Gauss-Jordan fallback out of line the PHASE_LDS = true build needs 163 -- but its 22 KB of LDS hold seven blocks per CU
-// anyway.  PHASE_LDS = false (phase matrices read from HBM / L2 in every layer, 13.7 KB of LDS: eleven blocks) is capped for
-// three waves per SIMD and spills 46 registers: slower (C4 0.67 against 0.61 s), kept for three and more components.
+// Register allocation and LDS decide how many waves share a SIMD, and a wave of this kernel spends half of its time waiting
+// to issue (dependent products on a shared MFMA pipe).  History at C4 (1e4 wavenumbers): 280 registers after the Fourier-order
+// loop moved into the block = ONE wave per SIMD, 1.05 s; capped at 256 = two, 0.73 s; libm calls and the Gauss-Jordan fallback
+// out of line (they count towards the allocation: log2 / exp2 14 registers, exp 14, cos more), the inverse's scratch aliased
+// onto r1 / t1 (4 instead of 6 LDS matrices) and a cap of 168 = three waves per SIMD, 0.59-0.60 s.  PHASE_LDS = true keeps the
+// phase matrices of the Fourier order in LDS (17.5 KB: nine blocks per CU, no spills); PHASE_LDS = false reads them from HBM / L2
+// in every layer (9.3 KB: twelve blocks, 65 registers spilled in the layer set-up) and is 2-4 % faster: the default.
 template <bool PHASE_LDS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE_LDS ? 2 : 3, PHASE_LDS ? 2 : 3))) void k_ms_chain16(MsParams p)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ms_chain16(MsParams p)
 {
     extern __shared__ double sm[];
     const int lane = threadIdx.x;
@@ -723,8 +753,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE_LDS ? 
     const int ig = p.ig0 + (int)(blockIdx.x % p.ng_launch);
     const int widx = blockIdx.x / p.ng_launch;
     const double pi = 3.141592653589793;
-    double *rc = sm, *tc = rc + msz, *r1 = tc + msz, *t1 = r1 + msz, *mA = t1 + msz, *mB = mA + msz;
-    double *jc = mB + msz, *j1 = jc + 16, *v0 = j1 + 16, *mus = v0 + 16, *wts = mus + 16;
+    // rc / tc: the stack below; r1 / t1: the layer's operators as LEFT operands (their right-operand form stays in registers).
+    // The same two matrices are the scratch of the inverse and of the chained products (mA / mB): every step reads its left
+    // operands out of r1 / t1 first and stores the new r1 / t1 last.
+    double *rc = sm, *tc = rc + msz, *r1 = tc + msz, *t1 = r1 + msz, *mA = r1, *mB = t1;
+    double *jc = t1 + msz, *j1 = jc + 16, *v0 = j1 + 16, *mus = v0 + 16, *wts = mus + 16;
     // radg[:, ::-1] (:765) sits in j1 once the layer loop is done
     double *radg = j1;
     // phase matrices of this Fourier order (P++ times the Hansen factor, P+-) by component, lane-private [comp][2][4][64]:
@@ -859,6 +892,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE_LDS ? 
             for (int it = 0; it < nd; ++it) {   // add :275-297
                 double aR[4], aT[4], aC[4], aS[4];
                 L.load_a(r1, aR);
+                L.load_a(t1, aT);                                             // before r1 / t1 serve as scratch
                 const ms_v4f64 bcom = Ms16::mm(aR, bR);                       // r1 r1
                 ms_v4f64 acom;
                 if (Ms16::frob(bR) > 0.1) {                                   // inv(e - bcom)
@@ -870,7 +904,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE_LDS ? 
                     }
                 } else
                     acom = L.eye_plus(bcom, 1.0);
-                L.load_a(t1, aT);
                 const ms_v4f64 ccom = Ms16::mm(aT, acom);                     // t1 acom
                 L.store_d(mB, ccom);
                 double jcom = 0.0;
@@ -907,6 +940,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE_LDS ? 
             const ms_v4f64 bR1 = L.load_d(r1), bT1 = L.load_d(t1), bRc = L.load_d(rc), bTc = L.load_d(tc);
             const double j1v = j1[c];
             L.load_a(rc, aRc);
+            L.load_a(t1, aT);                                                 // before r1 / t1 serve as scratch
             const ms_v4f64 rsq = Ms16::mm(aRc, bR1);                          // rsub r1
             ms_v4f64 acom;
             if (Ms16::frob(rsq) > 0.01) {
@@ -918,7 +952,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PHASE_LDS ? 
                 }
             } else
                 acom = L.eye_plus(rsq, 1.0);
-            L.load_a(t1, aT);
             const ms_v4f64 ccom = Ms16::mm(aT, acom);                         // t1 acom
             L.store_d(mB, ccom);
             const double jcom = L.mv(aRc, j1) + jc[c];                        // rsub j1 + jsub

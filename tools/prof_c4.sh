@@ -12,7 +12,7 @@ python3 - <<PY
 import csv,glob,json
 from collections import defaultdict
 f=glob.glob("$OUT/trace/**/*kernel_stats.csv",recursive=True)[0]
-st={r["Name"].split("(")[0]: r for r in csv.DictReader(open(f))}
+st={r["Name"].split("(")[0].replace("void ","").split("<")[0]: r for r in csv.DictReader(open(f))}
 for k,r in list(st.items())[:8]: print(k[:60], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"])
 f=glob.glob("$OUT/pmc/**/*counter_collection.csv",recursive=True)[0]
 acc=defaultdict(lambda: defaultdict(float)); n=defaultdict(int)
