@@ -492,6 +492,31 @@ def test_scloud11wave_core_vs_oracle_random(eng, oracle, golden_dir):
         eng.scloud11wave_core(*ms_args(z))
 
 
+def test_scloud11wave_core_nearly_conservative_thick_layers_vs_oracle(eng, oracle, golden_dir):
+    """Optically thick, almost conservatively scattering layers at 16 streams (20 and more doublings per layer, reflection
+    operators of norm close to 1): the regime where the product-form Neumann series of inv(E - r r) needs most of its 12
+    squarings.  The oracle inverts by elimination throughout."""
+    from test_ms_oracle import ms_args
+    z = dict(_load(golden_dir, "ms_nmu16_tab_ray"))
+    rng = np.random.default_rng(8)
+    W, G, L = 3, 2, 3
+    nmu = z["mu1"].size; ncont = z["phasarr"].shape[0]
+    z["vwaves"] = 500.0 + 10.0 * np.arange(W)
+    z["phasarr"] = np.ascontiguousarray(np.broadcast_to(z["phasarr"][:, :1], (ncont, W) + z["phasarr"].shape[2:]))
+    taus = np.empty((W, G, L)); taus[:, :, 0] = 0.3; taus[:, :, 1] = rng.uniform(300.0, 3000.0, (W, G)); taus[:, :, 2] = 40.0
+    tauray = np.full((W, L), 1e-4)
+    z["taus"] = taus; z["tauray"] = tauray
+    om = np.empty((W, G, L)); om[:, :, 0] = 0.6; om[:, :, 1] = 1.0 - 1e-7; om[:, :, 2] = 0.9999
+    z["omegas_s"] = om
+    fr = rng.uniform(0.1, 1.0, size=(W, ncont, L)); z["lfrac"] = fr / fr.sum(axis=1, keepdims=True)
+    z["bnu"] = 10.0 ** rng.uniform(-8, -6, size=(W, L)); z["radg"] = 10.0 ** rng.uniform(-8, -6, size=(W, nmu))
+    z["solar"] = 10.0 ** rng.uniform(-9, -8, W); z["brdf_matrix"] = np.zeros((W, nmu, nmu, int(z["nf"]) + 1))
+    rad = eng.scloud11wave_core(*ms_args(z))
+    ref = oracle.scloud11wave_core(*ms_args(z))
+    assert np.all(np.isfinite(rad))
+    np.testing.assert_allclose(rad, ref, rtol=1e-6)      # inv(E - r r) is ill-conditioned here: the contract, not 1e-8
+
+
 @pytest.mark.parametrize("name", ["lbl_tab", "lbl_tab_t2d_f32"])
 def test_calc_klbl_golden(eng, golden_dir, name):
     z = _load(golden_dir, name)
