@@ -709,14 +709,17 @@ __device__ __forceinline__ bool ms_inv16_series(const Ms16 &L, ms_v4f64 B, doubl
 {
     X = L.eye_plus(B, 1.0);
     ms_v4f64 Pw = B;
+    double fP = Ms16::frob(B);
     for (int it = 0; it < 12; ++it) {
         double aP[4], aX[4];
+        if (fP * fP < 1e-17) return true;                      // |P^2|_F <= |P|_F^2: the next power would be dropped anyway
         L.store_d(mA, Pw);
         L.store_d(mB, X);
         MS16_FENCE();
         L.load_a(mA, aP);
         const ms_v4f64 P2 = Ms16::mm(aP, Pw);                  // B^(2^(it+1))
-        if (!(Ms16::frob(P2) >= 1e-17)) return true;           // also leaves on NaN
+        fP = Ms16::frob(P2);
+        if (!(fP >= 1e-17)) return true;                       // also leaves on NaN
         L.load_a(mB, aX);
         const ms_v4f64 XP = Ms16::mm(aX, P2);
 #pragma unroll
