@@ -335,21 +335,23 @@ def main():
             YN, KK = jacobian_nemesis_batched(model, rank=rank, world_size=world, force_collective=use_dist)
             barrier()
             jt = time.perf_counter() - t0
+            km = eng.last_kernel_ms()
             if use_dist:
                 t = torch.tensor([jt], dtype=f8, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 jt = float(t.item())
-            return jt, model.last_rows, YN, KK
+            return jt, model.last_rows, YN, KK, km
 
         run_jac(True)                                   # warm-up: buffers of the batch sizes
-        jt_all, rows_all, YN_a, KK_a = run_jac(False)
+        jt_all, rows_all, YN_a, KK_a, _ = run_jac(False)
         reps = [run_jac(True) for _ in range(3)]        # median of three: a single call varies 0.06 - 0.12 s with the host side
         jts = sorted(r[0] for r in reps)
         jt, rows, YN_j, KK_j = jts[1], reps[-1][1], reps[-1][2], reps[-1][3]
         eng.set_layer_dedup(True)
         jac = {"forward_models": st.NX + 1, "state_vector": f"T and ln(VMR) of one absorber at {npro} levels (NX = {st.NX}), "
                "through layer_average (Curtis-Godson, NINT 101) and the Rayleigh continuum",
-               "wall_s": jt, "wall_s_three_calls": jts, "fm_per_s": (st.NX + 1) / jt, "wall_s_all_layers": jt_all,
+               "wall_s": jt, "wall_s_three_calls": jts, "merge_kernel_ms_rank0": reps[-1][4]["overlap_ms"],
+               "rt_kernel_ms_rank0": reps[-1][4]["rt_ms"], "fm_per_s": (st.NX + 1) / jt, "wall_s_all_layers": jt_all,
                "layer_opacities_computed_rank0": int(rows[0]), "layer_opacities_all_rank0": int(rows_all[0]),
                "dedup_bit_identical": bool(np.array_equal(KK_a, KK_j) and np.array_equal(YN_a, YN_j)),
                "kk_shape": list(KK_j.shape),
