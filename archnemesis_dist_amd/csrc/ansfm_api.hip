@@ -569,6 +569,18 @@ static int launch_overlap(ansfm_ctx *ctx, bool from_k, const double *kin, int W,
 static int lbl_prep_fwd(ansfm_ctx *ctx, int n_layers, const double *lay_press, const double *lay_temp, double press_div,
                         int with_grad);
 
+// src[W][X1][X2] -> dst[(x1, x2) or, swap12, (x2, x1)][Wpad] through a 32 x 32 LDS tile (k_transpose_w_last): both sides move
+// whole 256-byte segments.  The element-per-thread version read with a stride of X1 * X2 doubles: 0.18 TB/s, 17.7 of the
+// 58 ms of a C3 Jacobian call for the continuum of its 201 states.
+static void launch_w_to_last(hipStream_t st, unsigned n_batch, const double *src, double *dst, int W, int Wpad, int X1, int X2,
+                             int swap12, double padval, size_t src_stride = 0, size_t dst_stride = 0)
+{
+    const int X = X1 * X2;
+    dim3 grid((unsigned)(Wpad / 32), (unsigned)((X + 31) / 32), n_batch);
+    hipLaunchKernelGGL(k_transpose_w_last, grid, dim3(32, 8), 0, st, src, dst, W, Wpad, X1, X2, swap12, padval, src_stride,
+                       dst_stride);
+}
+
 static int launch_rt(ansfm_ctx *ctx, const RtParams &p, int n_models)
 {
     dim3 grid((unsigned)n_models, (unsigned)p.P, (unsigned)(p.Wpad / kWave));
@@ -654,8 +666,7 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
     const double *cont_t = nullptr;
     if (taucont) {
         HIPCHK(ctx->cont_t.reserve((size_t)n_models * L * Wpad * sizeof(double)));
-        hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256), (unsigned)n_models), dim3(256), 0, ctx->stream,
-                           taucont, ctx->cont_t.as<double>(), W, Wpad, 1, L, 0, 0.0, (size_t)W * L, (size_t)L * Wpad);
+        launch_w_to_last(ctx->stream, (unsigned)n_models, taucont, ctx->cont_t.as<double>(), W, Wpad, 1, L, 0, 0.0, (size_t)W * L, (size_t)L * Wpad);
         HIPCHK(hipGetLastError());
         cont_t = ctx->cont_t.as<double>();
     }
@@ -966,12 +977,9 @@ int ansfm_singlescatt_plane_spectrum(ansfm_ctx *ctx, int ISPACE, int W, int G, i
     HIPCHK(ctx->misc.reserve(2 * ntau * D));
     HIPCHK(ctx->cont_t.reserve((size_t)Li * Wpad * D));
     double *tau_t = ctx->misc.as<double>(), *om_t = tau_t + ntau;
-    hipLaunchKernelGGL(k_w_to_last, dim3(nblk(ntau, 256)), dim3(256), 0, ctx->stream, (const double *)d[0], tau_t, W, Wpad, G, Li,
-                       1, 0.0);
-    hipLaunchKernelGGL(k_w_to_last, dim3(nblk(ntau, 256)), dim3(256), 0, ctx->stream, (const double *)d[1], om_t, W, Wpad, G, Li,
-                       1, 0.0);
-    hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)Li * Wpad, 256)), dim3(256), 0, ctx->stream, (const double *)d[2],
-                       ctx->cont_t.as<double>(), W, Wpad, 1, Li, 0, 0.0);
+    launch_w_to_last(ctx->stream, (unsigned)1, (const double *)d[0], tau_t, W, Wpad, G, Li, 1, 0.0);
+    launch_w_to_last(ctx->stream, (unsigned)1, (const double *)d[1], om_t, W, Wpad, G, Li, 1, 0.0);
+    launch_w_to_last(ctx->stream, (unsigned)1, (const double *)d[2], ctx->cont_t.as<double>(), W, Wpad, 1, Li, 0, 0.0);
     HIPCHK(hipGetLastError());
     HIPCHK(ctx->tmp_out.reserve((size_t)W * G * D));
     RtParams r;
@@ -1057,14 +1065,11 @@ int ansfm_cirsrad_ck_singlescatt(ansfm_ctx *ctx, int ISPACE, int L, const double
     double *sca_t = ctx->misc.as<double>(), *ph_t = sca_t + (size_t)L * Wpad;
     const double *cont_t = nullptr;
     if (d[3]) {
-        hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256)), dim3(256), 0, ctx->stream, (const double *)d[3],
-                           ctx->cont_t.as<double>(), W, Wpad, 1, L, 0, 0.0);
+        launch_w_to_last(ctx->stream, (unsigned)1, (const double *)d[3], ctx->cont_t.as<double>(), W, Wpad, 1, L, 0, 0.0);
         cont_t = ctx->cont_t.as<double>();
     }
-    hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256)), dim3(256), 0, ctx->stream, (const double *)d[4], sca_t, W,
-                       Wpad, 1, L, 0, 0.0);
-    hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256), (unsigned)P), dim3(256), 0, ctx->stream, (const double *)d[5],
-                       ph_t, W, Wpad, 1, L, 0, 0.0, WL, (size_t)L * Wpad);
+    launch_w_to_last(ctx->stream, (unsigned)1, (const double *)d[4], sca_t, W, Wpad, 1, L, 0, 0.0);
+    launch_w_to_last(ctx->stream, (unsigned)P, (const double *)d[5], ph_t, W, Wpad, 1, L, 0, 0.0, WL, (size_t)L * Wpad);
     HIPCHK(hipGetLastError());
     HIPCHK(ctx->tmp_out.reserve((size_t)W * P * D));
     RtParams r;
@@ -1150,13 +1155,11 @@ int ansfm_thermal_emission(ansfm_ctx *ctx, int ISPACE, int W, int G, int NLAYIN,
     // TAUTOT_PATH[W][G][Li] -> tau[Li][G][Wpad]
     const size_t ntau = (size_t)Li * G * Wpad;
     HIPCHK(ctx->misc.reserve(ntau * D));
-    hipLaunchKernelGGL(k_w_to_last, dim3(nblk(ntau, 256)), dim3(256), 0, ctx->stream, (const double *)d[0],
-                       ctx->misc.as<double>(), W, Wpad, G, Li, 1, 0.0);
+    launch_w_to_last(ctx->stream, (unsigned)1, (const double *)d[0], ctx->misc.as<double>(), W, Wpad, G, Li, 1, 0.0);
     const double *emi_t = nullptr;
     if (d[1]) {
         HIPCHK(ctx->cont_t.reserve((size_t)Li * Wpad * D));
-        hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)Li * Wpad, 256)), dim3(256), 0, ctx->stream,
-                           (const double *)d[1], ctx->cont_t.as<double>(), W, Wpad, 1, Li, 0, 0.0);
+        launch_w_to_last(ctx->stream, (unsigned)1, (const double *)d[1], ctx->cont_t.as<double>(), W, Wpad, 1, Li, 0, 0.0);
         emi_t = ctx->cont_t.as<double>();
     }
     HIPCHK(hipGetLastError());
@@ -1295,15 +1298,12 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
     const double *cont_t = nullptr, *dcont_t = nullptr;
     if (taucont) {
         HIPCHK(ctx->cont_t.reserve((size_t)n_models * L * Wpad * sizeof(double)));
-        hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)L * Wpad, 256), (unsigned)n_models), dim3(256), 0, ctx->stream,
-                           taucont, ctx->cont_t.as<double>(), W, Wpad, 1, L, 0, 0.0, (size_t)W * L, (size_t)L * Wpad);
+        launch_w_to_last(ctx->stream, (unsigned)n_models, taucont, ctx->cont_t.as<double>(), W, Wpad, 1, L, 0, 0.0, (size_t)W * L, (size_t)L * Wpad);
         cont_t = ctx->cont_t.as<double>();
     }
     if (dtaucon) {
         HIPCHK(ctx->dcont_t.reserve((size_t)n_models * NPAR * L * Wpad * sizeof(double)));
-        hipLaunchKernelGGL(k_w_to_last, dim3(nblk((size_t)NPAR * L * Wpad, 256), (unsigned)n_models), dim3(256), 0, ctx->stream,
-                           dtaucon, ctx->dcont_t.as<double>(), W, Wpad, NPAR, L, 0, 0.0, (size_t)W * NPAR * L,
-                           (size_t)NPAR * L * Wpad);
+        launch_w_to_last(ctx->stream, (unsigned)n_models, dtaucon, ctx->dcont_t.as<double>(), W, Wpad, NPAR, L, 0, 0.0, (size_t)W * NPAR * L, (size_t)NPAR * L * Wpad);
         dcont_t = ctx->dcont_t.as<double>();
     }
     HIPCHK(hipGetLastError());

@@ -1742,21 +1742,33 @@ __global__ void k_dspec_to_ref(const double *__restrict__ src, double *__restric
 // ------------------------------------------------------------------------------------------------
 // layout helpers (host-pointer seams): src[W][X1][X2] -> dst[(x1,x2 or x2,x1)][Wpad]
 // ------------------------------------------------------------------------------------------------
-// blockIdx.y = model of a batch (src_stride / dst_stride elements apart; 0 for a single array)
-__global__ void k_w_to_last(const double *__restrict__ src, double *__restrict__ dst, int W, int Wpad,
-                            int X1, int X2, int swap12, double padval, size_t src_stride = 0, size_t dst_stride = 0)
+// blockIdx.z = model of a batch (src_stride / dst_stride elements apart; 0 for a single array).
+// Through a 32 x 32 LDS tile: block (32, 8); grid (Wpad / 32, ceil(X1 X2 / 32), batch).  Reads run along x (the source's
+// fastest axis), writes along w.
+__global__ __launch_bounds__(256) void k_transpose_w_last(const double *__restrict__ src, double *__restrict__ dst, int W, int Wpad,
+                                                          int X1, int X2, int swap12, double padval, size_t src_stride,
+                                                          size_t dst_stride)
 {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t total = (size_t)X1 * X2 * Wpad;
-    if (idx >= total) return;
-    src += (size_t)blockIdx.y * src_stride;
-    dst += (size_t)blockIdx.y * dst_stride;
-    int w = (int)(idx % Wpad);
-    size_t r = idx / Wpad;
-    int x1, x2;
-    if (swap12) { x1 = (int)(r % X1); x2 = (int)(r / X1); }
-    else { x2 = (int)(r % X2); x1 = (int)(r / X2); }
-    dst[idx] = (w < W) ? src[((size_t)w * X1 + x1) * X2 + x2] : padval;
+    __shared__ double tile[32][33];
+    const int X = X1 * X2;
+    src += (size_t)blockIdx.z * src_stride;
+    dst += (size_t)blockIdx.z * dst_stride;
+    const int w0 = blockIdx.x * 32, x0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int w = w0 + ty + 8 * k, x = x0 + tx;
+        tile[ty + 8 * k][tx] = (w < W && x < X) ? src[(size_t)w * X + x] : padval;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x0 + ty + 8 * k;           // source column = x1 * X2 + x2
+        if (x < X) {
+            const int row = swap12 ? (x % X2) * X1 + x / X2 : x;
+            dst[(size_t)row * Wpad + w0 + tx] = tile[tx][ty + 8 * k];
+        }
+    }
 }
 // src[X1][X2][Wpad] -> dst[W][X1][X2]  (swap12: dst[W][X2][X1])
 __global__ void k_w_to_first(const double *__restrict__ src, double *__restrict__ dst, int W, int Wpad,
