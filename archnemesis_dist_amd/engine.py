@@ -70,7 +70,16 @@ class AnsfmEngine:
 
     # ---- stream -------------------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr):
+        """Run on the caller's HIP stream.  0 / None = the engine's own (non-blocking) stream: a null handle cannot name the
+        legacy default stream through the C-ABI, so code that shares device buffers with another runtime on ITS default
+        stream must order the two itself (see `stream_ptr`, `BatchedCKThermalModel.spectra_batch`)."""
         self._check(self._lib.ansfm_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or 0)), "set_stream")
+        self._stream_ptr = int(hip_stream_ptr or 0)
+
+    @property
+    def stream_ptr(self):
+        """handle of the stream the engine was given, 0 while it runs on its own"""
+        return getattr(self, "_stream_ptr", 0)
 
     def synchronize(self):
         self._check(self._lib.ansfm_synchronize(self._ctx), "synchronize")

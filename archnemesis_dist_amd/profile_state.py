@@ -124,18 +124,32 @@ class BatchedCKThermalModel:
         td = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
         path = lay["path"]
         P_, LIMAX = path.NPATH, path.LAYINC.shape[0]
+        # torch and the engine share these buffers: on one stream they are ordered by construction; otherwise (the engine on
+        # its own stream, e.g. because torch's current stream is the default one, whose handle is null) what torch has queued
+        # is waited for before the engine starts and the engine is drained before torch sees the result
+        cur = torch.cuda.current_stream(dev)
+        shared = cur.cuda_stream != 0 and eng.stream_ptr == cur.cuda_stream
+        order = (lambda: None) if shared else cur.synchronize
         cont = None
         if self.IRAY != 0 or self.extra is not None:
-            cont = torch.zeros((n, self.W, L), dtype=torch.float64, device=dev)
-            if self.IRAY != 0:
+            if self.IRAY != 0:       # the kernel assigns every element
+                cont = torch.empty((n, self.W, L), dtype=torch.float64, device=dev)
+                order()
                 eng.calc_tau_rayleigh_batch_dev(self.IRAY, self.ISPACE, lay["TOTAM"], cont, ID=self.ID, ISO=self.ISO,
                                                 VMR=lay["VMRLAY"])
+                if not shared:
+                    eng.synchronize()
+            else:
+                cont = torch.zeros((n, self.W, L), dtype=torch.float64, device=dev)
             if self.extra is not None:
                 cont += td(self.extra)[None]
         out = torch.empty((n, self.W, P_), dtype=torch.float64, device=dev)
         scale = np.repeat(path.SCALE[None], n, 0)
-        eng.cirsrad_ck_thermal_dev(self.ISPACE, n, L, td(lay["PRESS"]), td(lay["TEMP"]), td(lay["amount"]), cont, P_, LIMAX,
-                                   td(path.NLAYIN, torch.int32), td(path.LAYINC, torch.int32), td(scale), td(path.EMTEMP),
-                                   td(np.full(n, self.TSURF)), None, None, None, None, None, None, out)
+        args = (td(lay["PRESS"]), td(lay["TEMP"]), td(lay["amount"]), cont, P_, LIMAX, td(path.NLAYIN, torch.int32),
+                td(path.LAYINC, torch.int32), td(scale), td(path.EMTEMP), td(np.full(n, self.TSURF)))
+        order()
+        eng.cirsrad_ck_thermal_dev(self.ISPACE, n, L, *args, None, None, None, None, None, None, out)
         self.last_rows = eng.last_layer_rows()
+        if not shared:
+            eng.synchronize()
         return out.reshape(n, self.W * P_)

@@ -245,7 +245,10 @@ def main():
     W, G, S, L, NP, NT, P = args.waves, args.ng, args.gases, args.layers, 20, 15, 1
     f8 = torch.float64
     eng = pkg.AnsfmEngine(local_rank)
-    stream = torch.cuda.current_stream()
+    # one stream for torch and the engine: torch's default stream has a null handle, which the C-ABI reads as "the engine's
+    # own stream" -- the two would then run side by side on shared buffers
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
 
     # ---- synthetic inputs, resident in HBM -----------------------------------------------------

@@ -14,7 +14,8 @@ from archnemesis_dist_amd.profile_state import ContinuousProfileState, BatchedCK
 dev = torch.device("cuda:0")
 W, G, S, L, NP, NT = 10000, 20, 8, 100, 20, 15
 eng = pkg.AnsfmEngine(0)
-eng.set_stream(torch.cuda.current_stream().cuda_stream)
+stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
+eng.set_stream(stream.cuda_stream)
 PRESS, TEMP, K = B.torch_ktable(torch, dev, W, G, NP, NT, S, seed=20260704)
 _, delg = syn.gauss_legendre_01(G, as_float32=True)
 WAVE = 200.0 + 0.1 * np.arange(W)
