@@ -76,6 +76,17 @@ class AnsfmEngine:
         self._check(self._lib.ansfm_set_stream(self._ctx, C.c_void_p(hip_stream_ptr or 0)), "set_stream")
         self._stream_ptr = int(hip_stream_ptr or 0)
 
+    def _order_after_torch(self, t):
+        """A torch CUDA tensor handed to a device entry point: unless torch's current stream IS the engine's, wait for what
+        torch has queued (its kernels may still be writing the tensor)."""
+        try:
+            import torch
+            cur = torch.cuda.current_stream(t.device)
+            if cur.cuda_stream == 0 or cur.cuda_stream != self.stream_ptr:
+                cur.synchronize()
+        except ImportError:
+            pass
+
     @property
     def stream_ptr(self):
         """handle of the stream the engine was given, 0 while it runs on its own"""
@@ -105,6 +116,7 @@ class AnsfmEngine:
                                                _ptr(WAVE), _ptr(DELG))
         else:
             assert K.is_contiguous() and K.dtype.is_floating_point and K.element_size() == 8
+            self._order_after_torch(K)
             rc = self._lib.ansfm_upload_ktable_dev(self._ctx, W, G, NP, NT, S, _ptr(K), _ptr(PRESS), _ptr(TEMP),
                                                    _ptr(WAVE), _ptr(DELG))
         self._check(rc, "upload_ktable")
