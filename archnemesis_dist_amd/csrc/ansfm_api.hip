@@ -1855,7 +1855,7 @@ int ansfm_calc_tau_rayleigh(ansfm_ctx *ctx, int mode, int ISPACE, int W, const d
     p.wavec = (const double *)d[0]; p.totam = (const double *)d[1]; p.f4 = (const double *)d[2];
     p.tau = ctx->tmp_out.as<double>(); p.dtau = p.tau + nt;
     p.W = W; p.L = L; p.mode = mode; p.ispace = ISPACE;
-    hipLaunchKernelGGL(k_tau_rayleigh, dim3(nblk((size_t)W, 128), (unsigned)L), dim3(128), 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_tau_rayleigh, dim3(nblk((size_t)W * L, 128)), dim3(128), 0, ctx->stream, p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(TAURAY, p.tau, nt * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(dTAURAY, p.dtau, nt * D, hipMemcpyDeviceToHost, ctx->stream));
@@ -1871,7 +1871,6 @@ int ansfm_calc_tau_rayleigh_batch_dev(ansfm_ctx *ctx, int mode, int ISPACE, int 
     if (n_models <= 0 || L <= 0 || !TOTAM || !TAURAY_dev || (ISPACE != 0 && ISPACE != 1) ||
         (mode != 1 && mode != 2 && mode != 4 && mode != 12) || (mode == 4 && !f4))
         FAIL(ANSFM_ERR_INVALID, "calc_tau_rayleigh_batch_dev: bad argument (mode = IRAY 1, 2, 4 or 12 for calc_tau_rayleighv)");
-    if ((long)n_models * L > 65535) FAIL(ANSFM_ERR_UNSUPPORTED, "calc_tau_rayleigh_batch_dev: at most 65535 layers in a batch");
     HIPCHK(hipSetDevice(ctx->device));
     const size_t D = sizeof(double), nl = (size_t)n_models * L;
     const void *d[2] = {nullptr, nullptr};
@@ -1883,7 +1882,7 @@ int ansfm_calc_tau_rayleigh_batch_dev(ansfm_ctx *ctx, int mode, int ISPACE, int 
     p.wavec = ctx->d_wave.as<double>(); p.totam = (const double *)d[0]; p.f4 = (const double *)d[1];
     p.tau = TAURAY_dev; p.dtau = nullptr;
     p.W = ctx->W; p.L = (int)nl; p.mode = mode; p.ispace = ISPACE; p.Lm = L;
-    hipLaunchKernelGGL(k_tau_rayleigh, dim3(nblk((size_t)ctx->W, 128), (unsigned)nl), dim3(128), 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_tau_rayleigh, dim3(nblk((size_t)ctx->W * nl, 128)), dim3(128), 0, ctx->stream, p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));       // the pinned-size host staging buffers are reused by the next call
     return ANSFM_OK;
