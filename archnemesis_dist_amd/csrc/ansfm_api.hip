@@ -586,7 +586,10 @@ static int launch_rt(ansfm_ctx *ctx, const RtParams &p, int n_models)
     dim3 grid((unsigned)n_models, (unsigned)p.P, (unsigned)(p.Wpad / kWave));
     if (p.Wpad / kWave > 65535) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: more than 65535 wavenumber tiles (4.19e6 wavenumbers)");
     if (p.LIMAX > 1500) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: at most 1500 layers along a path");
-    hipLaunchKernelGGL(k_thermal_rt, grid, dim3(kWave, kGY), (size_t)4 * p.LIMAX * sizeof(double), ctx->stream, p);
+    if (n_models >= 4)
+        hipLaunchKernelGGL(k_thermal_rt<true>, grid, dim3(kWave, kGY), (size_t)4 * p.LIMAX * sizeof(double), ctx->stream, p);
+    else
+        hipLaunchKernelGGL(k_thermal_rt<false>, grid, dim3(kWave, kGY), (size_t)4 * p.LIMAX * sizeof(double), ctx->stream, p);
     HIPCHK(hipGetLastError());
     return ANSFM_OK;
 }

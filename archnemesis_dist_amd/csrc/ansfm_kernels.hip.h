@@ -1302,7 +1302,12 @@ __device__ __forceinline__ double planck_bb(double a, double c2y, double T)
     return a / (exp(c2y / T) - 1.0);  // ForwardModel_0.py:6223-6225
 }
 
-__global__ __launch_bounds__(kWave *kGY) void k_thermal_rt(RtParams p)
+// BATCH: the build for many models per launch (a Jacobian's states).  One block is eight waves, two per SIMD; at the
+// kernel's natural 142 registers a second block does not fit on the CU, and a batch has the blocks to fill it: capped at 128
+// (14 spilled) the 201 states of a C3 Jacobian take 9.2 instead of 11.4 ms.  A single model has 157 blocks for 256 CUs and
+// only pays for the spills (0.093 -> 0.107 ms): it keeps the uncapped build.
+template <bool BATCH>
+__global__ __launch_bounds__(kWave *kGY) __attribute__((amdgpu_waves_per_eu(BATCH ? 4 : 1, BATCH ? 4 : 8))) void k_thermal_rt(RtParams p)
 {
     __shared__ double red[kGY][kWave];
     const int lane = threadIdx.x, gy = threadIdx.y;

@@ -29,3 +29,19 @@ for i in range(8):
     YN, KK = jacobian_nemesis_batched(model, rank=0, world_size=1)
     torch.cuda.synchronize(); t = time.perf_counter() - t0
     print(f"call {i}: {t*1e3:7.1f} ms  rows {model.last_rows}  reserved {torch.cuda.memory_reserved()/2**30:6.2f} GiB  kernels {eng.last_kernel_ms()}")
+
+# where the host time of a call goes
+import archnemesis_dist_amd.profile_state as ps
+_orig_layers = BatchedCKThermalModel.layers
+def timed_layers(self, X):
+    t0 = time.perf_counter(); r = _orig_layers(self, X); timed_layers.t = time.perf_counter() - t0; return r
+BatchedCKThermalModel.layers = timed_layers
+_orig_sb = BatchedCKThermalModel.spectra_batch
+def timed_sb(self, X, device=None):
+    t0 = time.perf_counter(); r = _orig_sb(self, X, device); torch.cuda.synchronize(); timed_sb.t = time.perf_counter() - t0; return r
+BatchedCKThermalModel.spectra_batch = timed_sb
+for i in range(6):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    YN, KK = jacobian_nemesis_batched(model, rank=0, world_size=1)
+    torch.cuda.synchronize(); t = time.perf_counter() - t0
+    print(f"split {i}: total {t*1e3:6.1f}  layers(host) {timed_layers.t*1e3:6.1f}  spectra_batch {timed_sb.t*1e3:6.1f}  rest {1e3*(t-timed_sb.t):6.1f} ms")
