@@ -153,3 +153,50 @@ class BatchedCKThermalModel:
         if not shared:
             eng.synchronize()
         return out.reshape(n, self.W * P_)
+
+    # ---- analytic route: nemesisfmg for the same configuration ----------------------------------------------------
+    def jacobian_analytic(self, X0=None):
+        """YN (NY,), KK (NY, NX) at the state X0 (default: the state's own XN) by analytic gradients -- what
+        `nemesisfmg` does (ForwardModel_0.py:593-779): `layer_averageg` (layer properties + DTE / DAM / DCO),
+        `CIRSrad(return_grad=True)` (k_ck_overlapg + k_thermal_rtg), `map2pro` (layers -> levels, :705) and `map2xvec`
+        (levels -> state vector, :711; for model 0 the map is 1 for a temperature element and the mixing ratio itself for
+        a ln(VMR) element, model_0.py), the two maps chained on the device.  Like the reference's, the temperature
+        columns are first order in DTE at fixed amounts (a level temperature enters through the layer temperatures as
+        `layer_averageg` linearises them, not through the number density) and, for TSURF <= 0, leave out the ground term's
+        dependence on the bottom layer's temperature (calc_thermal_emission_spectrumg :6484-6494 differentiates it with
+        respect to TSURF only) -- a finite difference through `layer_average` sees both.
+        Continuum gradients are not assembled here: IRAY must be 0."""
+        if self.IRAY != 0:
+            raise NotImplementedError("jacobian_analytic: Rayleigh continuum gradients (dTAURAY) are not assembled; use IRAY = 0 "
+                                      "or the finite-difference route")
+        eng, st, la, ge = self.eng, self.state, self.lay, self.geo
+        X0 = st.XN if X0 is None else np.asarray(X0, float)
+        T, VMR = st.profiles(X0[None])
+        T, VMR = T[0], VMR[0]
+        out = eng.layer_averageg(self.RADIUS, st.H, st.P, T, self.ID, VMR, self.DUST, self.PARAH2, self.BASEH, self.BASEP,
+                                 LAYANG=la["LAYANG"], LAYINT=la["LAYINT"], LAYHT=la["LAYHT"], NINT=la["NINT"])
+        names = ("HEIGHT", "PRESS", "TEMP", "TOTAM", "AMOUNT", "PP", "CONT", "FRAC", "DELH", "BASET", "LAYSF", "DTE", "DAM",
+                 "DCO", "DPH")
+        lay = dict(zip(names, out))
+        self.last_analytic_layers = lay              # layer properties and the DTE / DAM / DCO matrices of this call
+        path = layering.calc_path(self.RADIUS, self.BASEH, lay["DELH"], lay["TEMP"], float(st.H[-1]), pointing=ge["pointing"],
+                                  BOTLAY=ge["BOTLAY"], ANGLE=ge["ANGLE"], EMISS_ANG=ge["EMISS_ANG"], IPZEN=ge["IPZEN"])
+        amount = np.ascontiguousarray(lay["AMOUNT"][:, self.igas_map].T) * SQ_CM_TO_SQ_METER
+        NPRO, NVMR = VMR.shape
+        NDUST = lay["CONT"].shape[1]
+        NPAR = NVMR + 2 + NDUST
+        P_ = path.NPATH
+        spec, dspec, _ = eng.cirsradg_ck_thermal(self.ISPACE, lay["PRESS"], lay["TEMP"], amount, self.extra, None, NVMR, NPAR,
+                                                 self.igas_map.astype(np.int32), path.NLAYIN, path.LAYINC, path.SCALE,
+                                                 path.EMTEMP, self.TSURF)
+        pro = eng.map2pro(dspec, self.W, NVMR, NDUST, NPRO, P_, path.NLAYIN, path.LAYINC, lay["DTE"], lay["DAM"], lay["DCO"])
+        xmap = np.zeros((st.NX, NPAR, NPRO))
+        lev = np.arange(NPRO)
+        for b, (kind, j) in enumerate(st.blocks):
+            if kind == "T":
+                xmap[b * NPRO + lev, NVMR, lev] = 1.0
+            else:
+                xmap[b * NPRO + lev, j, lev] = VMR[:, j]           # d VMR / d ln VMR
+        xv = eng.map2xvec(pro, self.W, NVMR, NDUST, NPRO, P_, st.NX, xmap)          # (W, P, NX)
+        return spec.reshape(self.W * P_), xv.reshape(self.W * P_, st.NX)
+

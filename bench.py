@@ -359,6 +359,19 @@ def main():
                "dedup_bit_identical": bool(np.array_equal(KK_a, KK_j) and np.array_equal(YN_a, YN_j)),
                "kk_shape": list(KK_j.shape),
                "collective": "all_gather_into_tensor (RCCL)" if use_dist else None}
+        if rank == 0 and world == 1:
+            # the same state vector by analytic gradients (nemesisfmg's route: layer_averageg -> CIRSrad(return_grad) ->
+            # map2pro -> map2xvec), without the Rayleigh continuum (its gradients are not assembled on this route)
+            m2 = BatchedCKThermalModel(eng, st, pr["RADIUS"], pr["ID"], pr["ISO"], list(range(2, S + 2)),
+                                       layering_args=dict(NLAY=L, LAYINT=1, NINT=101), IRAY=0)
+            m2.jacobian_analytic()
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                ya, ka = m2.jacobian_analytic()
+                ts.append(time.perf_counter() - t0)
+            jac["analytic_route"] = {"what": "YN, KK (NY x NX) of the same state vector by analytic gradients, host arrays out "
+                                             "(dSPECOUT 80 MB crosses PCIe once)", "wall_s": sorted(ts)[1], "kk_shape": list(ka.shape)}
 
     if rank != 0:
         if use_dist:

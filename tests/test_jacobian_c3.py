@@ -150,6 +150,65 @@ def test_c3_numerical_jacobian_vs_oracle(oracle, pointing, f32):
     assert np.max(np.abs(KK - kk) / scale) < 1e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pointing", ["nadir", "limb"])
+def test_c3_analytic_jacobian_vs_small_step_differences(pointing):
+    """The nemesisfmg route at the state-vector level (layer_averageg -> CIRSrad(return_grad) -> map2pro -> map2xvec)
+    against central differences with a small step.  ln(VMR) columns: differences through the full batched forward route
+    (layer_average included).  Temperature columns: like the reference's, the analytic gradient is first order in DTE at
+    fixed layer amounts, so the differences move the layer temperatures along the DTE column and keep the amounts."""
+    import archnemesis_dist_amd as pkg
+    from archnemesis_dist_amd import synthetic as syn, layering
+    from archnemesis_dist_amd.profile_state import ContinuousProfileState, BatchedCKThermalModel
+    W, G, NP, NT, S, NPRO, NLAY = 192, 10, 8, 6, 4, 20, 16
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S, seed=78)
+    _, delg = syn.gauss_legendre_01(G)
+    WAVE = 300.0 + 0.5 * np.arange(W)
+    pr = syn.synth_profiles(NPRO, 6, seed=6, p_bottom_bar=5.0, p_top_bar=1.0e-5)
+    st = ContinuousProfileState(pr["H"], pr["P"], pr["T"], pr["VMR"], ["T", ("VMR", 3)])
+    geo = dict(pointing=layering.NADIR, EMISS_ANG=25.0, ANGLE=25.0) if pointing == "nadir" else \
+        dict(pointing=layering.LIMB, BOTLAY=3)
+    eng = pkg.AnsfmEngine(0)
+    try:
+        eng.upload_ktable(K, PRESS, TEMP, WAVE, delg)
+        model = BatchedCKThermalModel(eng, st, pr["RADIUS"], pr["ID"], pr["ISO"], [2, 3, 4, 5],
+                                      layering_args=dict(NLAY=NLAY, LAYINT=1, NINT=101), geometry=geo, IRAY=0)
+        YN, KK = model.jacobian_analytic()
+        y0 = model.spectra_batch(st.XN[None]).cpu().numpy()[0]
+        np.testing.assert_allclose(YN, y0, rtol=1e-12)
+        assert KK.shape == (y0.size, st.NX) and np.all(np.isfinite(KK))
+        # ln VMR columns through the whole forward route
+        lv = (2, 8, 13) if pointing == "nadir" else (8, 11, 14)      # the limb path starts at layer 3
+        cols = [NPRO + i for i in lv]
+        h = 1.0e-4
+        X = np.repeat(st.XN[None], 2 * len(cols), 0)
+        for k, c in enumerate(cols):
+            X[2 * k, c] += h; X[2 * k + 1, c] -= h
+        Y = model.spectra_batch(X).cpu().numpy()
+        for k, c in enumerate(cols):
+            fd = (Y[2 * k] - Y[2 * k + 1]) / (2 * h)
+            assert np.max(np.abs(fd)) > 0 and np.max(np.abs(KK[:, c] - fd)) < 1e-5 * np.max(np.abs(fd)), c     # differences of step 1e-4 / 1e-3: contract 1e-4
+        # temperature columns: the layer temperatures moved along the column of DTE (what the analytic map assumes), the
+        # amounts kept; levels whose layers include the bottom one are left out (the reference's gradient does not carry
+        # the ground term B(T_bottom) of a TSURF <= 0 atmosphere)
+        base = model.layers(st.XN[None]); path = base["path"]
+        DTE = model.last_analytic_layers["DTE"]
+        for c in ((6, 10, 14) if pointing == "nadir" else (8, 11, 14)):
+            assert DTE[0, c] == 0.0 and np.any(DTE[:, c] != 0.0)
+            hT = 1.0e-3
+            ys = []
+            for sg in (1.0, -1.0):
+                T = base["TEMP"][0] + sg * hT * DTE[:, c]
+                em = path.EMTEMP[0] + sg * hT * np.where(np.arange(path.LAYINC.shape[0])[:, None] < path.NLAYIN[None, :],
+                                                         DTE[path.LAYINC, c], 0.0)
+                ys.append(eng.cirsrad_ck_thermal(0, base["PRESS"][0], T, base["amount"][0], None, path.NLAYIN, path.LAYINC,
+                                                 path.SCALE, em, -1.0).reshape(-1))
+            fd = (ys[0] - ys[1]) / (2 * hT)
+            assert np.max(np.abs(fd)) > 0 and np.max(np.abs(KK[:, c] - fd)) < 1e-5 * np.max(np.abs(fd)), c     # differences of step 1e-4 / 1e-3: contract 1e-4
+    finally:
+        eng.close()
+
+
 # ---- multi-GPU plumbing of the other shardable path: one line-by-line model split by wavenumber (SURVEY 8e) ---------------
 def _lbl_case(seed=3, nw=4000, N=900):
     rng = np.random.default_rng(seed)
