@@ -1385,8 +1385,9 @@ int ansfm_cirsradg_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L, c
 {
     CHECK_CTX(ctx);
     if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "cirsradg: upload a k-table first");
-    if (n_models <= 0 || L <= 0 || P <= 0 || LIMAX <= 0 || NPAR <= 0 || !SPECOUT || !dSPECOUT || !dTSURF)
-        FAIL(ANSFM_ERR_INVALID, "cirsradg: bad argument");
+    if (n_models <= 0 || L <= 0 || P <= 0 || LIMAX <= 0 || NPAR <= 0 || !SPECOUT || !dTSURF || (!dSPECOUT && n_models != 1))
+        FAIL(ANSFM_ERR_INVALID, "cirsradg: bad argument (dSPECOUT may be NULL for a single model: the gradients then stay on the "
+                                "device for ansfm_map2pro)");
     HIPCHK(hipSetDevice(ctx->device));
     const int W = ctx->W, S = ctx->S;
     const size_t D = sizeof(double);
@@ -1420,7 +1421,7 @@ int ansfm_cirsradg_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L, c
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(SPECOUT, o_spec, nsp * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(dTSURF, o_dts, nsp * D, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dSPECOUT, ctx->dspec_ref.p, ndsp * D, hipMemcpyDeviceToHost, ctx->stream));
+    if (dSPECOUT) HIPCHK(hipMemcpyAsync(dSPECOUT, ctx->dspec_ref.p, ndsp * D, hipMemcpyDeviceToHost, ctx->stream));
     if (n_models == 1) { ctx->dspec_dims[0] = ctx->W; ctx->dspec_dims[1] = NPAR; ctx->dspec_dims[2] = LIMAX; ctx->dspec_dims[3] = P; }
     return check_unsorted(ctx);
 }

@@ -345,9 +345,10 @@ class AnsfmEngine:
         return (spec[0], dspec[0]) if single else (spec, dspec)
 
     def cirsradg_ck_thermal(self, ISPACE, lay_press_pa, lay_temp, amount, taucont, dtaucon, NVMR, NPAR, igas_map,
-                            NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None, xfac=None):
+                            NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None, xfac=None, gradients_on_device=False):
         """CIRSrad(return_grad=True): returns SPECOUT (n,W,P), dSPECOUT (n,W,NPAR,LIMAX,P), dTSURF (n,W,P)
-        (leading axis dropped for a single model)."""
+        (leading axis dropped for a single model).  gradients_on_device (single model): dSPECOUT is not copied to the host
+        (None is returned in its place); `map2pro(None, ...)` takes it from the device."""
         W, G, NP, NT, S = self.dims
         lay_press_pa = _np(lay_press_pa)
         single = lay_press_pa.ndim == 1
@@ -364,13 +365,18 @@ class AnsfmEngine:
         ET = _np(np.broadcast_to(_np(EMTEMP).reshape(-1, LIMAX, P), (n, LIMAX, P)))
         TS = _np(np.broadcast_to(np.atleast_1d(_np(TSURF)), (n,)))
         ig = _np(igas_map, np.int32)
-        spec = np.empty((n, W, P)); dspec = np.empty((n, W, NPAR, LIMAX, P)); dts = np.empty((n, W, P))
+        on_dev = bool(gradients_on_device) and n == 1
+        spec = np.empty((n, W, P)); dts = np.empty((n, W, P))
+        dspec = None if on_dev else np.empty((n, W, NPAR, LIMAX, P))
         rc = self._lib.ansfm_cirsradg_ck_thermal(
             self._ctx, int(ISPACE), n, L, _ptr(lp), _ptr(lt), _ptr(am), _ptr(tc), _ptr(dtc), int(NVMR), int(NPAR),
             _ptr(ig), P, LIMAX, _ptr(NLAYIN), _ptr(LAYINC), _ptr(SC), _ptr(ET), _ptr(TS), _ptr(_np(EMISSIVITY)),
             _ptr(_np(xfac)), _ptr(spec), _ptr(dspec), _ptr(dts))
         self._check(rc, "cirsradg_ck_thermal")
         self._chain_dspec = None
+        if on_dev:
+            self._chain_dspec = ("device", W, int(NPAR), LIMAX, P)
+            return (spec[0], None, dts[0]) if single else (spec, None, dts)
         if n == 1:                       # device copy usable by map2pro: hand the host array out read-only
             dspec.flags.writeable = False
             self._chain_dspec = _fingerprint(dspec[0])
@@ -495,12 +501,21 @@ class AnsfmEngine:
             self._check(self._lib.ansfm_layer_average(*args), "layer_average")
         return tuple(a[0] for a in out) if single else out
 
-    def map2pro(self, dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NLAYIN, LAYINC, DTE, DAM, DCO, INCPAR=(-1,)):
+    def map2pro(self, dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NLAYIN, LAYINC, DTE, DAM, DCO, INCPAR=(-1,), to_host=True):
         """ForwardModel_0.map2pro (:5319), same arguments -> dSPECOUT (NWAVE, NVMR+2+NDUST, NPRO, NPATH).
         When dSPECIN is the very array the last cirsradg_ck_thermal call returned, its device copy is used
-        (no host->device transfer); the result stays on the device for a following map2xvec."""
-        dSPECIN = _np(dSPECIN)
-        W, NPAR, LIMAX, P = dSPECIN.shape
+        (no host->device transfer); the result stays on the device for a following map2xvec.  dSPECIN = None: the
+        gradients a `cirsradg_ck_thermal(..., gradients_on_device=True)` call left on the device.  to_host = False: the
+        result is not copied back either (None is returned; `map2xvec(None, ...)` continues from the device)."""
+        dev_in = dSPECIN is None
+        if dev_in:
+            ch = getattr(self, "_chain_dspec", None)
+            if not (isinstance(ch, tuple) and ch[0] == "device"):
+                raise ValueError("map2pro: no device-resident cirsradg result (gradients_on_device=True) to continue from")
+            W, NPAR, LIMAX, P = ch[1:]
+        else:
+            dSPECIN = _np(dSPECIN)
+            W, NPAR, LIMAX, P = dSPECIN.shape
         if W != NWAVE or NPAR != NVMR + 2 + NDUST or P != NPATH:
             raise ValueError("map2pro: dSPECIN must be (NWAVE, NVMR+2+NDUST, NLAYIN, NPATH)")
         LAYINC = _np(LAYINC, np.int32)
@@ -514,25 +529,35 @@ class AnsfmEngine:
         inc = None if INCPAR[0] == -1 else _np(list(INCPAR), np.int32)
         if inc is not None and inc[0] > NVMR + NDUST:
             raise UnboundLocalError("local variable 'dSPECOUT1' referenced before assignment")   # as the reference
-        out = np.empty((W, NPAR, NPRO, P))
-        chained = getattr(self, "_chain_dspec", None) is not None and self._chain_dspec == _fingerprint(dSPECIN)
+        out = np.empty((W, NPAR, NPRO, P)) if to_host else None
+        chained = dev_in or (getattr(self, "_chain_dspec", None) is not None and self._chain_dspec == _fingerprint(dSPECIN))
         rc = self._lib.ansfm_map2pro(self._ctx, W, NPAR, LIMAX, P, int(NPRO), NLAY, int(NVMR), int(NDUST),
                                      None if chained else _ptr(dSPECIN), _ptr(LAYINC), _ptr(DTE), _ptr(DAM), _ptr(DCO),
                                      0 if inc is None else len(inc), _ptr(inc), _ptr(out))
         self._check(rc, "map2pro")
+        if out is None:
+            self._chain_map = ("device", W, NPAR, int(NPRO), P)
+            return None
         out.flags.writeable = False      # its device twin feeds map2xvec
         self._chain_map = _fingerprint(out)
         return out
 
     def map2xvec(self, dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NX, xmap):
-        """ForwardModel_0.map2xvec (:5387), same arguments -> dSPECOUT (NWAVE, NPATH, NX)."""
-        dSPECIN = _np(dSPECIN)
-        W, NPAR, NPROi, P = dSPECIN.shape
+        """ForwardModel_0.map2xvec (:5387), same arguments -> dSPECOUT (NWAVE, NPATH, NX).  dSPECIN = None: the result a
+        `map2pro(..., to_host=False)` call left on the device."""
+        if dSPECIN is None:
+            ch = getattr(self, "_chain_map", None)
+            if not (isinstance(ch, tuple) and ch[0] == "device"):
+                raise ValueError("map2xvec: no device-resident map2pro result (to_host=False) to continue from")
+            W, NPAR, NPROi, P = ch[1:]
+        else:
+            dSPECIN = _np(dSPECIN)
+            W, NPAR, NPROi, P = dSPECIN.shape
         xmap = _np(xmap)
         if xmap.shape != (NX, NPAR, NPROi):
             raise ValueError("shape-mismatch for sum")     # np.tensordot's message
         out = np.empty((W, P, NX))
-        chained = getattr(self, "_chain_map", None) is not None and self._chain_map == _fingerprint(dSPECIN)
+        chained = dSPECIN is None or (getattr(self, "_chain_map", None) is not None and self._chain_map == _fingerprint(dSPECIN))
         rc = self._lib.ansfm_map2xvec(self._ctx, W, NPAR, NPROi, P, int(NX), None if chained else _ptr(dSPECIN),
                                       _ptr(xmap), _ptr(out))
         self._check(rc, "map2xvec")

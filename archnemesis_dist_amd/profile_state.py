@@ -186,10 +186,13 @@ class BatchedCKThermalModel:
         NDUST = lay["CONT"].shape[1]
         NPAR = NVMR + 2 + NDUST
         P_ = path.NPATH
-        spec, dspec, _ = eng.cirsradg_ck_thermal(self.ISPACE, lay["PRESS"], lay["TEMP"], amount, self.extra, None, NVMR, NPAR,
-                                                 self.igas_map.astype(np.int32), path.NLAYIN, path.LAYINC, path.SCALE,
-                                                 path.EMTEMP, self.TSURF)
-        pro = eng.map2pro(dspec, self.W, NVMR, NDUST, NPRO, P_, path.NLAYIN, path.LAYINC, lay["DTE"], lay["DAM"], lay["DCO"])
+        # the layer-level and the level-level gradients (80 MB each at C3) stay on the device: only KK comes back
+        spec, _, _ = eng.cirsradg_ck_thermal(self.ISPACE, lay["PRESS"], lay["TEMP"], amount, self.extra, None, NVMR, NPAR,
+                                             self.igas_map.astype(np.int32), path.NLAYIN, path.LAYINC, path.SCALE,
+                                             path.EMTEMP, self.TSURF, gradients_on_device=True)
+        eng.map2pro(None, self.W, NVMR, NDUST, NPRO, P_, path.NLAYIN, path.LAYINC, lay["DTE"], lay["DAM"], lay["DCO"],
+                    to_host=False)
+        pro = None
         xmap = np.zeros((st.NX, NPAR, NPRO))
         lev = np.arange(NPRO)
         for b, (kind, j) in enumerate(st.blocks):

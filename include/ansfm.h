@@ -244,7 +244,8 @@ int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *d
  *   dtaucon[n][W][NPAR][L]  dTAUCON of calculate_layer_opacity (:3916-3981) or NULL
  *   NVMR, NPAR = NVMR+2+NDUST; igas_map[S] (HOST int32) = AtmosphereX.locate_gas(ID[i],ISO[i])
  *   SPECOUT[n][W][P], dSPECOUT[n][W][NPAR][LIMAX][P], dTSURF[n][W][P]
- * The reference's O(NPAR*Li^2) recursion is evaluated as one backward sweep. */
+ * The reference's O(NPAR*Li^2) recursion is evaluated as one backward sweep.  * dSPECOUT may be NULL for n_models = 1: the gradients then stay on the device (no 8 W NPAR LIMAX P byte copy) for
+ * ansfm_map2pro(dSPECIN = NULL); likewise ansfm_map2pro(dSPECOUT = NULL) keeps its result for ansfm_map2xvec(dSPECIN = NULL). */
 int ansfm_cirsradg_ck_thermal(ansfm_ctx *ctx, int ISPACE, int n_models, int L,
                               const double *lay_press_pa, const double *lay_temp,
                               const double *amount, const double *taucont, const double *dtaucon,
