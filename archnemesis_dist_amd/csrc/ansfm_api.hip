@@ -57,6 +57,7 @@ struct ansfm_ctx {
     int monotone = 0;
     std::vector<double> h_wave, h_press, h_temp;   // host copies of the grids of the table in HBM
     int force_generic = 0;   // rerun of a call whose k-distributions turned out not to be sorted in g
+    unsigned grad_gas_mask = 0xFFFFFFFFu;   // ansfm_set_gradient_gases: gases whose amount gradients cirsradg computes
     int rt_mode = 0;         // 1: the next cirsrad_ck_thermal call returns the path transmission (ansfm_cirsrad_ck_transmission)
     int merge_keys = 64;     // 32: run the forward merge on k_ck_overlap32's float32 keys (ansfm_set_merge_keys)
     bool have_table = false;
@@ -165,6 +166,13 @@ int ansfm_set_stream(ansfm_ctx *ctx, void *hip_stream)
 {
     CHECK_CTX(ctx);
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ANSFM_OK;
+}
+
+int ansfm_set_gradient_gases(ansfm_ctx *ctx, unsigned int mask)
+{
+    CHECK_CTX(ctx);
+    ctx->grad_gas_mask = mask;
     return ANSFM_OK;
 }
 
@@ -1225,6 +1233,7 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     }
     pg.dkin = dkin;
     pg.dk = dk;
+    pg.gas_mask = from_k ? 0xFFFFFFFFu : ctx->grad_gas_mask;      // the array-level seam returns every slot
     const int NP1 = S + 1;
     if (NP1 > 21) FAIL(ANSFM_ERR_UNSUPPORTED, "gradient path supports at most 20 spectroscopic gases");
     // fast path: every k(g) non-decreasing (tables: checked at upload; array-level seam: in the kernel, rerun otherwise)
@@ -1343,10 +1352,11 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
     q.dspec = ctx->dspec_i.as<double>();
     q.dtsurf = dTSURF;
     q.NPAR = NPAR; q.NVMR = NVMR; q.NP1 = NP1;
+    q.gas_mask = ctx->is_lbl ? 0xFFFFFFFFu : ctx->grad_gas_mask;
     for (int k = 0; k < kMaxPar; ++k) q.slot_of_param[k] = -1;
     for (int i = 0; i < S; ++i) {   // assignment order of :3868-3870: a later gas overwrites an earlier one
         if (igas_map_host[i] < 0 || igas_map_host[i] >= NPAR) FAIL(ANSFM_ERR_INVALID, "cirsradg: igas_map out of range");
-        q.slot_of_param[igas_map_host[i]] = (signed char)i;
+        q.slot_of_param[igas_map_host[i]] = ((q.gas_mask >> i) & 1u) ? (signed char)i : (signed char)-1;
     }
     q.slot_of_param[NVMR] = (signed char)S;   // :3872 (written last)
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));

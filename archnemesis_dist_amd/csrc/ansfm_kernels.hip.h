@@ -596,6 +596,9 @@ struct OverlapGParams {
     double *dk;               // out [n][L][S+1][G][Wpad]
     double *gscratch;         // [grid][2 + 2*(S+1) + 1][G][64]   KRB, DTB, Dbuf0, Dbuf1, Asave
     unsigned long long *perm; // [grid][ceil(G*G/4)][64]: four 16-bit step codes per word
+    unsigned gas_mask;        // bit s: the slot of gas s (d tau / d amount_s) is wanted.  A state vector names one or two gases:
+                              // every other gas's slot would cost a replay pass per later merge for nothing (its rows of dk are
+                              // written as zeros).  The temperature slot is always computed.
 };
 
 // from_k (array-level k_overlapg seam) is a run-time flag here: the load phase is a few per cent of the kernel and one
@@ -991,12 +994,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                     tail = grad_replay<true, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
                     grad_resolve<true, true>(G, lane, ig, rec, A, B, tail, DT);
                 }
-                {   // the new gas's slot: k_new[col]
+                if ((pg.gas_mask >> (igas + 1)) & 1u) {   // the new gas's slot: k_new[col]
                     stage_col(KRB);
                     const double tail = grad_replay<true, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
                     grad_resolve<true, false>(G, lane, ig, rec, A, B, tail, Dnew + (size_t)(igas + 1) * GW);
                 }
                 for (int pp = 0; pp <= igas; ++pp) {   // earlier gases: D_old[pp][row]
+                    if (!((pg.gas_mask >> pp) & 1u)) continue;
                     stage_row(Dold + (size_t)pp * GW);
                     const double tail = grad_replay<false, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
                     grad_resolve<false, false>(G, lane, ig, rec, A, B, tail, Dnew + (size_t)pp * GW);
@@ -1020,9 +1024,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         }
         double *dout = pg.dk + (((size_t)m * p.L + l) * NP1) * G * p.Wpad + nu;
         const double *Dc = gs + (cur ? dboff[1] : dboff[0]);
-        for (int pp = 0; pp < NP1; ++pp)
+        for (int pp = 0; pp < NP1; ++pp) {
+            const bool wanted = pp == NP1 - 1 || ((pg.gas_mask >> pp) & 1u);
             for (int g = 0; g < G; ++g)
-                dout[((size_t)pp * G + g) * p.Wpad] = Dc[(size_t)pp * GW + g * kWave + lane];
+                dout[((size_t)pp * G + g) * p.Wpad] = wanted ? Dc[(size_t)pp * GW + g * kWave + lane] : 0.0;
+        }
     }
 }
 
@@ -1489,6 +1495,7 @@ struct RtGParams {
     double *dspec;           // [n][P][NPAR][LIMAX][Wpad]   (internal layout)
     double *dtsurf;          // [n][W][P]
     int NPAR, NVMR, NP1;
+    unsigned gas_mask;                    // as OverlapGParams::gas_mask: the slots of the other gases are zero and not read
     signed char slot_of_param[kMaxPar];   // -1 none, 0..S-1 gas slot (x1e-4), S = temperature slot
 };
 
@@ -1629,6 +1636,7 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
         }
         __syncthreads();   // the previous layer's partial sums have been consumed by every thread
         for (int sidx = 0; sidx < NP1; ++sidx) {
+            if (sidx != NP1 - 1 && !((q.gas_mask >> sidx) & 1u)) continue;     // slot_of_param points away from it
             double ysum = 0.0;
 #pragma unroll
             for (int k = 0; k < kGPerG; ++k) {

@@ -95,6 +95,12 @@ class AnsfmEngine:
     def synchronize(self):
         self._check(self._lib.ansfm_synchronize(self._ctx), "synchronize")
 
+    def set_gradient_gases(self, gases=None):
+        """Spectroscopic gases (indices into the uploaded table) whose amount gradients `cirsradg_ck_*` computes; None = all
+        (the reference's behaviour).  The others' parameters come back without their gas part.  Sticky."""
+        mask = 0xFFFFFFFF if gases is None else sum(1 << int(g) for g in set(int(g) for g in gases))
+        self._check(self._lib.ansfm_set_gradient_gases(self._ctx, C.c_uint(mask & 0xFFFFFFFF)), "set_gradient_gases")
+
     def set_f32_semantics(self, grid_f32, delg_f32):
         """Reproduce NumPy's float32 arithmetic when Spectroscopy_0.PRESS/TEMP (grid) / DELG are
         float32 arrays, as they are after read_tables on .kta files (see include/ansfm.h)."""

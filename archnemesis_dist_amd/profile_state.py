@@ -186,13 +186,13 @@ class BatchedCKThermalModel:
         NDUST = lay["CONT"].shape[1]
         NPAR = NVMR + 2 + NDUST
         P_ = path.NPATH
-        # the layer-level and the level-level gradients (80 MB each at C3) stay on the device: only KK comes back
-        spec, _, _ = eng.cirsradg_ck_thermal(self.ISPACE, lay["PRESS"], lay["TEMP"], amount, self.extra, None, NVMR, NPAR,
-                                             self.igas_map.astype(np.int32), path.NLAYIN, path.LAYINC, path.SCALE,
-                                             path.EMTEMP, self.TSURF, gradients_on_device=True)
-        eng.map2pro(None, self.W, NVMR, NDUST, NPRO, P_, path.NLAYIN, path.LAYINC, lay["DTE"], lay["DAM"], lay["DCO"],
-                    to_host=False)
-        pro = None
+        # only the gases the state vector names need their amount gradients (the others' rows of xmap are zero)
+        wanted = {j for kind, j in st.blocks if kind == "VMR"}
+        eng.set_gradient_gases([i for i, col in enumerate(self.igas_map) if int(col) in wanted])
+        try:
+            spec = self._analytic_chain(eng, lay, amount, path, NVMR, NPAR, NDUST, NPRO, P_)
+        finally:
+            eng.set_gradient_gases(None)
         xmap = np.zeros((st.NX, NPAR, NPRO))
         lev = np.arange(NPRO)
         for b, (kind, j) in enumerate(st.blocks):
@@ -200,6 +200,16 @@ class BatchedCKThermalModel:
                 xmap[b * NPRO + lev, NVMR, lev] = 1.0
             else:
                 xmap[b * NPRO + lev, j, lev] = VMR[:, j]           # d VMR / d ln VMR
-        xv = eng.map2xvec(pro, self.W, NVMR, NDUST, NPRO, P_, st.NX, xmap)          # (W, P, NX)
+        xv = eng.map2xvec(None, self.W, NVMR, NDUST, NPRO, P_, st.NX, xmap)          # (W, P, NX)
         return spec.reshape(self.W * P_), xv.reshape(self.W * P_, st.NX)
+
+    def _analytic_chain(self, eng, lay, amount, path, NVMR, NPAR, NDUST, NPRO, P_):
+        # the layer-level and the level-level gradients (80 MB each at C3) stay on the device: only KK comes back
+        spec, _, _ = eng.cirsradg_ck_thermal(self.ISPACE, lay["PRESS"], lay["TEMP"], amount, self.extra, None, NVMR, NPAR,
+                                             self.igas_map.astype(np.int32), path.NLAYIN, path.LAYINC, path.SCALE,
+                                             path.EMTEMP, self.TSURF, gradients_on_device=True)
+        eng.map2pro(None, self.W, NVMR, NDUST, NPRO, P_, path.NLAYIN, path.LAYINC, lay["DTE"], lay["DAM"], lay["DCO"],
+                    to_host=False)
+        return spec
+
 

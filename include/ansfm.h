@@ -238,6 +238,13 @@ int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *d
                      const double *k, const double *dkdT, const double *amount, double *tau,
                      double *dk);
 
+/* Which spectroscopic gases' amount gradients the k-table gradient path (ansfm_cirsradg_ck_*) computes: bit s of `mask` for
+ * gas s of the uploaded table (default: all).  The reference always carries every gas through rankg (ForwardModel_0.py:
+ * 5842-6026) and lets map2xvec drop what the state vector does not name; a caller that knows its state vector saves the replay
+ * passes of the other gases (C2: 49 -> 21 passes for one gas).  The parameters of a gas that is switched off come back as the
+ * continuum part only (dTAUCON), i.e. zero without one; the temperature gradient is always computed.  Sticky until changed. */
+int ansfm_set_gradient_gases(ansfm_ctx *ctx, unsigned int mask);
+
 /* CIRSrad(return_grad=True), ILBL=K_TABLES, IMOD=THERMAL_EMISSION (ForwardModel_0.py:4376-4511
  * with :3853-3872 calc_kg/k_overlapg/dTAUGAS, :3993 dTAUTOT, :4012 LAYINC*SCALE, :4233
  * calc_thermal_emission_spectrumg, :4244-4247 xfac, :4504-4508 g-quadrature + nan_to_num).

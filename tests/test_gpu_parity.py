@@ -1302,6 +1302,45 @@ def test_c5_full_size_lbl_properties_and_slab_vs_oracle(eng, oracle):
         np.testing.assert_allclose(full[l, i0:i0 + ns], ref, rtol=1e-9)
 
 
+def test_gradient_gas_selection_leaves_the_selected_gradients_unchanged(eng):
+    """ansfm_set_gradient_gases: with two of four gases selected the temperature and the selected gases' parameters of
+    dSPECOUT are bit-identical to the full computation, the others reduce to their continuum part, SPECOUT is unchanged."""
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(91)
+    W, G, S, L = 200, 10, 4, 14
+    PRESS, TEMP, K = syn.synth_ktable(W, G, 8, 6, S, seed=31)
+    _, delg = syn.gauss_legendre_01(G)
+    eng.upload_ktable(K, PRESS, TEMP, 700.0 + 0.5 * np.arange(W), delg)
+    atm = syn.synth_atmosphere(L, S, seed=4)
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L, 20.0)
+    lp, lt, am = atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0]
+    EMTEMP = lt[LAYINC[:, 0]][:, None]
+    NVMR, NPAR = 6, 9
+    igas_map = np.array([4, 0, 2, 5], dtype=np.int32)
+    dcont = 10.0 ** rng.uniform(-25, -23, (W, NPAR, L))
+    args = (0, lp, lt, am, None, dcont, NVMR, NPAR, igas_map, NLAYIN, LAYINC, SCALE, EMTEMP, 300.0)
+    full = eng.cirsradg_ck_thermal(*args, EMISSIVITY=np.ones(W))
+    try:
+        eng.set_gradient_gases([1, 3])
+        part = eng.cirsradg_ck_thermal(*args, EMISSIVITY=np.ones(W))
+        eng.set_gradient_gases([])
+        none = eng.cirsradg_ck_thermal(*args, EMISSIVITY=np.ones(W))
+    finally:
+        eng.set_gradient_gases(None)
+    again = eng.cirsradg_ck_thermal(*args, EMISSIVITY=np.ones(W))
+    assert np.array_equal(part[0], full[0]) and np.array_equal(part[2], full[2])
+    for par in (igas_map[1], igas_map[3], NVMR):                       # selected gases and temperature
+        assert np.array_equal(part[1][:, par], full[1][:, par])
+    for i in (0, 2):                                                   # switched off: no gas part, the continuum part stays
+        par = igas_map[i]
+        assert not np.array_equal(part[1][:, par], full[1][:, par])
+        assert np.array_equal(part[1][:, par], none[1][:, par])
+    assert np.array_equal(none[1][:, NVMR], full[1][:, NVMR])          # the temperature gradient needs no gas selected
+    for par in (1, 3, 7, 8):                                           # parameters no table gas maps to
+        assert np.array_equal(part[1][:, par], full[1][:, par])
+    assert np.array_equal(again[1], full[1])
+
+
 def test_cirsrad_transmission_vs_oracle(eng, oracle):
     """CIRSrad's pure-transmission branch (calculate_transmission_spectrum :4110-4131): exp(-TAUTOT_PATH) of the same
     opacity assembly, g-quadrature, optional solar-flux factor -- two paths of different length, batch of two states."""
