@@ -137,6 +137,15 @@ class CIRSradGPU:
 
     ansfm_device = 0
     ansfm_keep_side_products = True   # fill LayerX.TAUGAS / TAUTOT like the reference (:3925, :3997)
+    # Opt-in: CIRSrad(return_grad=True) computes the gas-amount gradients only of the gases the last subprofretg() mapped
+    # to the state vector (non-zero xmap rows: what nemesisfmg's own `incpar` keeps for map2pro, :699-702); the other gases'
+    # parameters of dSPECOUT then hold their continuum part only.  dSPECONV is unchanged, the gradient merge is not.
+    ansfm_select_gradient_gases = False
+
+    def subprofretg(self, *a, **k):
+        xmap = super().subprofretg(*a, **k)
+        self._ansfm_xmap = xmap
+        return xmap
 
     # ---- what is supported -----------------------------------------------------------------------
     def _ansfm_supported(self, return_grad):
@@ -418,10 +427,19 @@ class CIRSradGPU:
             NVMR = int(A.NVMR)
             NPAR = NVMR + 2 + int(self.ScatterX.NDUST)
             igas_map = np.array([A.locate_gas(S.ID[i], S.ISO[i]) for i in range(S.NGAS)], dtype=np.int32)
-            SPECOUT, dSPECOUT, dTSURF = eng.cirsradg_ck_thermal(
-                int(self.MeasurementX.ISPACE), np.asarray(L.PRESS, dtype=np.float64),
-                np.asarray(L.TEMP, dtype=np.float64), f_gas, taucont, dTAUCON, NVMR, NPAR, igas_map, NLAYIN, LAYINC,
-                SCALE, EMTEMP, float(self.SurfaceX.TSURF), EMISSIVITY=emissivity, xfac=xfac)
+            xm = getattr(self, "_ansfm_xmap", None) if self.ansfm_select_gradient_gases else None
+            selected = xm is not None and np.ndim(xm) == 3 and np.shape(xm)[1] == NPAR and hasattr(eng, "set_gradient_gases")
+            if selected:
+                used = np.any(np.asarray(xm) != 0.0, axis=(0, 2))
+                eng.set_gradient_gases([i for i in range(S.NGAS) if used[igas_map[i]]])
+            try:
+                SPECOUT, dSPECOUT, dTSURF = eng.cirsradg_ck_thermal(
+                    int(self.MeasurementX.ISPACE), np.asarray(L.PRESS, dtype=np.float64),
+                    np.asarray(L.TEMP, dtype=np.float64), f_gas, taucont, dTAUCON, NVMR, NPAR, igas_map, NLAYIN, LAYINC,
+                    SCALE, EMTEMP, float(self.SurfaceX.TSURF), EMISSIVITY=emissivity, xfac=xfac)
+            finally:
+                if selected:
+                    eng.set_gradient_gases(None)
         else:
             SPECOUT = eng.cirsrad_ck_thermal(
                 int(self.MeasurementX.ISPACE), np.asarray(L.PRESS, dtype=np.float64),

@@ -162,6 +162,10 @@ class OracleEngineDouble:
     def get_taugas(self, L, model=0):
         return self.tg
 
+    def set_gradient_gases(self, gases=None):
+        """recorded only: the double returns every gas's gradient whatever is selected"""
+        self.gas_selections = getattr(self, "gas_selections", []) + [None if gases is None else sorted(gases)]
+
     # ILS convolution family
     def _conv(self, name, *a, **k):
         self.conv_calls = getattr(self, "conv_calls", []) + [name]
@@ -367,7 +371,9 @@ def test_nemesisfmg_through_the_adapter_matches_the_reference(c1_run, oracle, go
     Atm, Meas, Spec, Scat, Stel, Surf, CIA, Lay, Var, Ret = ans.Files.read_input_files("cirstest")
     fm = FMGPU(runname="cirstest", Atmosphere=Atm, Surface=Surf, Measurement=Meas, Spectroscopy=Spec, Stellar=Stel,
                Scatter=Scat, CIA=CIA, Layer=Lay, Variables=Var)
+    fm.ansfm_select_gradient_gases = True        # opt-in: only the gases subprofretg's xmap touches (here: none, T only)
     SPECONV, dSPECONV = fm.nemesisfmg()
+    assert double.gas_selections == [[], None]   # selected for the CIRSrad call, reset afterwards
     z = np.load(os.path.join(golden_dir, "c1_cirsrad_grad.npz"))
     np.testing.assert_allclose(SPECONV, z["SPECONVg"], rtol=1e-10)
     ref = z["dSPECONV"]
