@@ -1358,7 +1358,7 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
         if (igas_map_host[i] < 0 || igas_map_host[i] >= NPAR) FAIL(ANSFM_ERR_INVALID, "cirsradg: igas_map out of range");
         q.slot_of_param[igas_map_host[i]] = ((q.gas_mask >> i) & 1u) ? (signed char)i : (signed char)-1;
     }
-    q.slot_of_param[NVMR] = (signed char)S;   // :3872 (written last)
+    q.slot_of_param[NVMR] = (q.gas_mask >> 31) ? (signed char)S : (signed char)-1;   // :3872 (written last)
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     {
         dim3 grid((unsigned)n_models, (unsigned)P, (unsigned)(Wpad / kWave));

@@ -598,7 +598,7 @@ struct OverlapGParams {
     unsigned long long *perm; // [grid][ceil(G*G/4)][64]: four 16-bit step codes per word
     unsigned gas_mask;        // bit s: the slot of gas s (d tau / d amount_s) is wanted.  A state vector names one or two gases:
                               // every other gas's slot would cost a replay pass per later merge for nothing (its rows of dk are
-                              // written as zeros).  The temperature slot is always computed.
+                              // written as zeros).  Bit 31: the temperature slot (two passes per merge).
 };
 
 // from_k (array-level k_overlapg seam) is a run-time flag here: the load phase is a few per cent of the kernel and one
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 auto stage_col = [&](const double *src) {
                     if constexpr (SORTED) stage_slice(A, src, G, lane); else stage_slice_perm(A, src, PB, G, lane);
                 };
-                {   // temperature slot: D_old[igas+1][row] + dkdT_new[col]*amount, as a row pass plus a column pass
+                if (pg.gas_mask >> 31) {   // temperature slot: D_old[igas+1][row] + dkdT_new[col]*amount, as a row pass plus a column pass
                     double *DT = Dnew + (size_t)(igas + 2) * GW;
                     stage_row(Dold + (size_t)(igas + 1) * GW);
                     double tail = grad_replay<false, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         double *dout = pg.dk + (((size_t)m * p.L + l) * NP1) * G * p.Wpad + nu;
         const double *Dc = gs + (cur ? dboff[1] : dboff[0]);
         for (int pp = 0; pp < NP1; ++pp) {
-            const bool wanted = pp == NP1 - 1 || ((pg.gas_mask >> pp) & 1u);
+            const bool wanted = ((pg.gas_mask >> (pp == NP1 - 1 ? 31 : pp)) & 1u) != 0;
             for (int g = 0; g < G; ++g)
                 dout[((size_t)pp * G + g) * p.Wpad] = wanted ? Dc[(size_t)pp * GW + g * kWave + lane] : 0.0;
         }
@@ -1636,7 +1636,7 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
         }
         __syncthreads();   // the previous layer's partial sums have been consumed by every thread
         for (int sidx = 0; sidx < NP1; ++sidx) {
-            if (sidx != NP1 - 1 && !((q.gas_mask >> sidx) & 1u)) continue;     // slot_of_param points away from it
+            if (!((q.gas_mask >> (sidx == NP1 - 1 ? 31 : sidx)) & 1u)) continue;     // slot_of_param points away from it
             double ysum = 0.0;
 #pragma unroll
             for (int k = 0; k < kGPerG; ++k) {

@@ -95,10 +95,12 @@ class AnsfmEngine:
     def synchronize(self):
         self._check(self._lib.ansfm_synchronize(self._ctx), "synchronize")
 
-    def set_gradient_gases(self, gases=None):
+    def set_gradient_gases(self, gases=None, temperature=True):
         """Spectroscopic gases (indices into the uploaded table) whose amount gradients `cirsradg_ck_*` computes; None = all
-        (the reference's behaviour).  The others' parameters come back without their gas part.  Sticky."""
+        (the reference's behaviour).  The others' parameters come back without their gas part.  temperature=False also
+        leaves out the k-table part of the temperature gradient (a state vector without temperature elements).  Sticky."""
         mask = 0xFFFFFFFF if gases is None else sum(1 << int(g) for g in set(int(g) for g in gases))
+        mask = (mask | 0x80000000) if temperature else (mask & 0x7FFFFFFF)
         self._check(self._lib.ansfm_set_gradient_gases(self._ctx, C.c_uint(mask & 0xFFFFFFFF)), "set_gradient_gases")
 
     def set_f32_semantics(self, grid_f32, delg_f32):

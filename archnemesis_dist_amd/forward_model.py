@@ -431,7 +431,7 @@ class CIRSradGPU:
             selected = xm is not None and np.ndim(xm) == 3 and np.shape(xm)[1] == NPAR and hasattr(eng, "set_gradient_gases")
             if selected:
                 used = np.any(np.asarray(xm) != 0.0, axis=(0, 2))
-                eng.set_gradient_gases([i for i in range(S.NGAS) if used[igas_map[i]]])
+                eng.set_gradient_gases([i for i in range(S.NGAS) if used[igas_map[i]]], temperature=bool(used[NVMR]))
             try:
                 SPECOUT, dSPECOUT, dTSURF = eng.cirsradg_ck_thermal(
                     int(self.MeasurementX.ISPACE), np.asarray(L.PRESS, dtype=np.float64),

@@ -188,7 +188,8 @@ class BatchedCKThermalModel:
         P_ = path.NPATH
         # only the gases the state vector names need their amount gradients (the others' rows of xmap are zero)
         wanted = {j for kind, j in st.blocks if kind == "VMR"}
-        eng.set_gradient_gases([i for i, col in enumerate(self.igas_map) if int(col) in wanted])
+        eng.set_gradient_gases([i for i, col in enumerate(self.igas_map) if int(col) in wanted],
+                               temperature=any(kind == "T" for kind, _ in st.blocks))
         try:
             spec = self._analytic_chain(eng, lay, amount, path, NVMR, NPAR, NDUST, NPRO, P_)
         finally:

@@ -86,12 +86,16 @@ def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, d
     try:
         fg(); fg()
         k3 = eng.last_kernel_ms()
+        eng.set_gradient_gases([0], temperature=False)    # ... and for one gas at fixed temperature
+        fg(); fg()
+        k4 = eng.last_kernel_ms()
     finally:
         eng.set_gradient_gases(None)
     ex["cirsradg_c2"] = {"gpu_ms_whole_call": e0.elapsed_time(e1), "overlapg_kernel_ms_second_reading": k2["overlap_ms"],"what": "CIRSrad(return_grad=True) at C2: k_ck_overlapg + k_thermal_rtg, host arrays in / out "
                                  "(80 MB of dSPECOUT cross PCIe inside wall_s)", "wall_s": t,
                          "overlapg_kernel_ms": k["overlap_ms"], "rtg_kernel_ms": k["rt_ms"],
-                         "overlapg_kernel_ms_one_gas_selected": k3["overlap_ms"]}
+                         "overlapg_kernel_ms_one_gas_selected": k3["overlap_ms"],
+                         "overlapg_kernel_ms_one_gas_no_temperature": k4["overlap_ms"]}
 
     # ---- C4: CIRSrad scattering branch at full size on the C2 table: 1e4 nu x G 20 x 100 layers, 16 streams, NF = 8 ---
     NMU, NF = 16, 8

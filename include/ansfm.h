@@ -242,7 +242,9 @@ int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *d
  * gas s of the uploaded table (default: all).  The reference always carries every gas through rankg (ForwardModel_0.py:
  * 5842-6026) and lets map2xvec drop what the state vector does not name; a caller that knows its state vector saves the replay
  * passes of the other gases (C2: 49 -> 21 passes for one gas).  The parameters of a gas that is switched off come back as the
- * continuum part only (dTAUCON), i.e. zero without one; the temperature gradient is always computed.  Sticky until changed. */
+ * continuum part only (dTAUCON), i.e. zero without one.  Bit 31: the temperature slot of the merge (d tau / dT through the
+ * k-tables, two passes per merge); without it the temperature parameter keeps its continuum and Planck-function parts only.
+ * Sticky until changed. */
 int ansfm_set_gradient_gases(ansfm_ctx *ctx, unsigned int mask);
 
 /* CIRSrad(return_grad=True), ILBL=K_TABLES, IMOD=THERMAL_EMISSION (ForwardModel_0.py:4376-4511

@@ -162,9 +162,9 @@ class OracleEngineDouble:
     def get_taugas(self, L, model=0):
         return self.tg
 
-    def set_gradient_gases(self, gases=None):
+    def set_gradient_gases(self, gases=None, temperature=True):
         """recorded only: the double returns every gas's gradient whatever is selected"""
-        self.gas_selections = getattr(self, "gas_selections", []) + [None if gases is None else sorted(gases)]
+        self.gas_selections = getattr(self, "gas_selections", []) + [None if gases is None else (sorted(gases), temperature)]
 
     # ILS convolution family
     def _conv(self, name, *a, **k):
@@ -373,7 +373,7 @@ def test_nemesisfmg_through_the_adapter_matches_the_reference(c1_run, oracle, go
                Scatter=Scat, CIA=CIA, Layer=Lay, Variables=Var)
     fm.ansfm_select_gradient_gases = True        # opt-in: only the gases subprofretg's xmap touches (here: none, T only)
     SPECONV, dSPECONV = fm.nemesisfmg()
-    assert double.gas_selections == [[], None]   # selected for the CIRSrad call, reset afterwards
+    assert double.gas_selections == [([], True), None]   # no gas, temperature: selected for the CIRSrad call, reset afterwards
     z = np.load(os.path.join(golden_dir, "c1_cirsrad_grad.npz"))
     np.testing.assert_allclose(SPECONV, z["SPECONVg"], rtol=1e-10)
     ref = z["dSPECONV"]

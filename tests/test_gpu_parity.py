@@ -1336,6 +1336,14 @@ def test_gradient_gas_selection_leaves_the_selected_gradients_unchanged(eng):
         assert not np.array_equal(part[1][:, par], full[1][:, par])
         assert np.array_equal(part[1][:, par], none[1][:, par])
     assert np.array_equal(none[1][:, NVMR], full[1][:, NVMR])          # the temperature gradient needs no gas selected
+    try:                                                               # a state vector without temperature elements
+        eng.set_gradient_gases([1, 3], temperature=False)
+        not_t = eng.cirsradg_ck_thermal(*args, EMISSIVITY=np.ones(W))
+    finally:
+        eng.set_gradient_gases(None)
+    for par in (igas_map[1], igas_map[3]):
+        assert np.array_equal(not_t[1][:, par], full[1][:, par])
+    assert not np.array_equal(not_t[1][:, NVMR], full[1][:, NVMR]) and np.array_equal(not_t[0], full[0])
     for par in (1, 3, 7, 8):                                           # parameters no table gas maps to
         assert np.array_equal(part[1][:, par], full[1][:, par])
     assert np.array_equal(again[1], full[1])
