@@ -358,13 +358,16 @@ def main():
 
         run_jac(True)                                   # warm-up: buffers of the batch sizes
         jt_all, rows_all, YN_a, KK_a, _ = run_jac(False)
-        reps = [run_jac(True) for _ in range(3)]        # median of three: a single call varies 0.06 - 0.12 s with the host side
+        reps = []                                       # median of five: the host side of a call (Python, NumPy, copies on a
+        for _ in range(5):                              # shared box) varies 0.057 - 0.08 s while its kernels take the same 47 ms
+            reps.append(run_jac(True))
+            reps[-1] = reps[-1][:2] + ((None, None) if len(reps) < 5 else reps[-1][2:4]) + reps[-1][4:]   # keep one KK only
         jts = sorted(r[0] for r in reps)
-        jt, rows, YN_j, KK_j = jts[1], reps[-1][1], reps[-1][2], reps[-1][3]
+        jt, rows, YN_j, KK_j = jts[2], reps[-1][1], reps[-1][2], reps[-1][3]
         eng.set_layer_dedup(True)
         jac = {"forward_models": st.NX + 1, "state_vector": f"T and ln(VMR) of one absorber at {npro} levels (NX = {st.NX}), "
                "through layer_average (Curtis-Godson, NINT 101) and the Rayleigh continuum",
-               "wall_s": jt, "wall_s_three_calls": jts, "merge_kernel_ms_rank0": reps[-1][4]["overlap_ms"],
+               "wall_s": jt, "wall_s_five_calls": jts, "merge_kernel_ms_rank0": reps[-1][4]["overlap_ms"],
                "rt_kernel_ms_rank0": reps[-1][4]["rt_ms"], "fm_per_s": (st.NX + 1) / jt, "wall_s_all_layers": jt_all,
                "layer_opacities_computed_rank0": int(rows[0]), "layer_opacities_all_rank0": int(rows_all[0]),
                "dedup_bit_identical": bool(np.array_equal(KK_a, KK_j) and np.array_equal(YN_a, YN_j)),
