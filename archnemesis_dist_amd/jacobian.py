@@ -87,7 +87,7 @@ def finite_difference_jacobian_dev(allY, XN, inum, FIX=None):
     return host[0].copy(), KK
 
 
-def jacobian_nemesis_batched(model, rank=0, world_size=1, group=None, force_collective=False):
+def jacobian_nemesis_batched(model, rank=0, world_size=1, group=None, force_collective=False, analytical_gradient=False):
     """jacobian_nemesis (ForwardModel_0.py:2184-2361, numerical part) with every forward model of a rank in ONE batched
     call.  `model` offers the state (`model.state`: XN, NX, NUM, FIX, calc_DSTEP()) and `spectra_batch(X (n, NX)) ->
     torch (n, NY)` on its GPU (profile_state.BatchedCKThermalModel).
@@ -96,7 +96,13 @@ def jacobian_nemesis_batched(model, rank=0, world_size=1, group=None, force_coll
     chunk does not start with the unperturbed state puts it in front of its batch all the same: the engine shares every
     layer that is bit-identical to the FIRST state of a batch, and every perturbed state is one step away from the
     unperturbed one, not from its neighbour.  One all_gather of the (nfm_local, NY) blocks (RCCL over xGMI when the
-    backend is nccl), then KK on the device and a single copy to the host."""
+    backend is nccl), then KK on the device and a single copy to the host.
+
+    analytical_gradient=True (jacobian_nemesis's own switch, :2262-2289): one forward model with analytic gradients
+    (`model.jacobian_analytic`, the nemesisfmg route) instead of nfm forward models.  There is nothing to shard: every
+    rank computes the same (YN, KK)."""
+    if analytical_gradient:
+        return model.jacobian_analytic()
     V = model.state
     V.calc_DSTEP()
     XN = np.array(V.XN, dtype=float)
@@ -130,7 +136,8 @@ def jacobian_nemesis_sharded(fm, rank=0, world_size=1, device=None, analytical_g
     analytical_gradient=True defers to the reference's own jacobian_nemesis (nemesisfmg path)."""
     import torch
     if hasattr(fm, "spectra_batch"):                # a batched model: one call per rank instead of one per column
-        return jacobian_nemesis_batched(fm, rank=rank, world_size=world_size, group=group)
+        return jacobian_nemesis_batched(fm, rank=rank, world_size=world_size, group=group,
+                                        analytical_gradient=analytical_gradient and hasattr(fm, "jacobian_analytic"))
     V, M = fm.Variables, fm.Measurement
     if analytical_gradient:
         return fm.jacobian_nemesis(analytical_gradient=True, **flags)

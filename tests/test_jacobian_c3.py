@@ -173,7 +173,8 @@ def test_c3_analytic_jacobian_vs_small_step_differences(pointing):
         eng.upload_ktable(K, PRESS, TEMP, WAVE, delg)
         model = BatchedCKThermalModel(eng, st, pr["RADIUS"], pr["ID"], pr["ISO"], [2, 3, 4, 5],
                                       layering_args=dict(NLAY=NLAY, LAYINT=1, NINT=101), geometry=geo, IRAY=0)
-        YN, KK = model.jacobian_analytic()
+        from archnemesis_dist_amd.jacobian import jacobian_nemesis_sharded
+        YN, KK = jacobian_nemesis_sharded(model, analytical_gradient=True)       # -> model.jacobian_analytic()
         y0 = model.spectra_batch(st.XN[None]).cpu().numpy()[0]
         np.testing.assert_allclose(YN, y0, rtol=1e-12)
         assert KK.shape == (y0.size, st.NX) and np.all(np.isfinite(KK))
