@@ -164,11 +164,9 @@ class BatchedCKThermalModel:
         columns are first order in DTE at fixed amounts (a level temperature enters through the layer temperatures as
         `layer_averageg` linearises them, not through the number density) and, for TSURF <= 0, leave out the ground term's
         dependence on the bottom layer's temperature (calc_thermal_emission_spectrumg :6484-6494 differentiates it with
-        respect to TSURF only) -- a finite difference through `layer_average` sees both.
-        Continuum gradients are not assembled here: IRAY must be 0."""
-        if self.IRAY != 0:
-            raise NotImplementedError("jacobian_analytic: Rayleigh continuum gradients (dTAURAY) are not assembled; use IRAY = 0 "
-                                      "or the finite-difference route")
+        respect to TSURF only) -- a finite difference through `layer_average` sees both.  The Rayleigh continuum enters the
+        gradients the reference's way (calculate_layer_opacity :3952-3957: dTAURAY, the cross section per unit column, is
+        added to EVERY gas's parameter; its dependence on the composition, IRAY = 4, is not differentiated)."""
         eng, st, la, ge = self.eng, self.state, self.lay, self.geo
         X0 = st.XN if X0 is None else np.asarray(X0, float)
         T, VMR = st.profiles(X0[None])
@@ -186,6 +184,14 @@ class BatchedCKThermalModel:
         NDUST = lay["CONT"].shape[1]
         NPAR = NVMR + 2 + NDUST
         P_ = path.NPATH
+        cont, dcont = self.extra, None
+        if self.IRAY != 0:
+            tauray, dtauray = eng.calc_tau_rayleigh(self.IRAY, self.ISPACE, eng.WAVE, lay["TOTAM"], ID=self.ID, ISO=self.ISO,
+                                                    VMR=lay["PP"] / lay["PRESS"][:, None])
+            cont = tauray if cont is None else cont + tauray
+            dcont = np.zeros((self.W, NPAR, tauray.shape[1]))
+            dcont[:, :NVMR, :] = dtauray[:, None, :]
+        lay["_cont"], lay["_dcont"] = cont, dcont
         # only the gases the state vector names need their amount gradients (the others' rows of xmap are zero)
         wanted = {j for kind, j in st.blocks if kind == "VMR"}
         eng.set_gradient_gases([i for i, col in enumerate(self.igas_map) if int(col) in wanted],
@@ -206,7 +212,7 @@ class BatchedCKThermalModel:
 
     def _analytic_chain(self, eng, lay, amount, path, NVMR, NPAR, NDUST, NPRO, P_):
         # the layer-level and the level-level gradients (80 MB each at C3) stay on the device: only KK comes back
-        spec, _, _ = eng.cirsradg_ck_thermal(self.ISPACE, lay["PRESS"], lay["TEMP"], amount, self.extra, None, NVMR, NPAR,
+        spec, _, _ = eng.cirsradg_ck_thermal(self.ISPACE, lay["PRESS"], lay["TEMP"], amount, lay["_cont"], lay["_dcont"], NVMR, NPAR,
                                              self.igas_map.astype(np.int32), path.NLAYIN, path.LAYINC, path.SCALE,
                                              path.EMTEMP, self.TSURF, gradients_on_device=True)
         eng.map2pro(None, self.W, NVMR, NDUST, NPRO, P_, path.NLAYIN, path.LAYINC, lay["DTE"], lay["DAM"], lay["DCO"],

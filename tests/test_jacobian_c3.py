@@ -210,6 +210,53 @@ def test_c3_analytic_jacobian_vs_small_step_differences(pointing):
         eng.close()
 
 
+@pytest.mark.gpu
+def test_c3_analytic_jacobian_vs_oracle_chain(oracle):
+    """The same route with the Rayleigh continuum (IRAY = 4) against the oracle's restatement of every step:
+    layer_averageg, calc_tau_rayleigh, CIRSrad(return_grad) with dTAURAY added to every gas parameter (:3952-3957),
+    map2pro, map2xvec.  Two gases and temperature in the state vector: the gradient merge runs with those two selected."""
+    import archnemesis_dist_amd as pkg
+    from archnemesis_dist_amd import synthetic as syn, layering
+    from archnemesis_dist_amd.profile_state import ContinuousProfileState, BatchedCKThermalModel
+    W, G, NP, NT, S, NPRO, NLAY = 160, 10, 8, 6, 4, 18, 14
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S, seed=79)
+    _, delg = syn.gauss_legendre_01(G)
+    WAVE = 400.0 + 0.5 * np.arange(W)
+    pr = syn.synth_profiles(NPRO, 6, seed=7, p_bottom_bar=5.0, p_top_bar=1.0e-5)
+    st = ContinuousProfileState(pr["H"], pr["P"], pr["T"], pr["VMR"], [("VMR", 5), "T", ("VMR", 2)])
+    igas = [2, 3, 4, 5]
+    eng = pkg.AnsfmEngine(0)
+    try:
+        eng.upload_ktable(K, PRESS, TEMP, WAVE, delg)
+        model = BatchedCKThermalModel(eng, st, pr["RADIUS"], pr["ID"], pr["ISO"], igas, layering_args=dict(NLAY=NLAY, LAYINT=1, NINT=101),
+                                      geometry=dict(pointing=layering.NADIR, EMISS_ANG=15.0, ANGLE=15.0), IRAY=4)
+        YN, KK = model.jacobian_analytic()
+        BASEH, BASEP = model.BASEH, model.BASEP
+    finally:
+        eng.close()
+    names = ("HEIGHT", "PRESS", "TEMP", "TOTAM", "AMOUNT", "PP", "CONT", "FRAC", "DELH", "BASET", "LAYSF", "DTE", "DAM", "DCO", "DPH")
+    lay = dict(zip(names, oracle.layer_averageg(pr["RADIUS"], st.H, st.P, st.T, pr["ID"], st.VMR, None, None, BASEH, BASEP, LAYINT=1,
+                                                NINT=101)))
+    path = layering.calc_path(pr["RADIUS"], BASEH, lay["DELH"], lay["TEMP"], float(st.H[-1]), pointing=layering.NADIR,
+                              EMISS_ANG=15.0, ANGLE=15.0)
+    NVMR = st.VMR.shape[1]; NPAR = NVMR + 2
+    tauray, dtauray = oracle.calc_tau_rayleigh(4, 0, WAVE, lay["TOTAM"], pr["ID"], pr["ISO"], lay["PP"] / lay["PRESS"][:, None])
+    dcont = np.zeros((W, NPAR, NLAY)); dcont[:, :NVMR, :] = dtauray[:, None, :]
+    amount = np.ascontiguousarray(lay["AMOUNT"][:, igas].T) * 1.0e-4
+    spec, dspec, _ = oracle.cirsradg_ck_thermal(0, K, PRESS, TEMP, WAVE, delg, lay["PRESS"], lay["TEMP"], amount, tauray, dcont, NVMR,
+                                                NPAR, np.array(igas, dtype=np.int32), path.NLAYIN, path.LAYINC, path.SCALE, path.EMTEMP,
+                                                -1.0)
+    pro = oracle.map2pro(dspec, W, NVMR, 0, NPRO, 1, path.NLAYIN, path.LAYINC, lay["DTE"], lay["DAM"], lay["DCO"])
+    xmap = np.zeros((st.NX, NPAR, NPRO)); lev = np.arange(NPRO)
+    xmap[lev, 5, lev] = st.VMR[:, 5]; xmap[NPRO + lev, NVMR, lev] = 1.0; xmap[2 * NPRO + lev, 2, lev] = st.VMR[:, 2]
+    kk = oracle.map2xvec(pro, W, NVMR, 0, NPRO, 1, st.NX, xmap).reshape(W, st.NX)
+    np.testing.assert_allclose(YN, spec.reshape(-1), rtol=1e-10)
+    scale = np.max(np.abs(kk), axis=0); scale = np.maximum(scale, 1e-9 * scale.max())
+    # thin top layers: (trold - tr) with tr = trold * exp(-tau) cancels, a 1-ulp difference between the two exp() shows up as
+    # ~1e-7 of the column maximum in the (tiny) gradient entries there (as in the C1 drop-in test); contract 1e-4
+    assert np.max(np.abs(KK - kk) / scale) < 1e-6
+
+
 # ---- multi-GPU plumbing of the other shardable path: one line-by-line model split by wavenumber (SURVEY 8e) ---------------
 def _lbl_case(seed=3, nw=4000, N=900):
     rng = np.random.default_rng(seed)
