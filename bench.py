@@ -375,9 +375,8 @@ def main():
                "collective": "all_gather_into_tensor (RCCL)" if use_dist else None}
         if rank == 0 and world == 1:
             # the same state vector by analytic gradients (nemesisfmg's route: layer_averageg -> CIRSrad(return_grad) ->
-            # map2pro -> map2xvec), here without the Rayleigh continuum
-            m2 = BatchedCKThermalModel(eng, st, pr["RADIUS"], pr["ID"], pr["ISO"], list(range(2, S + 2)),
-                                       layering_args=dict(NLAY=L, LAYINT=1, NINT=101), IRAY=0)
+            # map2pro -> map2xvec; jacobian_nemesis(analytical_gradient=True))
+            m2 = model
             m2.jacobian_analytic()
             ts = []
             for _ in range(3):
