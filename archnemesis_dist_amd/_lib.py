@@ -26,7 +26,7 @@ EXPORTS = [
     "ansfm_k_overlapg", "ansfm_cirsradg_ck_thermal", "ansfm_cirsradg_ck_thermal_dev", "ansfm_scloud11wave_core", "ansfm_upload_lbltable", "ansfm_calc_klbl", "ansfm_add_line_set_monochromatic_absorption", "ansfm_layer_average",
     "ansfm_map2pro", "ansfm_map2xvec", "ansfm_layer_averageg", "ansfm_lblconv", "ansfm_lblconv_fil", "ansfm_lblconv_ngeom", "ansfm_lblconv_fil_ngeom", "ansfm_conv_fil", "ansfm_integrate_filter", "ansfm_calc_tau_rayleigh", "ansfm_calc_tau_dust", "ansfm_set_layer_dedup", "ansfm_last_layer_rows",
     "ansfm_ktable_file_header", "ansfm_upload_ktable_files", "ansfm_ktable_grids", "ansfm_lbltable_file_header",
-    "ansfm_upload_lbltable_files", "ansfm_kdist_bins", "ansfm_calc_tau_cia", "ansfm_set_merge_keys", "ansfm_merge_redo_count", "ansfm_calc_tau_rayleigh_batch_dev", "ansfm_cirsrad_ck_scatter", "ansfm_thermal_emission_g", "ansfm_cirsrad_ck_transmission", "ansfm_cirsradg_ck_transmission", "ansfm_set_gradient_gases", "ansfm_singlescatt_plane_spectrum",
+    "ansfm_upload_lbltable_files", "ansfm_kdist_bins", "ansfm_calc_tau_cia", "ansfm_set_merge_keys", "ansfm_merge_redo_count", "ansfm_calc_tau_rayleigh_batch_dev", "ansfm_cirsrad_ck_scatter", "ansfm_thermal_emission_g", "ansfm_cirsrad_ck_transmission", "ansfm_cirsradg_ck_transmission", "ansfm_set_gradient_gases", "ansfm_set_shared_gas_gradient", "ansfm_singlescatt_plane_spectrum",
     "ansfm_cirsrad_ck_singlescatt",
 ]
 
@@ -129,6 +129,7 @@ def load():
     lib.ansfm_cirsrad_ck_thermal_dev.argtypes = cirs
     lib.ansfm_cirsrad_ck_transmission.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp]
     lib.ansfm_set_gradient_gases.argtypes = [vp, C.c_uint]
+    lib.ansfm_set_shared_gas_gradient.argtypes = [vp, ci, vp]
     lib.ansfm_cirsradg_ck_transmission.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp]
     lib.ansfm_singlescatt_plane_spectrum.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, cd, vp, vp, vp, cd, cd, vp]
     lib.ansfm_cirsrad_ck_singlescatt.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, cd, vp, vp, vp, vp, vp, vp, vp]

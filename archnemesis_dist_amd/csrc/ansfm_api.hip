@@ -57,6 +57,8 @@ struct ansfm_ctx {
     int monotone = 0;
     std::vector<double> h_wave, h_press, h_temp;   // host copies of the grids of the table in HBM
     int force_generic = 0;   // rerun of a call whose k-distributions turned out not to be sorted in g
+    DevBuf dcont_gas;                       // ansfm_set_shared_gas_gradient: [L][Wpad], consumed by the next cirsradg call
+    int dcont_gas_L = 0;                    // 0: none pending
     unsigned grad_gas_mask = 0xFFFFFFFFu;   // ansfm_set_gradient_gases: gases whose amount gradients cirsradg computes
     int rt_mode = 0;         // 1: the next cirsrad_ck_thermal call returns the path transmission (ansfm_cirsrad_ck_transmission)
     int merge_keys = 64;     // 32: run the forward merge on k_ck_overlap32's float32 keys (ansfm_set_merge_keys)
@@ -149,7 +151,7 @@ void ansfm_destroy(ansfm_ctx *ctx)
     DevBuf *bufs[] = {&ctx->lnK, &ctx->d_press, &ctx->d_temp, &ctx->d_wave, &ctx->d_delg, &ctx->d_flag,
                       &ctx->li, &ctx->tau, &ctx->scratch, &ctx->cont_t, &ctx->tmp_in, &ctx->tmp_out,
                       &ctx->misc, &ctx->gscratch, &ctx->dkbuf, &ctx->trold_ws, &ctx->dspec_i, &ctx->dcont_t,
-                      &ctx->tmp_in2, &ctx->tmp_out2, &ctx->lbl_li, &ctx->ms_taus, &ctx->ms_omegas, &ctx->ms_bnu};
+                      &ctx->tmp_in2, &ctx->tmp_out2, &ctx->lbl_li, &ctx->ms_taus, &ctx->ms_omegas, &ctx->ms_bnu, &ctx->dcont_gas};
     for (auto *b : bufs) b->release();
     for (auto &b : ctx->hb) b.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1282,6 +1284,25 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     return ANSFM_OK;
 }
 
+int ansfm_set_shared_gas_gradient(ansfm_ctx *ctx, int L, const double *dTAU_WL)
+{
+    CHECK_CTX(ctx);
+    ctx->dcont_gas_L = 0;
+    if (!dTAU_WL) return ANSFM_OK;
+    if (!ctx->have_table || L <= 0) FAIL(ANSFM_ERR_INVALID, "set_shared_gas_gradient: upload a table first; L > 0");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int W = ctx->W, Wpad = ctx->Wpad;
+    const void *d;
+    int rc;
+    if ((rc = h2d(ctx, ctx->hb[12], dTAU_WL, (size_t)W * L * sizeof(double), &d))) return rc;
+    HIPCHK(ctx->dcont_gas.reserve((size_t)L * Wpad * sizeof(double)));
+    launch_w_to_last(ctx->stream, 1u, (const double *)d, ctx->dcont_gas.as<double>(), W, Wpad, 1, L, 0, 0.0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));      // the staging buffer is reused
+    ctx->dcont_gas_L = L;
+    return ANSFM_OK;
+}
+
 int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L, const double *lay_press_pa,
                                   const double *lay_temp, const double *amount, const double *taucont,
                                   const double *dtaucon, int NVMR, int NPAR, const int32_t *igas_map_host, int P,
@@ -1348,6 +1369,16 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
     r.mode = ctx->rt_mode == 1 ? 1 : 0;      // 1: path transmission and its gradients (ansfm_cirsradg_ck_transmission)
     q.dk = ctx->dkbuf.as<double>();
     q.dcont = dcont_t;
+    q.dcont_gas = nullptr;
+    if (ctx->dcont_gas_L) {
+        if (ctx->dcont_gas_L != L || n_models != 1) {
+            ctx->dcont_gas_L = 0;
+            FAIL(ANSFM_ERR_INVALID, "cirsradg: the pending shared gas gradient (ansfm_set_shared_gas_gradient) is for one model "
+                                    "with a different number of layers");
+        }
+        q.dcont_gas = ctx->dcont_gas.as<double>();
+        ctx->dcont_gas_L = 0;               // one call only
+    }
     q.trold_ws = ctx->trold_ws.as<double>();
     q.dspec = ctx->dspec_i.as<double>();
     q.dtsurf = dTSURF;

@@ -1491,6 +1491,8 @@ struct RtGParams {
     RtParams r;              // r.out = SPECOUT [n][W][P]
     const double *dk;        // [n][L][NP1][G][Wpad]
     const double *dcont;     // [n][NPAR][L][Wpad] or nullptr   (dTAUCON)
+    const double *dcont_gas; // [L][Wpad] or nullptr: one array added to the dTAUCON of EVERY gas parameter (kpar < NVMR) -- the
+                             // Rayleigh term of calculate_layer_opacity (:3955-3957) without NVMR copies of it
     double *trold_ws;        // [n][P][LIMAX+1][G][Wpad]
     double *dspec;           // [n][P][NPAR][LIMAX][Wpad]   (internal layout)
     double *dtsurf;          // [n][W][P]
@@ -1661,6 +1663,7 @@ __global__ __launch_bounds__(kWave *GY) void k_thermal_rtg(RtGParams q)
                 v = ys * ((slot == NP1 - 1) ? 1.0 : 1.0e-4);      // :3870 / :3872
             }
             if (q.dcont) v += q.dcont[(((size_t)m * q.NPAR + kpar) * p.L + lay) * p.Wpad + nu] * Xs;
+            if (q.dcont_gas && kpar < q.NVMR) v += q.dcont_gas[(size_t)lay * p.Wpad + nu] * Xs;
             v *= sc;                                               // :4012
             if (kpar == q.NVMR && !transmission) v += Zs * dB;     // :6467-6468
             v *= xf;                                               // :4247

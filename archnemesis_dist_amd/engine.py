@@ -353,10 +353,12 @@ class AnsfmEngine:
         return (spec[0], dspec[0]) if single else (spec, dspec)
 
     def cirsradg_ck_thermal(self, ISPACE, lay_press_pa, lay_temp, amount, taucont, dtaucon, NVMR, NPAR, igas_map,
-                            NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None, xfac=None, gradients_on_device=False):
+                            NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None, xfac=None, gradients_on_device=False,
+                            dtau_every_gas=None):
         """CIRSrad(return_grad=True): returns SPECOUT (n,W,P), dSPECOUT (n,W,NPAR,LIMAX,P), dTSURF (n,W,P)
         (leading axis dropped for a single model).  gradients_on_device (single model): dSPECOUT is not copied to the host
-        (None is returned in its place); `map2pro(None, ...)` takes it from the device."""
+        (None is returned in its place); `map2pro(None, ...)` takes it from the device.  dtau_every_gas (W, L), single
+        model: added to dTAUCON of every gas parameter (the Rayleigh term, :3955-3957) without building the NVMR copies."""
         W, G, NP, NT, S = self.dims
         lay_press_pa = _np(lay_press_pa)
         single = lay_press_pa.ndim == 1
@@ -374,6 +376,11 @@ class AnsfmEngine:
         TS = _np(np.broadcast_to(np.atleast_1d(_np(TSURF)), (n,)))
         ig = _np(igas_map, np.int32)
         on_dev = bool(gradients_on_device) and n == 1
+        if dtau_every_gas is not None:
+            dg = _np(dtau_every_gas)
+            if n != 1 or dg.shape != (W, L):
+                raise ValueError("cirsradg_ck_thermal: dtau_every_gas must be (NWAVE, NLAY) for a single model")
+            self._check(self._lib.ansfm_set_shared_gas_gradient(self._ctx, L, _ptr(dg)), "set_shared_gas_gradient")
         spec = np.empty((n, W, P)); dts = np.empty((n, W, P))
         dspec = None if on_dev else np.empty((n, W, NPAR, LIMAX, P))
         rc = self._lib.ansfm_cirsradg_ck_thermal(

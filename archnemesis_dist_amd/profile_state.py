@@ -189,8 +189,7 @@ class BatchedCKThermalModel:
             tauray, dtauray = eng.calc_tau_rayleigh(self.IRAY, self.ISPACE, eng.WAVE, lay["TOTAM"], ID=self.ID, ISO=self.ISO,
                                                     VMR=lay["PP"] / lay["PRESS"][:, None])
             cont = tauray if cont is None else cont + tauray
-            dcont = np.zeros((self.W, NPAR, tauray.shape[1]))
-            dcont[:, :NVMR, :] = dtauray[:, None, :]
+            dcont = dtauray                          # (W, L): goes to every gas parameter inside the kernel
         lay["_cont"], lay["_dcont"] = cont, dcont
         # only the gases the state vector names need their amount gradients (the others' rows of xmap are zero)
         wanted = {j for kind, j in st.blocks if kind == "VMR"}
@@ -212,9 +211,9 @@ class BatchedCKThermalModel:
 
     def _analytic_chain(self, eng, lay, amount, path, NVMR, NPAR, NDUST, NPRO, P_):
         # the layer-level and the level-level gradients (80 MB each at C3) stay on the device: only KK comes back
-        spec, _, _ = eng.cirsradg_ck_thermal(self.ISPACE, lay["PRESS"], lay["TEMP"], amount, lay["_cont"], lay["_dcont"], NVMR, NPAR,
+        spec, _, _ = eng.cirsradg_ck_thermal(self.ISPACE, lay["PRESS"], lay["TEMP"], amount, lay["_cont"], None, NVMR, NPAR,
                                              self.igas_map.astype(np.int32), path.NLAYIN, path.LAYINC, path.SCALE,
-                                             path.EMTEMP, self.TSURF, gradients_on_device=True)
+                                             path.EMTEMP, self.TSURF, gradients_on_device=True, dtau_every_gas=lay["_dcont"])
         eng.map2pro(None, self.W, NVMR, NDUST, NPRO, P_, path.NLAYIN, path.LAYINC, lay["DTE"], lay["DAM"], lay["DCO"],
                     to_host=False)
         return spec

@@ -238,6 +238,11 @@ int ansfm_k_overlapg(ansfm_ctx *ctx, int W, int G, int L, int S, const double *d
                      const double *k, const double *dkdT, const double *amount, double *tau,
                      double *dk);
 
+/* A continuum gradient that is the same for every gas parameter: dTAU_WL[W][L] (host) is added to dTAUCON[:, v, :] of all
+ * v < NVMR in the NEXT ansfm_cirsradg_ck_thermal call of one model (then forgotten) -- what calculate_layer_opacity does with
+ * dTAURAY (ForwardModel_0.py:3955-3957), without NVMR copies of the array crossing PCIe inside `dtaucon`.  NULL cancels. */
+int ansfm_set_shared_gas_gradient(ansfm_ctx *ctx, int L, const double *dTAU_WL);
+
 /* Which spectroscopic gases' amount gradients the k-table gradient path (ansfm_cirsradg_ck_*) computes: bit s of `mask` for
  * gas s of the uploaded table (default: all).  The reference always carries every gas through rankg (ForwardModel_0.py:
  * 5842-6026) and lets map2xvec drop what the state vector does not name; a caller that knows its state vector saves the replay

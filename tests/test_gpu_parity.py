@@ -1349,6 +1349,32 @@ def test_gradient_gas_selection_leaves_the_selected_gradients_unchanged(eng):
     assert np.array_equal(again[1], full[1])
 
 
+def test_shared_gas_continuum_gradient_equals_the_full_array(eng):
+    """ansfm_set_shared_gas_gradient: one (W, L) array for every gas parameter gives the dSPECOUT of the (W, NPAR, L) dTAUCON
+    that repeats it NVMR times, bit for bit; the setting is consumed by one call."""
+    from archnemesis_dist_amd import synthetic as syn
+    rng = np.random.default_rng(92)
+    W, G, S, L = 150, 10, 3, 11
+    PRESS, TEMP, K = syn.synth_ktable(W, G, 8, 6, S, seed=32)
+    _, delg = syn.gauss_legendre_01(G)
+    eng.upload_ktable(K, PRESS, TEMP, 650.0 + 0.5 * np.arange(W), delg)
+    atm = syn.synth_atmosphere(L, S, seed=5)
+    NLAYIN, LAYINC, SCALE = syn.nadir_path(L, 10.0)
+    lp, lt, am = atm["lay_press_pa"][0], atm["lay_temp"][0], atm["amount"][0]
+    EMTEMP = lt[LAYINC[:, 0]][:, None]
+    NVMR, NPAR = 5, 8
+    igas_map = np.array([3, 0, 4], dtype=np.int32)
+    dray = 10.0 ** rng.uniform(-26, -24, (W, L))
+    full = np.zeros((W, NPAR, L)); full[:, :NVMR, :] = dray[:, None, :]
+    args = (0, lp, lt, am, None)
+    rest = (NVMR, NPAR, igas_map, NLAYIN, LAYINC, SCALE, EMTEMP, -1.0)
+    a = eng.cirsradg_ck_thermal(*args, full, *rest)
+    b = eng.cirsradg_ck_thermal(*args, None, *rest, dtau_every_gas=dray)
+    c = eng.cirsradg_ck_thermal(*args, None, *rest)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert not np.array_equal(c[1][:, 0], a[1][:, 0]) and np.array_equal(c[1][:, NVMR], a[1][:, NVMR])
+
+
 def test_cirsrad_transmission_vs_oracle(eng, oracle):
     """CIRSrad's pure-transmission branch (calculate_transmission_spectrum :4110-4131): exp(-TAUTOT_PATH) of the same
     opacity assembly, g-quadrature, optional solar-flux factor -- two paths of different length, batch of two states."""
