@@ -383,10 +383,14 @@ class AnsfmEngine:
             self._check(self._lib.ansfm_set_shared_gas_gradient(self._ctx, L, _ptr(dg)), "set_shared_gas_gradient")
         spec = np.empty((n, W, P)); dts = np.empty((n, W, P))
         dspec = None if on_dev else np.empty((n, W, NPAR, LIMAX, P))
-        rc = self._lib.ansfm_cirsradg_ck_thermal(
-            self._ctx, int(ISPACE), n, L, _ptr(lp), _ptr(lt), _ptr(am), _ptr(tc), _ptr(dtc), int(NVMR), int(NPAR),
-            _ptr(ig), P, LIMAX, _ptr(NLAYIN), _ptr(LAYINC), _ptr(SC), _ptr(ET), _ptr(TS), _ptr(_np(EMISSIVITY)),
-            _ptr(_np(xfac)), _ptr(spec), _ptr(dspec), _ptr(dts))
+        try:
+            rc = self._lib.ansfm_cirsradg_ck_thermal(
+                self._ctx, int(ISPACE), n, L, _ptr(lp), _ptr(lt), _ptr(am), _ptr(tc), _ptr(dtc), int(NVMR), int(NPAR),
+                _ptr(ig), P, LIMAX, _ptr(NLAYIN), _ptr(LAYINC), _ptr(SC), _ptr(ET), _ptr(TS), _ptr(_np(EMISSIVITY)),
+                _ptr(_np(xfac)), _ptr(spec), _ptr(dspec), _ptr(dts))
+        finally:
+            if dtau_every_gas is not None:           # consumed by a successful call; cancelled if the call failed before that
+                self._lib.ansfm_set_shared_gas_gradient(self._ctx, 0, None)
         self._check(rc, "cirsradg_ck_thermal")
         self._chain_dspec = None
         if on_dev:
