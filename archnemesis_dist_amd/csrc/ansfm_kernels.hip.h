@@ -764,24 +764,26 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
     return acc;
 }
 
-// deferred bin boundaries of one replayed vector: the record pairs of bin b = (frac, 1/weight-sum), (weight, code)
-// ACCUM: the column part of the temperature slot is added to the row part already in OUT.
-template <bool COL, bool ACCUM>
+// deferred bin boundaries of one replayed vector.  The record of bin b is ONE 16-byte pair per lane, (frac, 1 / weight-sum), with
+// the closing element's (row, column) in the 11 lowest mantissa bits of frac; its weight is re-formed from the tables.  (Four
+// values in two pairs until the end of round 2: the records are read by every replay pass -- 49 per cell -- and with the step
+// codes and the slot vectors they cycle through L2 at 5 TB/s, profiles/r02_grad_traffic.json: the kernel is bound by that
+// stream.)  ACCUM: the column part of the temperature slot is added to the row part already in OUT.
+template <bool COL, bool ACCUM, bool W32, bool SORTED>
 __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const double *__restrict__ rec,
                                              const double *SL, const double *OUTL, double tail,
-                                             double *__restrict__ OUT)
+                                             double *__restrict__ OUT, const double *DG, const unsigned char *PA,
+                                             const unsigned char *PB)
 {
     double carry = 0.0;
     constexpr int kRB = 10;     // two memory round trips per pass for G = 20
     for (int b0 = 0; b0 < G; b0 += kRB) {
-        double rfr[kRB], rri[kRB], rw[kRB], rold[kRB];
-        unsigned rcd[kRB];
+        double rfr[kRB], rri[kRB], rold[kRB];
 #pragma unroll
         for (int k = 0; k < kRB; ++k) {
             const int bi = (b0 + k < G) ? b0 + k : G - 1;
-            const unsigned ro = (unsigned)bi * kRecBin + (unsigned)lane * 16u;
-            const dbl2 v0 = gld<dbl2>(rec, ro), v1 = gld<dbl2>(rec, ro + kRecRow);
-            rfr[k] = v0.x; rri[k] = v0.y; rw[k] = v1.x; rcd[k] = (unsigned)__double_as_longlong(v1.y);
+            const dbl2 v0 = gld<dbl2>(rec, (unsigned)bi * kRecBin + (unsigned)lane * 16u);
+            rfr[k] = v0.x; rri[k] = v0.y;
             if constexpr (ACCUM) rold[k] = gld<double>(OUT, (unsigned)(bi * kWave + lane) * 8u);
         }
 #pragma unroll
@@ -790,9 +792,15 @@ __device__ __forceinline__ void grad_resolve(int G, int lane, int ig, const doub
             if (b < G) {
                 double v = 0.0;
                 if (b < ig) {
-                    const unsigned code = rcd[k];
-                    const double g = SL[(COL ? ((code >> 5) & 31) : (code & 31)) * kWave + lane];
-                    const double gw = g * rw[k];
+                    const long long fb = __double_as_longlong(rfr[k]);
+                    const unsigned code = (unsigned)fb & 0x7FFu;
+                    const int crow = code & 31, ccol = (code >> 5) & 63;
+                    rfr[k] = __longlong_as_double(fb & ~0x7FFLL);
+                    double wk;
+                    if constexpr (SORTED) wk = pair_weight<W32>(DG, crow, ccol);
+                    else wk = pair_weight<W32>(DG, PA[crow * kWave + lane], PB[ccol * kWave + lane]);
+                    const double g = SL[(COL ? ccol : crow) * kWave + lane];
+                    const double gw = g * wk;
                     v = ((carry + OUTL[b * kWave + lane]) + rfr[k] * gw) * rri[k];
                     carry = (1.0 - rfr[k]) * gw;
                 } else if (b == ig)
@@ -973,8 +981,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                             }
                             const unsigned ro = (unsigned)b * kRecBin + (unsigned)lane * 16u;
                             ASAVE[b * kWave + lane] = outv;
-                            gst<dbl2>(rec, ro, dbl2{fr, rinv});
-                            gst<double>(rec, ro + kRecRow, w);          // pair 1 = (weight, code): the code stays
+                            // what the replay passes read: (frac | row, column of the closing element; 1 / weight-sum)
+                            const double frc = __longlong_as_double((__double_as_longlong(fr) & ~0x7FFLL) | (long long)(rcd[k] & 0x7FFu));
+                            gst<dbl2>(rec, ro, dbl2{frc, rinv});
                         }
                     }
                 }
@@ -989,21 +998,21 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                     double *DT = Dnew + (size_t)(igas + 2) * GW;
                     stage_row(Dold + (size_t)(igas + 1) * GW);
                     double tail = grad_replay<false, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
-                    grad_resolve<false, false>(G, lane, ig, rec, A, B, tail, DT);
+                    grad_resolve<false, false, W32, SORTED>(G, lane, ig, rec, A, B, tail, DT, DG, PA, PB);
                     stage_col(DTB);
                     tail = grad_replay<true, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
-                    grad_resolve<true, true>(G, lane, ig, rec, A, B, tail, DT);
+                    grad_resolve<true, true, W32, SORTED>(G, lane, ig, rec, A, B, tail, DT, DG, PA, PB);
                 }
                 if ((pg.gas_mask >> (igas + 1)) & 1u) {   // the new gas's slot: k_new[col]
                     stage_col(KRB);
                     const double tail = grad_replay<true, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
-                    grad_resolve<true, false>(G, lane, ig, rec, A, B, tail, Dnew + (size_t)(igas + 1) * GW);
+                    grad_resolve<true, false, W32, SORTED>(G, lane, ig, rec, A, B, tail, Dnew + (size_t)(igas + 1) * GW, DG, PA, PB);
                 }
                 for (int pp = 0; pp <= igas; ++pp) {   // earlier gases: D_old[pp][row]
                     if (!((pg.gas_mask >> pp) & 1u)) continue;
                     stage_row(Dold + (size_t)pp * GW);
                     const double tail = grad_replay<false, W32, SORTED>(nloop, lane, perm, A, B, DG, PA, PB);
-                    grad_resolve<false, false>(G, lane, ig, rec, A, B, tail, Dnew + (size_t)pp * GW);
+                    grad_resolve<false, false, W32, SORTED>(G, lane, ig, rec, A, B, tail, Dnew + (size_t)pp * GW, DG, PA, PB);
                 }
                 for (int pp = n; pp < NP1; ++pp)
                     for (int g = 0; g < G; ++g) Dnew[(size_t)pp * GW + g * kWave + lane] = 0.0;
