@@ -1252,7 +1252,7 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     if (grid < 1) grid = 1;
     HIPCHK(ctx->scratch.reserve((size_t)grid * 6 * (G + 1) * kWave * sizeof(double)));
     HIPCHK(ctx->gscratch.reserve((size_t)grid * (3 + 2 * (size_t)NP1) * G * kWave * sizeof(double)));
-    HIPCHK(ctx->perm.reserve((size_t)grid * ((G * G + 3) / 4) * kWave * sizeof(unsigned long long)));
+    HIPCHK(ctx->perm.reserve((size_t)grid * ((G * G + kCodesPerWord - 1) / kCodesPerWord) * kWave * sizeof(unsigned long long)));
     p.scratch = ctx->scratch.as<double>();
     pg.gscratch = ctx->gscratch.as<double>();
     pg.perm = ctx->perm.as<unsigned long long>();

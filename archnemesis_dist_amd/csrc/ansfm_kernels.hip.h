@@ -346,9 +346,9 @@ __device__ __forceinline__ unsigned merge_step(double (&R)[NR], MergeElem &e, Me
     bool cross;
     if constexpr (NODIV) cross = merge_walk_nodiv(e, ws, rec);
     else cross = merge_walk<REC_CODE>(e, ws, rec, GORD, lane);
-    // stream format of the gradient replay: bits 2-6 = row * 4, bits 9-13 = column * 4 (byte offsets into the float32
-    // weight table, << 7 more = the row of an [index][lane] LDS array), bit 15 = the element closed a bin
-    return (unsigned)((e.ci << 2) | ((e.np - 1) << 9) | (cross ? 0x8000 : 0));
+    // step code of the gradient replay, 12 bits: row (0-4), column (5-9), "the element closed a bin" (10); kCodesPerWord of
+    // them to a 64-bit word of the stream
+    return (unsigned)(e.ci | ((e.np - 1) << 5) | (cross ? 0x400 : 0));
 }
 
 // R[i] = head of row i = a_i + b_0: ascending in i when a is.  A loaded gas is (fast path: by precondition; generic: sorted
@@ -691,6 +691,7 @@ __device__ __forceinline__ void stage_slice_perm(double *dst_lds, const double *
     for (int g = 0; g < G; ++g) dst_lds[g * kWave + lane] = src[(size_t)P[g * kWave + lane] * kWave + lane];
 }
 
+constexpr int kCodesPerWord = 5;       // 12-bit step codes in a 64-bit word of the replay stream (60 bits used)
 // Replay of the recorded order for one gathered vector: SL[row] (slots of the earlier gases, row part of the
 // temperature slot) or, COL, SL[col] (the new gas's slot, column part of the temperature slot).
 // Store-free and branch-free: the running sum is written every step to the LDS row of
@@ -705,18 +706,22 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
     double acc = 0.0;
     unsigned bo = lds_addr(OUTL + lane);            // LDS byte address of the lane's slot in the row of its current bin
     const unsigned lane8 = (unsigned)lane * 8u;     // SL is the A region (offset kLdsA)
-    // four steps of one code word: all LDS operands first (one LDS round trip per word), then the dependent part.
-    // Code = row * 4 (bits 2-6) | column * 4 (bits 9-13) | closed-a-bin (bit 15): the two masked fields ARE the byte
-    // offsets into the float32 weight table, and << 7 the row offset of an [index][lane] array -- 32-bit ops only.
+    // the steps of one code word: all LDS operands first (one LDS round trip per word), then the dependent part.
+    // Field k of the word = bits [12k, 12k + 12): row, column, closed-a-bin.  The row / column are taken out already
+    // multiplied by 4 (byte offsets into the float32 weight table; << 7 more = the row of an [index][lane] array).
     auto group = [&](unsigned long long word, int nst) {
-        double g[4], wr[4];
+        double g[kCodesPerWord], wr[kCodesPerWord];
         const unsigned wlo = (unsigned)word, whi = (unsigned)(word >> 32);
-        unsigned crs[4];
+        const unsigned wmid = __builtin_amdgcn_alignbit(whi, wlo, 24);      // bits 24..55: the field across the two halves
+        unsigned crs[kCodesPerWord];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned code = (k < 2 ? wlo : whi) >> (16 * (k & 1));
-            crs[k] = code & 0x8000u;
-            const unsigned r4 = code & 0x7Cu, c4 = (code >> 7) & 0x7Cu;
+        for (int k = 0; k < kCodesPerWord; ++k) {
+            const unsigned src = (k < 2) ? wlo : (k == 2 ? wmid : whi);
+            constexpr int offs[kCodesPerWord] = {0, 12, 0, 4, 16};
+            const int off = offs[k];
+            crs[k] = src & (0x400u << off);
+            const unsigned r4 = (off >= 2 ? (src >> (off - 2)) : (src << (2 - off))) & 0x7Cu;
+            const unsigned c4 = (src >> (off + 3)) & 0x7Cu;
             if constexpr (SORTED) {
                 if constexpr (W32) wr[k] = (double)(lds_ldf(kLdsDGF + r4) * lds_ldf(kLdsDGF + c4));
                 else wr[k] = lds_ld(kLdsDG + 2 * r4) * lds_ld(kLdsDG + 2 * c4);
@@ -725,7 +730,7 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
             g[k] = lds_ld(kLdsA + (((COL ? c4 : r4) << 7) + lane8));
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kCodesPerWord; ++k) {
             if (k < nst) {
                 const bool cross = crs[k] != 0;
                 lds_st(bo, acc);
@@ -735,7 +740,7 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
             }
         }
     };
-    const int nfull = nloop >> 2, ngrp = (nloop + 3) >> 2;
+    const int nfull = nloop / kCodesPerWord, ngrp = (nloop + kCodesPerWord - 1) / kCodesPerWord;
     // Code words are fetched kPF words (4*kPF steps) ahead into kPF statically named registers: no register
     // rotation (a move of the newest word would wait for its load) and no predicated loads (clamped index).
     constexpr int kPF = 4;
@@ -750,15 +755,15 @@ __device__ __forceinline__ double grad_replay(int nloop, int lane, const unsigne
             const unsigned long long word = q[j];
             const int nxt = gidx + j + kPF;
             q[j] = gld<unsigned long long>(perm, (unsigned)(nxt < ngrp ? nxt : ngrp - 1) * (kWave * 8u) + lane8p);
-            group(word, 4);
+            group(word, kCodesPerWord);
         }
     }
     // remaining full words and the partial last one (their loads are already in flight / clamped duplicates)
 #pragma unroll
     for (int j = 0; j < kPF; ++j) {
         if (gidx + j < ngrp) {
-            const int nst = (nloop - 4 * (gidx + j)) < 4 ? (nloop - 4 * (gidx + j)) : 4;
-            group(q[j], nst);
+            const int left = nloop - kCodesPerWord * (gidx + j);
+            group(q[j], left < kCodesPerWord ? left : kCodesPerWord);
         }
     }
     return acc;
@@ -857,7 +862,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     double *const Dbuf0 = gs + dboff[0];
     double *ASAVE = gs + (2 + 2 * (size_t)NP1) * GW;
     const int nloop = G * G;
-    unsigned long long *perm = pg.perm + (size_t)blockIdx.x * ((nloop + 3) >> 2) * kWave;
+    unsigned long long *perm = pg.perm + (size_t)blockIdx.x * ((nloop + kCodesPerWord - 1) / kCodesPerWord) * kWave;
 
     TileQueue tq;
     tq.init();
@@ -923,22 +928,35 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
                 WalkState ws = walk_begin(GORD, lane);
                 unsigned long long *pw = perm + lane;
                 int it = 0;
-                for (; it + 3 < nloop; it += 4) {   // four 16-bit codes per word, assembled as two 32-bit halves
+                auto put5 = [&](unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned c4) {
+                    *reinterpret_cast<uint2 *>(pw) = make_uint2(c0 | (c1 << 12) | (c2 << 24), (c2 >> 8) | (c3 << 4) | (c4 << 16));
+                    pw += kWave;
+                };
+                // five 12-bit codes per word; the two element registers swap roles every step, so ten steps are written out
+                for (; it + 9 < nloop; it += 10) {
                     const unsigned c0 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
                     const unsigned c1 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
                     const unsigned c2 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
                     const unsigned c3 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
-                    *reinterpret_cast<uint2 *>(pw) = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
-                    pw += kWave;
+                    const unsigned c4 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    put5(c0, c1, c2, c3, c4);
+                    const unsigned c5 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    const unsigned c6 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    const unsigned c7 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    const unsigned c8 = merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    const unsigned c9 = merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                    put5(c5, c6, c7, c8, c9);
                 }
-                if (it < nloop) {   // G*G not a multiple of 4: a partial last word
+                if (it < nloop) {   // G*G not a multiple of 10: the remaining steps, one at a time
                     unsigned long long word = 0;
-                    for (int k = 0; it < nloop; ++it, ++k) {
-                        const unsigned long long c = (k & 1) ? merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB)
-                                                             : merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
-                        word |= c << (16 * k);
+                    int k = 0;
+                    for (int par = 0; it < nloop; ++it, par ^= 1) {
+                        const unsigned long long c = par ? merge_step<NR, W32, true, SORTED>(R, e1, e0, ws, lane, A, B, DG, GORD, rec, PA, PB)
+                                                         : merge_step<NR, W32, true, SORTED>(R, e0, e1, ws, lane, A, B, DG, GORD, rec, PA, PB);
+                        word |= c << (12 * k);
+                        if (++k == kCodesPerWord) { *pw = word; pw += kWave; word = 0; k = 0; }
                     }
-                    *pw = word;
+                    if (k) *pw = word;
                 }
                 // ---- resolve the bins: merged k -> ASAVE, (frac, 1/sum, weight) -> rec rows 0-2 -------------------
                 double ck = 0.0, cs = 0.0;
