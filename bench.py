@@ -228,6 +228,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (S=20 variant, gradients, C4, C5)")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (RCCL prints a version banner at the
+    # first communicator), so file descriptor 1 is pointed at stderr for the run and the line goes out through a copy of
+    # the original descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import archnemesis_dist_amd as pkg
@@ -474,7 +481,9 @@ def main():
         "table_relayout_s": table_relayout_s,
         "extras": extras,
     }
-    print(json.dumps(line))
+    sys.stdout.flush()
+    with os.fdopen(json_fd, "w") as out:
+        out.write(json.dumps(line) + "\n")
     if use_dist:
         dist.destroy_process_group()
 
