@@ -382,3 +382,28 @@ def test_rccl_collectives_under_a_one_rank_nccl_group(tmp_path):
     r = subprocess.run([sys.executable, str(f)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "nccl ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_under_torch_distributed_run():
+    """The driver's launch of bench.py for N > 1 (torch.distributed.run, one rank per GPU, RCCL), rehearsed with the one GPU of
+    this box: stdout must be exactly ONE JSON line (RCCL prints a version banner on file descriptor 1 at the first communicator;
+    bench.py routes everything but its line to stderr), with the contract's keys, the roofline object and the Jacobian gathered
+    through the collective."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline",
+                        "--waves", "2048", "--jac-models", "21"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["value"] > 0
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert "RCCL" in (d["jacobian"].get("collective") or "")
