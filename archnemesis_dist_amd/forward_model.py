@@ -76,6 +76,30 @@ def _delegate(what):
     DELEGATED[what] = DELEGATED.get(what, 0) + 1
 
 
+NOTES = {}
+
+
+def _note(what):
+    """Something the adapter does differently from the reference on purpose (not a delegation: the work stays on the GPU
+    path), said once as a RuntimeWarning and counted in NOTES -- e.g. NCores > 1 without joblib workers."""
+    if what not in NOTES:
+        import warnings
+        warnings.warn("ansfm: " + what, RuntimeWarning, stacklevel=3)
+    NOTES[what] = NOTES.get(what, 0) + 1
+
+
+def summary():
+    """What left the GPU path (DELEGATED: case -> count) and what was done differently on purpose (NOTES) since the
+    process started or `reset_summary()`; `install_all()` returns the same object, so a caller can print it after a
+    retrieval."""
+    return {"delegated": dict(DELEGATED), "notes": dict(NOTES), "strict": STRICT}
+
+
+def reset_summary():
+    DELEGATED.clear()
+    NOTES.clear()
+
+
 class KtaTableOnDevice:
     """Stand-in for Spectroscopy.K when the k-table is taken from the .kta files straight into HBM
     (install_gpu_table_reader): knows the files, the wavenumber range and the shape the array would have.  Code that
@@ -456,8 +480,10 @@ class CIRSradGPU:
 
 
 def make_gpu_forward_model(reference_forward_model_cls, device=0):
-    """Subclass of the reference's ForwardModel_0 with the GPU CIRSrad seam."""
-    return type("ForwardModel_0", (CIRSradGPU, reference_forward_model_cls),
+    """Subclass of the reference's ForwardModel_0 with the GPU CIRSrad seam and `jacobian_nemesis` without the joblib
+    fan-out (jacobian_dropin.JacobianGPU)."""
+    from .jacobian_dropin import JacobianGPU
+    return type("ForwardModel_0", (JacobianGPU, CIRSradGPU, reference_forward_model_cls),
                 {"ansfm_device": device, "__doc__": reference_forward_model_cls.__doc__})
 
 

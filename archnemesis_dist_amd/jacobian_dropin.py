@@ -1,0 +1,326 @@
+"""`ForwardModel_0.jacobian_nemesis` (ForwardModel_0.py:2184-2361) as a drop-in on one GPU per process.
+
+The reference fans the nfm = NX_run + 1 forward models of the numerical part out to joblib / loky workers (:2322-2337);
+every worker is a pickled copy of the whole ForwardModel_0, runs `nemesisfm()` per column (8 deep copies, `read_tables`,
+`subprofretg`, `calc_path`, CIRSrad) and hands back a zero-padded (NY, nfm) matrix that the parent sums.  With CIRSrad
+on a GPU that fan-out is the wrong shape: every worker would open its own context and upload its own k-table.  The
+override keeps the method's signature, state-vector arithmetic (:2234-2242), NUM / FIX / ISCAT rules (:2251-2255,
+:2291-2302) and quotient (:2348-2359), and replaces the fan-out by three in-process routes, tried in this order:
+
+  "profile"  every variable is a continuous profile (Models/PreRTModels/model_0.py), k-tables, thermal emission, no
+             hydrostatic re-adjustment, Rayleigh-only continuum: the state vector is mapped to
+             profile_state.ContinuousProfileState / BatchedCKThermalModel and ALL forward models are one
+             `layer_average` launch + one Rayleigh launch + one CIRSrad launch (jacobian.jacobian_nemesis_batched; sharded
+             over ranks when a process group is given).
+  "staged"   any model of the reference's zoo, any continuum, several geometries / averaging points, hydrostatic
+             re-adjustment, instrument convolution: the reference's OWN host code (select_Measurement, the deep copies,
+             subprofretg, calc_path, the continuum routines) is run per state up to the point where nemesisfm would call
+             CIRSrad (:490-516); what CIRSrad would read is kept, and the states of one (geometry, averaging point) go
+             to the GPU as ONE batched call (layers bit-identical to the unperturbed state's are not recomputed,
+             DESIGN.md 4.1d); the second half of nemesisfm (FOV weights, convolution, subspecret, :531-587) then runs
+             per state.  read_tables runs once per geometry instead of once per forward model.
+  "loop"     everything else (nemesisSO / L / C / disc / PT variants, line-by-line runtime, Telluric, a CIRSrad branch
+             that has no batch axis): the reference's `execute_fm` (:2121) per column, in this process, one after the
+             other -- never joblib workers on one GPU.  NCores > 1 is noted once (RuntimeWarning) and not used.
+
+`ansfm_last_jacobian` records which route ran, the number of forward models and the layer rows computed / total."""
+import warnings
+from copy import deepcopy
+
+import numpy as np
+
+from . import forward_model as _fm
+from .jacobian import chunk_range, perturbed_states
+
+ISCAT_THERMAL_EMISSION = 0             # ScatteringCalculationModeEnum.THERMAL_EMISSION
+IFORM_NORMALISED_RADIANCE = 5          # SpectraUnitEnum.Normalised_radiance
+IFORM_INTEGRATED_RADIANCE = 6          # SpectraUnitEnum.Integrated_radiance
+
+
+class JacobianGPU:
+    """Mixin: jacobian_nemesis without the joblib fan-out.  Sits in front of CIRSradGPU and the reference class."""
+
+    ansfm_jacobian_route = "auto"      # "auto" | "profile" | "staged" | "loop": force a route (tests, A/B timing)
+    ansfm_jacobian_group = None        # (rank, world_size, process group): shard the forward models over ranks
+    ansfm_last_jacobian = None
+
+    # ---- the method the retrieval loop calls (OptimalEstimation_0.py:1333, :1467; Retrievals.py:182, :257) ----------
+    def jacobian_nemesis(self, NCores=1, nemesisSO=False, nemesisL=False, nemesisC=False, nemesisdisc=False,
+                         nemesisPT=False, analytical_gradient=True):
+        V, M = self.Variables, self.Measurement
+        flags = dict(nemesisSO=nemesisSO, nemesisL=nemesisL, nemesisC=nemesisC, nemesisdisc=nemesisdisc, nemesisPT=nemesisPT)
+        V.calc_DSTEP()
+        XN0 = np.array(V.XN, dtype=float)
+        xnx = perturbed_states(XN0, V.DSTEP)                                       # :2234-2242
+        if int(self.Scatter.ISCAT) != ISCAT_THERMAL_EMISSION or analytical_gradient is False:
+            V.NUM[:] = 1                                                           # :2251-2255
+        NY, NX = int(M.NY), int(V.NX)
+        KK = np.zeros((NY, NX))
+        YN = None
+        info = dict(route=None, nfm=0, analytic_columns=0, rows=(0, 0))
+        ian = np.where(np.asarray(V.NUM) == 0)[0]
+        if len(ian) > 0:                                                           # analytic part: nemesisfmg (:2263-2285)
+            SPECMOD, dSPECMOD = self.select_nemesis_fm(analytical_gradient=True, **flags)()
+            YN = np.zeros(NY)
+            ik = 0
+            for ig in range(M.NGEOM):
+                nc = int(M.NCONV[ig])
+                YN[ik:ik + nc] = SPECMOD[0:nc, ig]
+                KK[ik:ik + nc, :] = dSPECMOD[0:nc, ig, :]
+                ik += nc
+            info["analytic_columns"] = int(len(ian))
+        inum = np.where((np.asarray(V.NUM) == 1) & (np.asarray(V.FIX) == 0))[0]     # :2291-2302
+        lead = 0 if YN is not None else 1
+        nfm = len(inum) + lead
+        ixrun = np.zeros(nfm, dtype="int32")
+        ixrun[lead:] = inum + 1
+        info["nfm"] = int(nfm)
+        if nfm > 0:
+            try:
+                YNtot = self._ansfm_forward_models(xnx, ixrun, flags, NCores, info)   # (NY, nfm)
+            finally:
+                V.XN = XN0                       # the reference mutates worker copies only (:2154)
+            if YN is None:
+                YN = YNtot[:, 0].copy()
+            for i, ix in enumerate(inum):                                          # :2348-2359
+                xn1 = XN0[ix] * 1.05
+                if xn1 == 0.0:
+                    xn1 = 0.05
+                KK[:, ix] = (YNtot[:, i + lead] - YN) / (xn1 - XN0[ix])
+        self.ansfm_last_jacobian = info
+        return YN, KK
+
+    # ---- route selection -------------------------------------------------------------------------------------------
+    def _ansfm_forward_models(self, xnx, ixrun, flags, NCores, info):
+        want = self.ansfm_jacobian_route
+        plain = not any(flags.values())
+        routes = []
+        if plain and want in ("auto", "profile"):
+            routes.append(("profile", self._ansfm_profile_route))
+        if plain and want in ("auto", "staged"):
+            routes.append(("staged", self._ansfm_staged_route))
+        if want not in ("auto", "loop") and not routes:
+            raise ValueError("jacobian_nemesis: route %r is not available for these flags" % (want,))
+        for name, fn in routes:
+            Y = fn(xnx, ixrun, info)
+            if Y is not None:
+                info["route"] = name
+                return Y
+            if want == name:
+                raise NotImplementedError("jacobian_nemesis: the %s route does not cover this configuration (%s)"
+                                          % (name, info.get("why_not_" + name, "")))
+        info["route"] = "loop"
+        return self._ansfm_loop_route(xnx, ixrun, flags, NCores, info)
+
+    # ---- "loop": execute_fm per column, in process -------------------------------------------------------------------
+    def _ansfm_loop_route(self, xnx, ixrun, flags, NCores, info):
+        if NCores is not None and int(NCores) > 1:
+            _fm._note("jacobian_nemesis(NCores > 1): the forward models run one after the other in this process on the GPU, "
+                      "no joblib workers")
+        nfm = len(ixrun)
+        Y = np.zeros((int(self.Measurement.NY), nfm))
+        rank, world, group = self.ansfm_jacobian_group or (0, 1, None)
+        s, e = chunk_range(nfm, world, rank)
+        for ifm in range(s, e):
+            Y = self.execute_fm((ifm, nfm, xnx, ixrun, flags["nemesisSO"], flags["nemesisL"], flags["nemesisC"],
+                                 flags["nemesisdisc"], flags["nemesisPT"], Y, 1))
+        if world > 1:
+            Y = self._ansfm_gather(Y, s, e, nfm, rank, world, group)
+        return Y
+
+    def _ansfm_gather(self, Y, s, e, nfm, rank, world, group):
+        """One all_gather of the (nfm_local, NY) blocks of a sharded run (RCCL when the group's backend is nccl)."""
+        import torch
+        from .jacobian import gather_columns
+        dev = torch.device("cuda", self.ansfm_device) if (group is not None and torch.cuda.is_available()) else "cpu"
+        block = torch.as_tensor(np.ascontiguousarray(Y[:, s:e].T), dtype=torch.float64, device=dev)
+        return np.ascontiguousarray(gather_columns(block, nfm, rank, world, group=group).cpu().numpy().T)
+
+    # ---- "staged": the reference's host code per state, one batched CIRSrad per (geometry, averaging point) ------------
+    def _ansfm_staged_supported(self, info):
+        A, Sf, M = self.Atmosphere, self.Surface, self.Measurement
+        why = None
+        if getattr(A, "NLOCATIONS", 1) > 1 or getattr(Sf, "NLOCATIONS", 1) > 1:
+            why = "several locations"
+        elif getattr(self, "Telluric", None) is not None:
+            why = "Telluric transmission"
+        elif getattr(self, "Emissions", None) is not None:
+            why = "layer emissions"
+        elif int(self.Spectroscopy.ILBL) not in (_fm.ILBL_K_TABLES, _fm.ILBL_LBL_TABLES) or self.Spectroscopy.NGAS <= 0:
+            why = "spectral mode without tables"
+        info["why_not_staged"] = why
+        return why is None
+
+    def _ansfm_stage_one(self, IGEOM, IAV):
+        """nemesisfm between the table read and the CIRSrad call (:490-516) for the state in Variables.XN."""
+        self.select_Measurement(IGEOM, IAV)
+        for name in ("Atmosphere", "Scatter", "Stellar", "Surface", "Layer", "CIA", "Telluric"):
+            setattr(self, name + "X", deepcopy(getattr(self, name)))
+        MX, SX = self.MeasurementX, self.ScatterX
+        if MX.EMISS_ANG[0, 0] >= 0.0:
+            SX.SOL_ANG, SX.EMISS_ANG, SX.AZI_ANG = MX.SOL_ANG[0, 0], MX.EMISS_ANG[0, 0], MX.AZI_ANG[0, 0]
+        else:
+            SX.SOL_ANG, SX.EMISS_ANG = MX.TANHE[0, 0], MX.EMISS_ANG[0, 0]
+        self.subprofretg()
+        self.LayerX.DUST_UNITS_FLAG = self.AtmosphereX.DUST_UNITS_FLAG
+        self.calc_path()
+
+    def _ansfm_staged_route(self, xnx, ixrun, info):
+        if not self._ansfm_staged_supported(info):
+            return None
+        M, V = self.Measurement, self.Variables
+        nfm = len(ixrun)
+        rank, world, group = self.ansfm_jacobian_group or (0, 1, None)
+        s, e = chunk_range(nfm, world, rank)
+        # the unperturbed state leads every batch although its spectrum may not be wanted (another rank's chunk, or YN came
+        # from the analytic part): the engine shares layers with the FIRST model of a batch, and every perturbed state
+        # is one step away from the unperturbed one, not from its neighbour
+        owners = list(range(s, e))
+        if not owners:
+            return self._ansfm_gather(np.zeros((int(M.NY), nfm)), s, e, nfm, rank, world, group) if world > 1 else np.zeros((int(M.NY), nfm))
+        cols = [int(ixrun[i]) for i in owners]
+        if cols[0] != 0:
+            cols, owners = [0] + cols, [None] + owners
+        states = cols
+        eng = _fm.get_engine(self.ansfm_device)
+        self.check_gas_spec_atm()
+        self.check_wave_range_consistency()
+        SPECONV = np.zeros((len(states),) + tuple(M.MEAS.shape))
+        rows_c = rows_t = 0
+        for IGEOM in range(M.NGEOM):
+            M.build_ils(IGEOM=IGEOM)                                                # :476-482, once per geometry
+            wmin, wmax = M.calc_wave_range(apply_doppler=True, IGEOM=IGEOM)
+            self.SpectroscopyX = deepcopy(self.Spectroscopy)
+            if self.SpectroscopyX.NGAS > 0:
+                self.SpectroscopyX.read_tables(wavemin=wmin, wavemax=wmax)
+            W = int(self.SpectroscopyX.NWAVE)
+            NAV = int(M.NAV[IGEOM])
+            staged = [[None] * NAV for _ in states]
+            for k, col in enumerate(states):
+                V.XN = xnx[:, col]                                                  # execute_fm :2154
+                for IAV in range(NAV):
+                    self._ansfm_stage_one(IGEOM, IAV)
+                    rec = self._ansfm_thermal_inputs()
+                    if rec is None:                  # a CIRSrad branch without a batch axis: this state runs on its own
+                        rec = dict(alone=self.CIRSrad())
+                    if int(self.PathX.NPATH) > 1:    # nemesisfm's several-paths branch (:521-527) fails on a shape mismatch
+                        info["why_not_staged"] = "NPATH > 1"     # in the reference: let its own code say so ("loop")
+                        return None
+                    staged[k][IAV] = rec
+            SPEC = np.zeros((len(states), W))
+            for IAV in range(NAV):
+                recs = [staged[k][IAV] for k in range(len(states))]
+                spectra, rc, rt = self._ansfm_run_batches(eng, recs, W)
+                rows_c += rc; rows_t += rt
+                for k, sp in enumerate(spectra):                                    # :531 (NAV >= 1 inside this loop)
+                    SPEC[k] += M.WGEOM[IGEOM, IAV] * sp[:, 0]
+            for k in range(len(states)):
+                SPECONV[k, 0:int(M.NCONV[IGEOM]), IGEOM] = self._ansfm_convolve(SPEC[k], IGEOM)
+        Y = np.zeros((int(M.NY), nfm))
+        for k, (col, ifm) in enumerate(zip(states, owners)):
+            if ifm is None:
+                continue
+            V.XN = xnx[:, col]
+            dS = np.zeros((int(M.NCONV.max()), int(M.NGEOM), int(V.NX)))
+            SP, _ = self.subspecret(SPECONV[k], dS)                                 # :585-587
+            ik = 0
+            for ig in range(M.NGEOM):                                               # execute_fm :2171-2174
+                nc = int(M.NCONV[ig])
+                Y[ik:ik + nc, ifm] = SP[0:nc, ig]
+                ik += nc
+        info["rows"] = (int(rows_c), int(rows_t))
+        if world > 1:
+            Y = self._ansfm_gather(Y, s, e, nfm, rank, world, group)
+        return Y
+
+    def _ansfm_convolve(self, SPEC, IGEOM):
+        """nemesisfm :556-581 for one geometry: filter integral, ILS convolution by table kind, normalisation."""
+        import os
+        M, S = self.Measurement, self.SpectroscopyX
+        nc = int(M.NCONV[IGEOM])
+        if int(M.IFORM) == IFORM_INTEGRATED_RADIANCE:
+            return np.asarray(M.integrate_filter(S.WAVE, SPEC, IGEOM=IGEOM))[0:nc]
+        if int(S.ILBL) == _fm.ILBL_K_TABLES:
+            fw = self.runname if os.path.exists(self.runname + ".fwh") else ""
+            out = M.conv(S.WAVE, SPEC, IGEOM=IGEOM, FWHMEXIST=fw)
+        else:
+            out = M.lblconv(S.WAVE, SPEC, IGEOM=IGEOM)
+        out = np.array(out[0:nc], dtype=float)
+        if int(M.IFORM) == IFORM_NORMALISED_RADIANCE:
+            out /= np.interp(M.VNORM, M.VCONV[0:nc, IGEOM], out)
+        return out
+
+    def _ansfm_thermal_inputs(self):
+        """What CIRSrad's thermal-emission branch hands to the engine (forward_model.CIRSradGPU.CIRSrad), kept instead
+        of run; None when the staged state takes another branch of CIRSrad's dispatch."""
+        if not self._ansfm_supported(False):
+            return None
+        P = self.PathX
+        imod = int(np.unique(np.asarray(P.IMOD).astype(int))[0])
+        if self._ansfm_transmission_branch(imod) or not (imod & _fm.IMOD_THERMAL_EMISSION):
+            return None
+        L = self.LayerX
+        TAUCIA, TAUDUST, TAURAY, _ = self._ansfm_continuum(False)
+        xfac, emissivity = self._ansfm_units_and_surface()
+        NPATH = int(P.NPATH) if hasattr(P, "NPATH") else np.asarray(P.LAYINC).shape[1]
+        return dict(
+            ISPACE=int(self.MeasurementX.ISPACE), lp=np.array(L.PRESS, dtype=np.float64), lt=np.array(L.TEMP, dtype=np.float64),
+            f_gas=self._ansfm_layer_inputs(), taucont=TAUCIA + TAUDUST + TAURAY,
+            NLAYIN=np.asarray(P.NLAYIN, dtype=np.int32).reshape(NPATH), LAYINC=np.asarray(P.LAYINC, dtype=np.int32).reshape(-1, NPATH),
+            SCALE=np.asarray(P.SCALE, dtype=np.float64).reshape(-1, NPATH), EMTEMP=np.asarray(P.EMTEMP, dtype=np.float64).reshape(-1, NPATH),
+            TSURF=float(self.SurfaceX.TSURF), emissivity=emissivity, xfac=xfac,
+            SOL_ANG=np.asarray(P.SOL_ANG, dtype=np.float64).reshape(NPATH), EMISS_ANG=np.asarray(P.EMISS_ANG, dtype=np.float64).reshape(NPATH))
+
+    @staticmethod
+    def _ansfm_batch_key(r):
+        """States that may share one batched call: same path structure and same per-wavenumber boundary vectors."""
+        opt = lambda a: b"-" if a is None else np.ascontiguousarray(a, dtype=np.float64).tobytes()
+        return (r["ISPACE"], r["lp"].shape, r["LAYINC"].shape, r["NLAYIN"].tobytes(), r["LAYINC"].tobytes(), opt(r["emissivity"]),
+                opt(r["xfac"]), r["SOL_ANG"].tobytes(), r["EMISS_ANG"].tobytes())
+
+    def _ansfm_run_batches(self, eng, recs, W):
+        """recs: one staged record per state -> list of SPECOUT (NWAVE, NPATH) per state, rows computed, rows total."""
+        out = [None] * len(recs)
+        groups = {}
+        for k, r in enumerate(recs):
+            if "alone" in r:
+                out[k] = np.asarray(r["alone"]).reshape(W, -1)
+            else:
+                groups.setdefault(self._ansfm_batch_key(r), []).append(k)
+        self._ansfm_upload_table(eng)
+        rc = rt = 0
+        for ks in groups.values():
+            r0 = recs[ks[0]]
+            st = lambda name: np.stack([recs[k][name] for k in ks])
+            spec = eng.cirsrad_ck_thermal(r0["ISPACE"], st("lp"), st("lt"), st("f_gas"), st("taucont"), r0["NLAYIN"], r0["LAYINC"],
+                                          st("SCALE"), st("EMTEMP"), np.array([recs[k]["TSURF"] for k in ks]),
+                                          EMISSIVITY=r0["emissivity"], SOL_ANG=r0["SOL_ANG"], EMISS_ANG=r0["EMISS_ANG"], xfac=r0["xfac"])
+            spec = np.asarray(spec).reshape(len(ks), W, -1)
+            if hasattr(eng, "last_layer_rows"):
+                a, b = eng.last_layer_rows()
+                rc += a; rt += b
+            for j, k in enumerate(ks):
+                out[k] = spec[j]
+        return out, rc, rt
+
+    # ---- "profile": model-0 state vectors through the vectorised host path --------------------------------------------
+    def _ansfm_profile_route(self, xnx, ixrun, info):
+        from .profile_dropin import batched_model_from_reference
+        model, why = batched_model_from_reference(self)
+        info["why_not_profile"] = why
+        if model is None:
+            return None
+        import torch
+        rank, world, group = self.ansfm_jacobian_group or (0, 1, None)
+        nfm = len(ixrun)
+        s, e = chunk_range(nfm, world, rank)
+        cols = [int(c) for c in ixrun[s:e]]
+        lead = 0 if (not cols or cols[0] == 0) else 1          # the unperturbed state leads every batch (de-duplication)
+        X = np.ascontiguousarray(xnx[:, [0] * lead + cols].T)
+        Yd = model.spectra_batch(X)[lead:]                        # torch (nfm_local, NWAVE * NPATH) on the device
+        info["rows"] = tuple(int(v) for v in model.last_rows)
+        Yd = model.measurement_vector(Yd)                         # calculation grid -> NY (interp / ILS), still on the device
+        if world > 1:
+            from .jacobian import gather_columns
+            Yd = gather_columns(Yd, nfm, rank, world, group=group)
+        return np.ascontiguousarray(Yd.cpu().numpy().T) if isinstance(Yd, torch.Tensor) else np.ascontiguousarray(np.asarray(Yd).T)

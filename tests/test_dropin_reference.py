@@ -41,6 +41,14 @@ class OracleEngineDouble:
     def cirsrad_ck_thermal(self, ISPACE, lp, lt, am, cont, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY=None,
                            SOL_ANG=None, EMISS_ANG=None, xfac=None, **kw):
         K, P, T, W, D = self.t
+        if np.ndim(lp) == 2:                         # leading model axis (the engine's batched call): one model at a time
+            n = np.shape(lp)[0]
+            self.batch_sizes = getattr(self, "batch_sizes", []) + [n]
+            per = lambda a, i: None if a is None else (np.asarray(a)[i] if np.ndim(a) == 3 else np.asarray(a))
+            return np.stack([self.cirsrad_ck_thermal(ISPACE, lp[i], lt[i], am[i], None if cont is None else np.asarray(cont)[i],
+                                                     NLAYIN, LAYINC, per(SCALE, i), per(EMTEMP, i), float(np.atleast_1d(TSURF)[i]),
+                                                     EMISSIVITY=EMISSIVITY, SOL_ANG=SOL_ANG, EMISS_ANG=EMISS_ANG, xfac=xfac)
+                             for i in range(n)])
         out, self.tg = self.orc.cirsrad_ck_thermal(ISPACE, K, P, T, W, D, lp, lt, am, cont, NLAYIN, LAYINC, SCALE, EMTEMP,
                                                    TSURF, EMISSIVITY=EMISSIVITY, SOL_ANG=SOL_ANG, EMISS_ANG=EMISS_ANG,
                                                    xfac=xfac, return_taugas=True)
@@ -127,9 +135,50 @@ class OracleEngineDouble:
         dspec = np.nan_to_num(np.tensordot(-sg[:, :, None, None, :] * dlay, D, axes=([1], [0])))
         return np.tensordot(sg, D, axes=([1], [0])), dspec
 
-    def layer_average(self, *a, **k):
+    def layer_average(self, RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP=None, **k):
         self.lay_calls = getattr(self, "lay_calls", 0) + 1
-        return self.orc.layer_average(*a, **k)
+        if np.ndim(H) == 2:                          # leading state axis: the engine's batched launch, one state at a time
+            n = np.shape(H)[0]
+            pick = lambda a, i: None if a is None else (np.asarray(a)[i] if np.ndim(a) >= 2 and np.shape(a)[0] == n else a)
+            xm = k.pop("XMOLWT", None)
+            rows = [self.orc.layer_average(RADIUS, H[i], pick(P, i), T[i], ID, VMR[i], pick(DUST, i), pick(PARAH2, i),
+                                           np.asarray(BASEH).reshape(-1, np.shape(BASEH)[-1])[i if np.ndim(BASEH) == 2 else 0], None,
+                                           XMOLWT=xm, **k) for i in range(n)]
+            return tuple(np.stack([r[j] for r in rows]) for j in range(len(rows[0])))
+        return self.orc.layer_average(RADIUS, H, P, T, ID, VMR, DUST, PARAH2, BASEH, BASEP, **k)
+
+    # ---- what the batched ("profile") route calls with torch tensors: answered on the CPU ------------------------------
+    @property
+    def torch_device(self):
+        import torch
+        return torch.device("cpu")
+
+    device = 0
+
+    def synchronize(self):
+        pass
+
+    def last_layer_rows(self):
+        return getattr(self, "_rows", (0, 0))
+
+    def calc_tau_rayleigh_batch_dev(self, IRAY, ISPACE, TOTAM, out, ID=None, ISO=None, VMR=None, variant=None):
+        import torch
+        K, P, T, W, D = self.t
+        for i in range(np.shape(TOTAM)[0]):
+            tau = self.orc.calc_tau_rayleigh(int(IRAY), int(ISPACE), W, TOTAM[i], ID, ISO, None if VMR is None else VMR[i])[0]
+            out[i] = torch.as_tensor(tau)
+        return out
+
+    def cirsrad_ck_thermal_dev(self, ISPACE, n, L, lp, lt, am, cont, P_, LIMAX, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMIS, SOLF,
+                               REFL, SOL, EMI, xfac, out):
+        import torch
+        h = lambda a: None if a is None else a.numpy()
+        self.dev_batches = getattr(self, "dev_batches", []) + [int(n)]
+        for i in range(n):
+            sp = self.cirsrad_ck_thermal(ISPACE, h(lp)[i], h(lt)[i], h(am)[i], None if cont is None else h(cont)[i], h(NLAYIN),
+                                         h(LAYINC), h(SCALE)[i], h(EMTEMP)[i], float(h(TSURF)[i]), EMISSIVITY=h(EMIS), xfac=h(xfac))
+            out[i] = torch.as_tensor(sp)
+        self._rows = (n * L, n * L)
 
     def layer_averageg(self, *a, **k):
         self.lay_calls = getattr(self, "lay_calls", 0) + 1
@@ -137,8 +186,9 @@ class OracleEngineDouble:
 
     def calc_tau_cia(self, *a, **k):
         self.cia_calls = getattr(self, "cia_calls", 0) + 1
-        k.pop("with_grad", None)
-        return self.orc.calc_tau_cia(*a, **k)
+        with_grad = k.pop("with_grad", True)
+        r = self.orc.calc_tau_cia(*a, **k)
+        return r if with_grad else r[0]
 
     def calc_tau_rayleigh(self, IRAY, ISPACE, WAVEC, TOTAM, ID=None, ISO=None, VMR=None, variant=None):
         self.ray_calls = getattr(self, "ray_calls", 0) + 1

@@ -1,0 +1,180 @@
+"""`jacobian_nemesis` as a drop-in (archnemesis_dist_amd.jacobian_dropin) against the reference's own Jacobian harness.
+
+tests/golden/jacobian_c1.npz is the output of the REFERENCE's `jacobian_nemesis(analytical_gradient=False)`
+(ForwardModel_0.py:2184-2361) on the C1 inputs cut to 40 convolution points and 12 free temperature levels, run with two
+loky workers (oracle/gen_golden_jacobian.py), plus what each of its 13 forward models handed to CIRSrad.
+
+  * CPU, no reference: the oracle's CIRSrad on the 13 recorded states -> YNtot, KK vs the fixture (pins the chain the
+    other Jacobian tests use as their checker, oracle/jacobian_twin.py's `cirsrad_ck_thermal` leg, to the reference);
+  * CPU, reference present: the subclass from `make_gpu_forward_model` (engine double) called the way coreretOE calls it,
+    every route, vs the fixture;
+  * GPU: the recorded states as ONE batched call through the C-ABI -> KK vs the fixture, de-duplication on / off."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REF = "/root/reference"
+needs_reference = [pytest.mark.needs_reference,
+                   pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")]
+
+
+def _load(golden_dir):
+    return np.load(os.path.join(golden_dir, "jacobian_c1.npz"))
+
+
+def _kk_from_spectra(z, SPECOUT):
+    """Measurement vectors and KK from per-state spectra (nfm, NWAVE, 1) the reference's way: conv with FWHM = 0 is a
+    linear interpolation onto VCONV (Measurement_0.py:2330-2336), then the quotient of :2348-2359."""
+    Y = np.stack([np.interp(z["VCONV"], z["WAVE"], s[:, 0]) for s in SPECOUT], axis=1)
+    XN, inum = z["XN"], z["inum"]
+    KK = np.zeros((Y.shape[0], XN.size))
+    for i, ix in enumerate(inum):
+        xn1 = XN[ix] * 1.05
+        if xn1 == 0.0:
+            xn1 = 0.05
+        KK[:, ix] = (Y[:, i + 1] - Y[:, 0]) / (xn1 - XN[ix])
+    return Y, KK
+
+
+def _assert_kk(KK, z, tol, tight=None):
+    """Each free column against the fixture, relative to that column's largest element (the contract: 1e-4), plus the
+    floor a finite difference cannot go below: a few units of round-off of the spectrum divided by the step (the top
+    level's column is ten decades below the largest one -- its whole signal is 1e-12 of the radiance)."""
+    eps = np.finfo(float).eps
+    for ix in z["inum"]:
+        scale = np.abs(z["KK"][:, ix]).max()
+        assert scale > 0
+        floor = 64 * eps * np.abs(z["YN"]).max() / abs(0.05 * z["XN"][ix])
+        err = np.abs(KK[:, ix] - z["KK"][:, ix]).max()
+        assert err <= tol * scale + floor, (ix, err / scale)
+        if tight is not None and scale >= 1e-6 * np.abs(z["KK"]).max():       # measured: <= 3e-11 on these columns
+            assert err <= tight * scale, (ix, err / scale)
+    fixed = np.setdiff1d(np.arange(KK.shape[1]), z["inum"])
+    assert not KK[:, fixed].any()
+
+
+def test_fixture_is_what_the_reference_documents(golden_dir):
+    """Shape of the harness and the one reference quirk the fixture records: with NCores = 1 joblib runs
+    execute_fm in the caller's process, `Variables.XN` is left at the last perturbed state (:2154) and the last column's
+    quotient (:2355-2359) is formed with the perturbed value -> that column is the two-worker result / 1.05."""
+    z = _load(golden_dir)
+    NX = z["XN"].size
+    assert z["xnx"].shape == (NX, NX + 1) and z["KK"].shape == (40, NX) and z["YNtot"].shape == (40, 13)
+    assert np.array_equal(z["ixrun"], np.concatenate([[0], z["inum"] + 1]))
+    assert np.array_equal(z["xnx"][:, 0], z["XN"])
+    for i in z["inum"]:
+        assert z["xnx"][i, i + 1] == z["XN"][i] + 0.05 * z["XN"][i]
+    last = z["inum"][-1]
+    assert np.array_equal(z["KK_ncores1"][:, z["inum"][:-1]], z["KK"][:, z["inum"][:-1]])
+    np.testing.assert_allclose(z["KK_ncores1"][:, last] * 1.05, z["KK"][:, last], rtol=1e-12)
+    from archnemesis_dist_amd.jacobian import perturbed_states
+    assert np.array_equal(perturbed_states(z["XN"], 0.05 * z["XN"]), z["xnx"])       # the product's (:2234-2242)
+    Y, KK = _kk_from_spectra(z, z["SPECOUT"])             # the reference's own spectra through this file's quotient
+    np.testing.assert_allclose(Y, z["YNtot"], rtol=1e-13)
+    _assert_kk(KK, z, 1e-12)
+
+
+def test_oracle_chain_reproduces_the_reference_jacobian(oracle, golden_dir):
+    z = _load(golden_dir)
+    spec = [oracle.cirsrad_ck_thermal(int(z["ISPACE"]), z["K"], z["TPRESS"], z["TTEMP"], z["WAVE"], z["DELG"], z["LAY_PRESS"][m],
+                                      z["LAY_TEMP"][m], np.ascontiguousarray(z["LAY_AMOUNT"][m].T) * 1.0e-4, z["TAUCONT"][m],
+                                      z["NLAYIN"], z["LAYINC"], z["SCALE"][m], z["EMTEMP"][m], float(z["TSURF"]))
+            for m in range(z["LAY_PRESS"].shape[0])]
+    np.testing.assert_allclose(np.stack(spec), z["SPECOUT"], rtol=2e-7)       # float32 table grids: NumPy's float32 log
+    Y, KK = _kk_from_spectra(z, spec)
+    np.testing.assert_allclose(Y[:, 0], z["YN"], rtol=2e-7)
+    _assert_kk(KK, z, 1e-4)                                                    # contract; measured below
+
+
+@pytest.mark.gpu
+def test_gpu_batched_replay_of_the_reference_jacobian(golden_dir):
+    """The 13 forward models of the reference's run as ONE batched call through the C-ABI (layers shared with the
+    unperturbed state are not recomputed) -> KK within 1e-4 of each column (measured ~1e-7: finite differences amplify
+    the float32-log 2e-7 of the spectra), identical with de-duplication off."""
+    from archnemesis_dist_amd.engine import AnsfmEngine
+    z = _load(golden_dir)
+    eng = AnsfmEngine(0)
+    eng.upload_ktable(z["K"], z["TPRESS"], z["TTEMP"], z["WAVE"], z["DELG"])
+    amount = np.ascontiguousarray(np.transpose(z["LAY_AMOUNT"], (0, 2, 1))) * 1.0e-4
+    args = (int(z["ISPACE"]), z["LAY_PRESS"], z["LAY_TEMP"], amount, z["TAUCONT"], z["NLAYIN"], z["LAYINC"], z["SCALE"], z["EMTEMP"],
+            np.full(z["LAY_PRESS"].shape[0], float(z["TSURF"])))
+    spec = eng.cirsrad_ck_thermal(*args)
+    rows = eng.last_layer_rows()
+    np.testing.assert_allclose(spec, z["SPECOUT"], rtol=2e-7)
+    Y, KK = _kk_from_spectra(z, spec)
+    _assert_kk(KK, z, 1e-4)
+    assert rows[1] == 13 * 71 and 71 <= rows[0] < rows[1]      # hydrostatic re-adjustment moves the layers above a level
+    eng.set_layer_dedup(False)
+    try:
+        spec2 = eng.cirsrad_ck_thermal(*args)
+    finally:
+        eng.set_layer_dedup(True)
+    assert np.array_equal(spec, spec2)
+
+
+@pytest.fixture()
+def c1_cut(oracle, monkeypatch):
+    """The cut C1 case in a scratch directory, the reference imported, the adapter's engine replaced by the oracle double."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle.ref_import import import_reference
+    from oracle import gen_golden_jacobian as gj
+    from test_dropin_reference import OracleEngineDouble
+    import archnemesis_dist_amd.forward_model as fmod
+    ans = import_reference()
+    work = tempfile.mkdtemp(prefix="ansfm_jacdrop_")
+    gj.setup_c1(ans, work)
+    cwd = os.getcwd()
+    os.chdir(work)
+    double = OracleEngineDouble(oracle)
+    monkeypatch.setattr(fmod, "get_engine", lambda device=0: double)
+    fmod.set_strict(True)
+    fmod.reset_summary()
+    try:
+        yield ans, gj, fmod, double
+    finally:
+        fmod.set_strict(False)
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.parametrize("route", ["auto", "profile", "staged", "loop"])
+def test_jacobian_nemesis_through_the_subclass_matches_the_reference(c1_cut, golden_dir, route):
+    """What coreretOE does (OptimalEstimation_0.py:1318-1333): build the forward model, call jacobian_nemesis(NCores, ...).
+    The subclass takes it without joblib workers.  "auto" lands on the profile route here (one continuous temperature
+    profile; hydrostatic re-adjustment, CIA, aerosol and Rayleigh continuum are all inside it): one layer_average launch and
+    ONE batched CIRSrad call for the 13 states; "staged" runs the reference's subprofretg / calc_path per state and batches
+    CIRSrad; "loop" is execute_fm per column."""
+    ans, gj, fmod, double = c1_cut
+    z = _load(golden_dir)
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    fm = gj.cut_case(ans, cls=FMGPU)
+    fm.ansfm_jacobian_route = route
+    XN0 = np.array(fm.Variables.XN)
+    with pytest.warns(RuntimeWarning) if route == "loop" else _nullcontext():
+        YN, KK = fm.jacobian_nemesis(NCores=4, analytical_gradient=False)
+    info = fm.ansfm_last_jacobian
+    assert info["route"] == ("profile" if route == "auto" else route) and info["nfm"] == 13
+    assert np.array_equal(fm.Variables.XN, XN0)                # never left at a perturbed state
+    np.testing.assert_allclose(YN, z["YN"], rtol=2e-7)
+    _assert_kk(KK, z, 1e-4, tight=1e-8)
+    if route in ("auto", "profile"):
+        assert double.dev_batches == [13] and not getattr(double, "batch_sizes", [])
+    elif route == "staged":
+        assert double.batch_sizes == [13]
+    else:
+        assert not getattr(double, "batch_sizes", []) and any("NCores" in k for k in fmod.summary()["notes"])
+    assert fmod.summary()["delegated"] == {}
+
+
+class _nullcontext:
+    def __enter__(self): return None
+    def __exit__(self, *a): return False
+
+
+test_jacobian_nemesis_through_the_subclass_matches_the_reference = pytest.mark.needs_reference(
+    pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")(
+        test_jacobian_nemesis_through_the_subclass_matches_the_reference))
