@@ -54,7 +54,7 @@ def torch_ktable(torch, dev, W, G, NP, NT, S, seed):
     return PRESS.cpu().numpy(), TEMP.cpu().numpy(), K
 
 
-def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, delg, do_cpu):
+def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, delg, do_cpu, K_sample=None, PRESS=None, TEMP=None):
     """Numbers for the other BASELINE configs and the north-star variant, OUTSIDE the timed region of the headline
     metric (rank 0, one GPU).  Each entry says what it timed; profiles/README.md names the rocprofv3 run it can be
     reproduced from."""
@@ -120,6 +120,40 @@ def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, d
                                 "wavenumbers x 20 g x 100 layers, 16 streams, 36 phase moments, NF = 8, Rayleigh on, 1 limb-free path; "
                                 "gas opacities + TAUTOT/OMEGA/BB formed on the device", "wall_s": t, "ms_per_1000_nu": t * 1e2,
                         "chains_per_s": W * G * (NF + 1) / t}
+    # parity samples of the SAME full-size configuration (checker leg, outside any timing):
+    # (i) the non-scattering limit over all 1e4 wavenumbers: without scatterers the doubling / adding branch must return
+    #     the plane-parallel thermal emission of the same gas opacities under the quadrature angles (k_thermal_rt, SCALE = 1/mu)
+    pick = np.array([0, 5, 10, 15])
+    emi = np.rad2deg(np.arccos(MU[pick]))
+    ns = eng.cirsrad_ck_scatter(0, lay_p, lay_t, am, None, None, None, None, None, None, radg, np.full(pick.size, 40.0), emi,
+                                np.zeros(pick.size), np.zeros(W), 0, np.zeros((W, NMU, NMU, NF + 1)), MU, WT, NF, 101, 0, 0)
+    nl = np.full(pick.size, L, dtype=np.int32)
+    li = np.repeat(np.arange(L - 1, -1, -1, dtype=np.int32)[:, None], pick.size, 1)
+    th = eng.cirsrad_ck_thermal(0, lay_p, lay_t, am, None, nl, li, np.repeat((1.0 / MU[pick])[None, :], L, 0),
+                                np.repeat(lay_t[::-1][:, None], pick.size, 1), -1.0)
+    ex["c4_scatter"]["non_scattering_limit_max_rel_err_vs_thermal_rt"] = float(np.max(np.abs(ns - th) / th))
+    # (ii) the scattering configuration itself against the oracle's restatement of scloud11wave_core: the first four
+    #     wavenumbers at the first g-ordinate -- the Hansen renormalisation carries its factors from one (g, wavenumber) to
+    #     the next in loop order (g outer), so only a leading run of the sequence can be replayed without the whole call
+    if do_cpu and K_sample is not None:
+        from oracle import oracle as orc
+        nq = 4
+        t0 = time.perf_counter()
+        _, sg = eng.cirsrad_ck_scatter(0, lay_p, lay_t, am, None, TAUDUST, TAURAY, TAUSCAT, ph, np.ones((W, 1, L)), radg, [30.0],
+                                       [20.0], [45.0], np.full(W, 1e-8), 0, np.zeros((W, NMU, NMU, NF + 1)), MU, WT, NF, 101, 1, 1,
+                                       return_spec_g=True)
+        kk = orc.calc_k(K_sample[:nq], PRESS, TEMP, lay_p / 101325.0, lay_t)
+        tg = orc.k_overlap(delg, kk, am)
+        tautot = tg + TAUDUST[:nq, None, :] + TAURAY[:nq, None, :]
+        omega = np.where(tautot > 0, (TAURAY + TAUSCAT)[:nq, None, :] / np.where(tautot > 0, tautot, 1.0), 0.0)
+        bnu = c1 * WAVE[:nq, None] ** 3 / (np.exp(c2 * WAVE[:nq, None] / lay_t[None, :]) - 1.0)
+        rad = orc.scloud11wave_core(ph[:, :nq], radg[:nq], [30.0], [20.0], np.full(nq, 1e-8), [45.0], 0, np.zeros((nq, NMU, NMU, NF + 1)),
+                                    MU, WT, NF, WAVE[:nq], bnu, np.ascontiguousarray(tautot[:, 0:1, :]), TAURAY[:nq],
+                                    np.ascontiguousarray(omega[:, 0:1, :]), 101, 1, 1, np.ones((nq, 1, L)))
+        ref = rad[0, 0, :]
+        ex["c4_scatter"]["max_rel_err_vs_oracle"] = float(np.max(np.abs(sg[:nq, 0, 0] - ref) / np.abs(ref)))
+        ex["c4_scatter"]["oracle_sample"] = (f"{nq} (wavenumber, g) chains (first {nq} wavenumbers, first g-ordinate: 16 streams x {L} "
+                                             f"layers x {NF + 1} orders each) through oracle/ansfm_oracle_ms.c, {time.perf_counter() - t0:.1f} s")
 
     # ---- C5: runtime line-by-line, 1e6 wavenumbers x 50 layers x 1e5 lines (Voigt, windows 25 / 75 cm-1) --------------
     nw, N, Ll = 1000000, 100000, 50
@@ -138,6 +172,21 @@ def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, d
     ex["c5_lbl"] = {"what": "add_line_set_monochromatic_absorption at BASELINE configs[4] size (k_lbl_line_params + "
                             "k_lbl_accumulate), host arrays in / out (800 MB of PCIe inside wall_s)", "wall_s": t,
                     "profile_evaluations": evals, "Gevals_per_s": evals / t / 1e9}
+    if do_cpu:      # a slab of the same launch against the oracle's line loop (every line whose window reaches the slab)
+        from oracle import oracle as orc
+        o[:] = 0.0
+        fl()
+        i0, nsl = 431000, 2000
+        grid = wn[i0:i0 + nsl]
+        near = (nu > grid[0] - 75.5) & (nu < grid[-1] + 75.5)
+        err = 0.0
+        for l in (0, 24, 49):
+            ref = np.zeros(nsl)
+            orc.add_line_set_monochromatic_absorption(grid, 0, tt[l], 296.0, pp[l], 1.0, qq[l], 1.0, 28.0, np.array([1.0]), bp[:, near],
+                                                      nu[near], sw[near], el[near], sr[near], ref)
+            err = max(err, float(np.max(np.abs(o[l, i0:i0 + nsl] - ref) / ref)))
+        ex["c5_lbl"]["max_rel_err_vs_oracle"] = err
+        ex["c5_lbl"]["oracle_sample"] = f"{nsl} grid points x 3 layers of the full-size launch, {int(near.sum())} lines in reach"
     del o
 
     # ---- north-star variant: C2 with 20 gases (replaces the table in HBM: last) ----------------------------------------
@@ -364,6 +413,7 @@ def main():
             return jt, model.last_rows, YN, KK, km
 
         run_jac(True)                                   # warm-up: buffers of the batch sizes
+        run_jac(False)                                  # ... and of the all-layers call (first-touch allocation of 3.2 GB)
         jt_all, rows_all, YN_a, KK_a, _ = run_jac(False)
         reps = []                                       # median of five: the host side of a call (Python, NumPy, copies on a
         for _ in range(5):                              # shared box) varies 0.057 - 0.08 s while its kernels take the same 47 ms
@@ -403,6 +453,7 @@ def main():
     abytes = algorithmic_bytes(W, G, S, L, NP, NT, P, 1)
     traffic = None
     valu = None
+    traffic_src = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -410,10 +461,12 @@ def main():
             key = f"W{W}_G{G}_S{S}_L{L}"
             traffic = tj.get(key, {}).get("ck_overlap_hbm_bytes_per_launch")
             valu = tj.get(key, {}).get("valu_insts_per_launch")
+            traffic_src = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc pass (run %s), NOT measured in this run"
+                           % tj.get(key, {}).get("profile", "?"))
         except Exception:
             traffic = None
     roof = {"bound": "hbm", "kernel": "k_ck_overlap", "achieved": abytes / ov / 1e9, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": abytes / ov / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "unit": "GB/s", "frac": abytes / ov / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": abytes, "kernel_ms": ov * 1e3, "rt_kernel_ms": float(np.mean(rt_ms)),
             "note": "second bound (fp64 VALU of the per-lane G-way merge) dominates; see second_bound and DESIGN.md 4.1"}
     if valu:
@@ -425,7 +478,7 @@ def main():
         peak = n_simd * clk_hz / 4.0
         roof["second_bound"] = {"bound": "valu_issue", "insts_per_launch": valu, "achieved": valu / ov / 1e9,
                                 "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": valu / ov / peak,
-                                "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json (rocprofv3 --pmc pass) / live kernel time"}
+                                "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json, not this run) / live kernel time"}
 
     # ---- CPU baseline: the oracle (port) on a bounded sample, rank 0 only ---------------------------------
     cpu = None
@@ -455,7 +508,7 @@ def main():
     # ---- C3 check: a sample of KK columns against the reference's recipe run on the oracle's forward models -------
     if do_cpu and jac is not None:
         from oracle import jacobian_twin as twin
-        cols = np.array([npro // 8, npro // 2, npro + npro // 4, 2 * npro - 5])
+        cols = np.unique(np.concatenate([np.linspace(2, npro - 3, 8).astype(int), npro + np.linspace(2, npro - 3, 8).astype(int)]))
         t0 = time.perf_counter()
         y0, kk = twin.jacobian(model, K_sample, PRESS, TEMP, WAVE[:Wc], delg, columns=cols)
         sc = np.max(np.abs(kk), axis=0)
@@ -463,12 +516,12 @@ def main():
         nyc = kk.shape[0]
         jac["kk_max_rel_err_vs_oracle"] = float(np.max(np.abs(KK_j[:nyc, cols] - kk) / sc))
         jac["yn_max_rel_err_vs_oracle"] = float(np.max(np.abs(YN_j[:nyc] - y0) / np.abs(y0)))
-        jac["oracle_sample"] = (f"columns {cols.tolist()} of KK ({len(cols) + 1} oracle forward models at "
+        jac["oracle_sample"] = (f"columns {cols.tolist()} of KK (8 temperature levels, 8 ln VMR levels; {len(cols) + 1} oracle forward models at "
                                 f"{Wc} wavenumbers, {time.perf_counter() - t0:.1f} s); error relative to each column's maximum")
 
     extras = None
     if world == 1 and not args.no_extras and (W, G, S, L) == (10000, 20, 8, 100):
-        extras = run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, delg, do_cpu)
+        extras = run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, delg, do_cpu, K_sample, PRESS, TEMP)
 
     line = {
         "metric": "forward-models/sec (10k nu x 100 layers)", "value": value, "unit": "forward-models/s",
