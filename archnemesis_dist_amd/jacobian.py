@@ -87,21 +87,50 @@ def finite_difference_jacobian_dev(allY, XN, inum, FIX=None):
     return host[0].copy(), KK
 
 
-def jacobian_nemesis_batched(model, rank=0, world_size=1, group=None, force_collective=False, analytical_gradient=False):
+def gather_wavenumber_blocks(local_block, ny_local_all, rank, world_size, group=None, force=False):
+    """All-gather for the wavenumber-sharded mode: every rank holds ALL nfm forward models on ITS part of the spectral
+    axis, local_block (nfm, NY_local); ny_local_all = NY_local of every rank (ragged parts are padded to the largest).
+    -> (nfm, sum NY_local) on every rank, the parts side by side in rank order.  One collective."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1 and not force:
+        return local_block
+    nmax = int(max(ny_local_all))
+    nfm = local_block.shape[0]
+    pad = torch.zeros((nfm, nmax), dtype=local_block.dtype, device=local_block.device)
+    pad[:, : local_block.shape[1]] = local_block
+    out = torch.empty((world_size * nfm, nmax), dtype=local_block.dtype, device=local_block.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    out = out.view(world_size, nfm, nmax)
+    return torch.cat([out[r, :, : int(ny_local_all[r])] for r in range(world_size)], dim=1)
+
+
+def jacobian_nemesis_batched(model, rank=0, world_size=1, group=None, force_collective=False, analytical_gradient=False,
+                             shard="states"):
     """jacobian_nemesis (ForwardModel_0.py:2184-2361, numerical part) with every forward model of a rank in ONE batched
     call.  `model` offers the state (`model.state`: XN, NX, NUM, FIX, calc_DSTEP()) and `spectra_batch(X (n, NX)) ->
     torch (n, NY)` on its GPU (profile_state.BatchedCKThermalModel).
 
-    Rank r of n takes the reference's contiguous chunk of the nfm = NX_run + 1 forward models (:2322-2330).  A rank whose
-    chunk does not start with the unperturbed state puts it in front of its batch all the same: the engine shares every
-    layer that is bit-identical to the FIRST state of a batch, and every perturbed state is one step away from the
-    unperturbed one, not from its neighbour.  One all_gather of the (nfm_local, NY) blocks (RCCL over xGMI when the
-    backend is nccl), then KK on the device and a single copy to the host.
+    shard = "states": rank r of n takes the reference's contiguous chunk of the nfm = NX_run + 1 forward models
+    (:2322-2330).  A rank whose chunk does not start with the unperturbed state puts it in front of its batch all the same:
+    the engine shares every layer that is bit-identical to the FIRST state of a batch, and every perturbed state is one
+    step away from the unperturbed one, not from its neighbour.  One all_gather of the (nfm_local, NY) blocks (RCCL over
+    xGMI when the backend is nccl), then KK on the device and a single copy to the host.
+
+    shard = "wavenumbers": every rank runs ALL nfm states on its own part of the spectral axis -- `model` was built on the
+    rank's slice `chunk_range(NWAVE, n, r)` of the k-table (the table is split, not replicated: 1/n of the HBM and of the
+    upload per GPU) and returns (nfm, NY_local).  With layer de-duplication on, this is the mode that scales: in the state
+    mode every rank recomputes the ~L rows of the unperturbed state next to its 1/n of the ~3 nfm perturbed rows, here no
+    row is computed twice anywhere (every wavenumber is independent up to the ILS).  The quotient is formed per
+    rank and ONE all_gather of the (nfm, NY_local) blocks puts the parts side by side; `model.ny_local_all(world)` gives
+    the split.
 
     analytical_gradient=True (jacobian_nemesis's own switch, :2262-2289): one forward model with analytic gradients
     (`model.jacobian_analytic`, the nemesisfmg route) instead of nfm forward models.  There is nothing to shard: every
     rank computes the same (YN, KK)."""
     if analytical_gradient:
+        if not hasattr(model, "jacobian_analytic"):
+            raise NotImplementedError("jacobian_nemesis_batched: this model has no analytic-gradient route")
         return model.jacobian_analytic()
     V = model.state
     V.calc_DSTEP()
@@ -111,14 +140,31 @@ def jacobian_nemesis_batched(model, rank=0, world_size=1, group=None, force_coll
     nfm = len(inum) + 1
     ixrun = np.zeros(nfm, dtype="int32")
     ixrun[1:nfm] = inum[:] + 1
+    if shard == "wavenumbers":
+        Y = model.spectra_batch(np.ascontiguousarray(xnx[:, ixrun].T))          # (nfm, NY_local): every state, my wavenumbers
+        if Y is None:
+            raise RuntimeError(f"Something went wrong when calculating forward models 1-{nfm}/{nfm}.")
+        sizes = model.ny_local_all(world_size) if world_size > 1 else [Y.shape[1]]
+        allY = gather_wavenumber_blocks(Y, sizes, rank, world_size, group=group, force=force_collective)
+        return finite_difference_jacobian_dev(allY, XN, inum, FIX=np.asarray(V.FIX))
+    if shard != "states":
+        raise ValueError("shard must be 'states' or 'wavenumbers'")
     s, e = chunk_range(nfm, world_size, rank)
     cols = list(ixrun[s:e])
-    lead = 0 if (s == 0 or e == s) else 1           # the unperturbed state as the batch's de-duplication reference
-    X = xnx[:, [0] * lead + cols].T                 # (lead + nfm_local, NX)
-    Y = model.spectra_batch(np.ascontiguousarray(X))
-    if Y is None:
-        raise RuntimeError(f"Something went wrong when calculating forward models {s + 1}-{e}/{nfm}.")        # :2177
-    block = Y[lead:]
+    if e == s:                                      # more ranks than forward models: nothing to compute, an empty block to gather
+        import torch
+        ny = int(model.ny()) if hasattr(model, "ny") else None
+        if ny is None:
+            raise RuntimeError("jacobian_nemesis_batched: a rank without forward models needs model.ny() to join the gather")
+        dev = model.torch_device() if hasattr(model, "torch_device") else "cpu"
+        block = torch.zeros((0, ny), dtype=torch.float64, device=dev)
+    else:
+        lead = 0 if s == 0 else 1                   # the unperturbed state as the batch's de-duplication reference
+        X = xnx[:, [0] * lead + cols].T             # (lead + nfm_local, NX)
+        Y = model.spectra_batch(np.ascontiguousarray(X))
+        if Y is None:
+            raise RuntimeError(f"Something went wrong when calculating forward models {s + 1}-{e}/{nfm}.")        # :2177
+        block = Y[lead:]
     allY = gather_columns(block, nfm, rank, world_size, group=group, force=force_collective)
     return finite_difference_jacobian_dev(allY, XN, inum, FIX=np.asarray(V.FIX))
 
@@ -137,7 +183,8 @@ def jacobian_nemesis_sharded(fm, rank=0, world_size=1, device=None, analytical_g
     import torch
     if hasattr(fm, "spectra_batch"):                # a batched model: one call per rank instead of one per column
         return jacobian_nemesis_batched(fm, rank=rank, world_size=world_size, group=group,
-                                        analytical_gradient=analytical_gradient and hasattr(fm, "jacobian_analytic"))
+                                        analytical_gradient=analytical_gradient,       # raises when the model has no such route
+                                        shard=flags.pop("shard", "states"))
     V, M = fm.Variables, fm.Measurement
     if analytical_gradient:
         return fm.jacobian_nemesis(analytical_gradient=True, **flags)

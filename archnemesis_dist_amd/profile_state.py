@@ -92,6 +92,27 @@ class BatchedCKThermalModel:
                                                       NLAY=la["NLAY"], LAYTYP=la["LAYTYP"])
         self.last_rows = (0, 0)
 
+    # ---- what the sharded Jacobian asks of a model -----------------------------------------------------------------
+    def ny(self):
+        """length of a measurement vector of this model (its wavenumbers x paths)"""
+        return self.W * (layering.calc_path(self.RADIUS, self.BASEH, np.ones_like(self.BASEH), np.ones_like(self.BASEH),
+                                            float(self.state.H[-1]), **{k: self.geo[k] for k in ("pointing", "BOTLAY", "ANGLE",
+                                                                                                  "EMISS_ANG", "IPZEN")}).NPATH)
+
+    def torch_device(self):
+        import torch
+        return torch.device("cuda", self.eng.device)
+
+    def ny_local_all(self, world_size):
+        """wavenumber-sharded mode: NY of every rank when the table of `global_waves` wavenumbers is split with
+        jacobian.chunk_range (this model holds one of the parts)"""
+        from .jacobian import chunk_range
+        Wg = int(getattr(self, "global_waves", None) or 0)
+        if Wg <= 0:
+            raise ValueError("wavenumber-sharded mode: set model.global_waves to the length of the whole spectral grid")
+        P_ = self.ny() // self.W
+        return [(e - s) * P_ for s, e in (chunk_range(Wg, world_size, r) for r in range(world_size))]
+
     # ---- host part: subprofretg + calc_path for n states -------------------------------------------------------
     def layers(self, X):
         """X (n, NX) -> dict of per-state layer arrays (Layer_0 attributes after calc_layering) and the ray path."""

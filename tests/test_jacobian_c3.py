@@ -95,6 +95,59 @@ def test_batched_jacobian_gloo_world2(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+class _ToyModelSlice(_ToyModel):
+    """the toy model on a part of its 9 'wavenumbers' (rows of A / B): what a rank holds in the wavenumber-sharded mode"""
+    def __init__(self, log, rank, world):
+        from archnemesis_dist_amd.jacobian import chunk_range
+        super().__init__(log)
+        self.global_waves = 9
+        s, e = chunk_range(9, world, rank)
+        self.A, self.B = self.A[s:e], self.B[s:e]
+        self.world = world
+
+    def ny_local_all(self, world):
+        from archnemesis_dist_amd.jacobian import chunk_range
+        return [e - s for s, e in (chunk_range(9, world, r) for r in range(world))]
+
+
+def test_wavenumber_sharded_jacobian_gloo_world2(tmp_path):
+    """shard = "wavenumbers": both ranks run all 12 forward models on their part of the spectral axis (5 + 4 of 9 points,
+    ragged), one all_gather puts the parts side by side: KK bit-identical to the one-rank result, and a rank count larger
+    than the number of forward models no longer deadlocks the state mode (the empty chunk joins the gather)."""
+    script = textwrap.dedent(f'''
+        import os, sys
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+        import numpy as np, torch.distributed as dist
+        from archnemesis_dist_amd.jacobian import jacobian_nemesis_batched
+        from test_jacobian_c3 import _ToyModel, _ToyModelSlice
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        log = []
+        YN1, KK1 = jacobian_nemesis_batched(_ToyModel([]))                       # the whole axis on one rank
+        m = _ToyModelSlice(log, rank, world)
+        YN, KK = jacobian_nemesis_batched(m, rank=rank, world_size=world, shard="wavenumbers")
+        assert log == [12], log                                                  # every state on every rank, none twice
+        assert YN.shape == (9,) and KK.shape == (9, 12)
+        assert np.array_equal(YN, YN1) and np.array_equal(KK, KK1)
+        print("rank", rank, "ok")
+        dist.destroy_process_group()
+    ''')
+    f = tmp_path / "jw.py"
+    f.write_text(script)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29623", str(f)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
+
+
+def test_state_sharded_jacobian_with_more_ranks_than_forward_models():
+    """chunk arithmetic of a rank that gets no forward model: an empty (0, NY) block, no call into the engine"""
+    from archnemesis_dist_amd.jacobian import chunk_range
+    assert chunk_range(3, 4, 3) == (3, 3) and chunk_range(3, 4, 2) == (2, 3)
+
+
 def test_profile_state_model0_semantics():
     from archnemesis_dist_amd import synthetic as syn
     from archnemesis_dist_amd.profile_state import ContinuousProfileState
@@ -331,6 +384,47 @@ def test_lbl_wavenumber_split_gloo_world2(tmp_path):
 
 
 @pytest.mark.gpu
+def test_wavenumber_sharded_jacobian_parts_equal_the_whole():
+    """What the ranks of a wavenumber-sharded Jacobian compute, on one GPU: three engines (contexts) hold the three ragged
+    parts chunk_range(W, 3, r) of the k-table, each runs ALL states on its part; the parts side by side are the
+    one-engine spectra bit for bit (every wavenumber is independent), and together they computed exactly as many layer
+    rows as the one engine -- no row twice (in the state mode every rank repeats the unperturbed state's)."""
+    import archnemesis_dist_amd as pkg
+    from archnemesis_dist_amd import synthetic as syn
+    from archnemesis_dist_amd.jacobian import chunk_range, perturbed_states
+    from archnemesis_dist_amd.profile_state import ContinuousProfileState, BatchedCKThermalModel
+    W, G, S, NPRO, NLAY = 200, 10, 3, 12, 10
+    PRESS, TEMP, K = syn.synth_ktable(W, G, 6, 5, S, seed=19)
+    _, delg = syn.gauss_legendre_01(G)
+    WAVE = 450.0 + 0.5 * np.arange(W)
+    pr = syn.synth_profiles(NPRO, 5, seed=3)
+    extra = syn.synth_continuum(W, NLAY, seed=8)[0]
+
+    def build(w0, w1):
+        eng = pkg.AnsfmEngine(0)
+        eng.upload_ktable(np.ascontiguousarray(K[w0:w1]), PRESS, TEMP, WAVE[w0:w1], delg)
+        st = ContinuousProfileState(pr["H"], pr["P"], pr["T"], pr["VMR"], ["T", ("VMR", 3)])
+        return eng, BatchedCKThermalModel(eng, st, pr["RADIUS"], pr["ID"], pr["ISO"], [2, 3, 4], layering_args=dict(NLAY=NLAY),
+                                          IRAY=4, extra_continuum=extra[w0:w1])
+    eng0, whole = build(0, W)
+    X = perturbed_states(whole.state.XN, 0.05 * whole.state.XN).T
+    Y = whole.spectra_batch(X).cpu().numpy()
+    rows_whole = whole.last_rows
+    parts, rows = [], 0
+    for r in range(3):
+        w0, w1 = chunk_range(W, 3, r)
+        eng, m = build(w0, w1)
+        m.global_waves = W
+        assert m.ny_local_all(3)[r] == w1 - w0 == m.ny()
+        parts.append(m.spectra_batch(X).cpu().numpy())
+        assert m.last_rows == rows_whole          # the same rows per rank, each on a third of the wavenumbers
+        eng.close()
+    eng0.close()
+    assert np.array_equal(np.concatenate(parts, axis=1), Y)
+    assert rows_whole[0] < rows_whole[1] // 3     # de-duplication is on: most layers are shared with the unperturbed state
+
+
+@pytest.mark.gpu
 def test_rccl_collectives_under_a_one_rank_nccl_group(tmp_path):
     """The RCCL path of the Jacobian gather and of the wavenumber split, on the one GPU of this box: a fresh process
     initialises a 1-rank `nccl` process group BEFORE any other GPU call, then runs jacobian_nemesis_batched with the
@@ -359,6 +453,9 @@ def test_rccl_collectives_under_a_one_rank_nccl_group(tmp_path):
         YN1, KK1 = jacobian_nemesis_batched(model)
         YN2, KK2 = jacobian_nemesis_batched(model, force_collective=True)       # all_gather_into_tensor through RCCL
         assert np.array_equal(KK1, KK2) and np.array_equal(YN1, YN2) and np.abs(KK1).max() > 0
+        model.global_waves = W
+        YN3, KK3 = jacobian_nemesis_batched(model, force_collective=True, shard="wavenumbers")   # the other gather, same RCCL call
+        assert np.array_equal(KK1, KK3) and np.array_equal(YN1, YN3)
         # wavenumber split of a line-by-line model: world 1, the gather still goes through the collective path
         from test_jacobian_c3 import _lbl_case
         wn, nu, sw, el, sr, bp = _lbl_case(nw=3000, N=500)
