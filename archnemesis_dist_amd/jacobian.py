@@ -63,10 +63,21 @@ def gather_columns(local_block, nfm, rank, world_size, group=None, force=False):
     NY = local_block.shape[1]
     pad = torch.zeros((nmax, NY), dtype=local_block.dtype, device=local_block.device)
     pad[: local_block.shape[0]] = local_block
-    out = torch.empty((world_size * nmax, NY), dtype=local_block.dtype, device=local_block.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    out = _all_gather(pad, world_size, group)
     parts = [out[r * nmax: r * nmax + (e - s)] for r, (s, e) in enumerate(sizes)]
     return torch.cat(parts, dim=0)
+
+
+def _all_gather(pad, world_size, group):
+    """dist.all_gather_into_tensor of equal blocks along dim 0.  The gloo backend (CPU tests, the one-GPU rehearsal of the
+    N > 1 path) gathers host copies of device tensors; nccl (= RCCL) works on the device tensors themselves."""
+    import torch
+    import torch.distributed as dist
+    via_host = pad.is_cuda and dist.get_backend(group) == "gloo"
+    src = pad.cpu() if via_host else pad
+    out = torch.empty((world_size * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src.contiguous(), group=group)
+    return out.to(pad.device) if via_host else out
 
 
 def finite_difference_jacobian_dev(allY, XN, inum, FIX=None):
@@ -99,9 +110,7 @@ def gather_wavenumber_blocks(local_block, ny_local_all, rank, world_size, group=
     nfm = local_block.shape[0]
     pad = torch.zeros((nfm, nmax), dtype=local_block.dtype, device=local_block.device)
     pad[:, : local_block.shape[1]] = local_block
-    out = torch.empty((world_size * nfm, nmax), dtype=local_block.dtype, device=local_block.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
-    out = out.view(world_size, nfm, nmax)
+    out = _all_gather(pad, world_size, group).view(world_size, nfm, nmax)
     return torch.cat([out[r, :, : int(ny_local_all[r])] for r in range(world_size)], dim=1)
 
 

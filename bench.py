@@ -298,11 +298,19 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # ANSFM_BENCH_REHEARSAL=1 (tests only): every rank on GPU 0 and the gloo backend, so that the N > 1 code path can be run
+    # on a one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver; the line says so when it is.
+    rehearsal = os.environ.get("ANSFM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # launched by torch.distributed.run
     if use_dist:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     if not os.path.exists(pkg.LIB_PATH):        # source-only checkout: one rank compiles the library, the others wait for it
         if local_rank == 0:
             pkg.build()
@@ -332,6 +340,15 @@ def main():
     Wc = min(args.cpu_sample_waves, W)
     do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline      # contract: rank 0 at N = 1 only
     K_sample = Kdev[:Wc].cpu().numpy() if do_cpu else None
+    # N > 1: the Jacobian is sharded over the spectral axis (jacobian_nemesis_batched, shard = "wavenumbers"): a second
+    # context on this GPU holds this rank's slice chunk_range(W, N, rank) of the same table -- 1/N of it, not a replica
+    eng_j, wj0, wj1 = eng, 0, W
+    if world > 1 and not args.no_jacobian:
+        wj0, wj1 = chunk_range(W, world, rank)
+        eng_j = pkg.AnsfmEngine(local_rank)
+        eng_j.set_stream(stream.cuda_stream)
+        eng_j.upload_ktable(Kdev[wj0:wj1].contiguous(), PRESS, TEMP, WAVE[wj0:wj1], delg)
+        torch.cuda.synchronize()
     del Kdev
     torch.cuda.empty_cache()
 
@@ -376,7 +393,7 @@ def main():
         k = eng.last_kernel_ms()
         ov_ms.append(k["overlap_ms"]); rt_ms.append(k["rt_ms"])
     if use_dist:
-        t = torch.tensor([elapsed], dtype=f8, device=dev)
+        t = torch.tensor([elapsed], dtype=f8, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = world * args.steps / elapsed
@@ -395,19 +412,21 @@ def main():
         npro = (nj - 1) // 2
         pr = syn.synth_profiles(npro, S + 2, seed=11)
         st = ContinuousProfileState(pr["H"], pr["P"], pr["T"], pr["VMR"], ["T", ("VMR", 2)])
-        model = BatchedCKThermalModel(eng, st, pr["RADIUS"], pr["ID"], pr["ISO"], list(range(2, S + 2)),
+        model = BatchedCKThermalModel(eng_j, st, pr["RADIUS"], pr["ID"], pr["ISO"], list(range(2, S + 2)),
                                       layering_args=dict(NLAY=L, LAYINT=1, NINT=101), IRAY=4)
+        model.global_waves = W
+        shard = "wavenumbers" if world > 1 else "states"
 
         def run_jac(dedup):
-            eng.set_layer_dedup(dedup)
+            eng_j.set_layer_dedup(dedup)
             barrier()
             t0 = time.perf_counter()
-            YN, KK = jacobian_nemesis_batched(model, rank=rank, world_size=world, force_collective=use_dist)
+            YN, KK = jacobian_nemesis_batched(model, rank=rank, world_size=world, force_collective=use_dist, shard=shard)
             barrier()
             jt = time.perf_counter() - t0
-            km = eng.last_kernel_ms()
+            km = eng_j.last_kernel_ms()
             if use_dist:
-                t = torch.tensor([jt], dtype=f8, device=dev)
+                t = torch.tensor([jt], dtype=f8, device="cpu" if rehearsal else dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 jt = float(t.item())
             return jt, model.last_rows, YN, KK, km
@@ -421,15 +440,17 @@ def main():
             reps[-1] = reps[-1][:2] + ((None, None) if len(reps) < 5 else reps[-1][2:4]) + reps[-1][4:]   # keep one KK only
         jts = sorted(r[0] for r in reps)
         jt, rows, YN_j, KK_j = jts[2], reps[-1][1], reps[-1][2], reps[-1][3]
-        eng.set_layer_dedup(True)
-        jac = {"forward_models": st.NX + 1, "state_vector": f"T and ln(VMR) of one absorber at {npro} levels (NX = {st.NX}), "
+        eng_j.set_layer_dedup(True)
+        jac = {"forward_models": st.NX + 1, "sharding": ("spectral axis: every rank runs all forward models on its 1/%d of the "
+                                                          "wavenumbers (table split, not replicated)" % world) if world > 1 else None, "state_vector": f"T and ln(VMR) of one absorber at {npro} levels (NX = {st.NX}), "
                "through layer_average (Curtis-Godson, NINT 101) and the Rayleigh continuum",
                "wall_s": jt, "wall_s_five_calls": jts, "merge_kernel_ms_rank0": reps[-1][4]["overlap_ms"],
                "rt_kernel_ms_rank0": reps[-1][4]["rt_ms"], "fm_per_s": (st.NX + 1) / jt, "wall_s_all_layers": jt_all,
                "layer_opacities_computed_rank0": int(rows[0]), "layer_opacities_all_rank0": int(rows_all[0]),
                "dedup_bit_identical": bool(np.array_equal(KK_a, KK_j) and np.array_equal(YN_a, YN_j)),
                "kk_shape": list(KK_j.shape),
-               "collective": "all_gather_into_tensor (RCCL)" if use_dist else None}
+               "collective": ("one all_gather_into_tensor (%s) of the (nfm, NY / N) blocks" % ("gloo, REHEARSAL on one GPU" if rehearsal else "RCCL"))
+               if use_dist else None}
         if rank == 0 and world == 1:
             # the same state vector by analytic gradients (nemesisfmg's route: layer_averageg -> CIRSrad(return_grad) ->
             # map2pro -> map2xvec; jacobian_nemesis(analytical_gradient=True))

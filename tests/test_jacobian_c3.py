@@ -504,3 +504,26 @@ def test_bench_prints_one_json_line_under_torch_distributed_run():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["value"] > 0
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert "RCCL" in (d["jacobian"].get("collective") or "")
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """bench.py --gpus 2 the way the driver launches it, except that both ranks sit on this box's one GPU and talk through
+    gloo (ANSFM_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device): the N > 1 path -- per-rank forward models, the
+    Jacobian sharded over the spectral axis on a per-rank slice of the table, one all_gather -- runs end to end and gives
+    the KK shape of the whole axis."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", ANSFM_BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29643", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline",
+                        "--waves", "2000", "--jac-models", "21"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    j = d["jacobian"]
+    assert j["kk_shape"] == [2000, 20] and "spectral axis" in j["sharding"] and "REHEARSAL" in j["collective"]
+    assert j["dedup_bit_identical"] is True and j["layer_opacities_computed_rank0"] < j["layer_opacities_all_rank0"]

@@ -45,7 +45,11 @@ def main():
             torch.cuda.synchronize(); ph[name] = ph.get(name, 0.0) + time.perf_counter() - t0
             return r
         return g
+    from archnemesis_dist_amd import layering
     model.layers = timed("layers (profiles + layer_average + path)", model.layers)
+    eng.layer_average = timed("  of which eng.layer_average", eng.layer_average)
+    layering.calc_path = timed("  of which layering.calc_path", layering.calc_path)
+    st.profiles = timed("  of which state.profiles", st.profiles)
     eng.calc_tau_rayleigh_batch_dev = timed("rayleigh", eng.calc_tau_rayleigh_batch_dev)
     eng.cirsrad_ck_thermal_dev = timed("cirsrad (merge + rt)", eng.cirsrad_ck_thermal_dev)
     jac.finite_difference_jacobian_dev = timed("KK quotient + copy", jac.finite_difference_jacobian_dev)
