@@ -27,7 +27,7 @@ EXPORTS = [
     "ansfm_map2pro", "ansfm_map2xvec", "ansfm_layer_averageg", "ansfm_lblconv", "ansfm_lblconv_fil", "ansfm_lblconv_ngeom", "ansfm_lblconv_fil_ngeom", "ansfm_conv_fil", "ansfm_integrate_filter", "ansfm_calc_tau_rayleigh", "ansfm_calc_tau_dust", "ansfm_set_layer_dedup", "ansfm_last_layer_rows",
     "ansfm_ktable_file_header", "ansfm_upload_ktable_files", "ansfm_ktable_grids", "ansfm_lbltable_file_header",
     "ansfm_upload_lbltable_files", "ansfm_kdist_bins", "ansfm_calc_tau_cia", "ansfm_set_merge_keys", "ansfm_merge_redo_count", "ansfm_calc_tau_rayleigh_batch_dev", "ansfm_cirsrad_ck_scatter", "ansfm_thermal_emission_g", "ansfm_cirsrad_ck_transmission", "ansfm_cirsradg_ck_transmission", "ansfm_set_gradient_gases", "ansfm_set_shared_gas_gradient", "ansfm_singlescatt_plane_spectrum",
-    "ansfm_cirsrad_ck_singlescatt",
+    "ansfm_cirsrad_ck_singlescatt", "ansfm_cirsrad_ck_scatter_batch", "ansfm_last_scatter_cache",
 ]
 
 _lib = None
@@ -138,6 +138,11 @@ def load():
                                             vp, vp, vp, ci, ci, ci, vp, vp]
     lib.ansfm_cirsrad_ck_scatter.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, ci,
                                              vp, vp, ci, ci, ci, ci, vp, vp, vp]
+    # (ctx, ISPACE, n_models, L, press, temp, amount, cia, dust, ray, scat, ncont, nth, phasarr, lfrac, radg, ngeom, sol, emi, aphi,
+    #  solar, lowbc, brdf, nmu, mu1, wt1, nf, nphi, iray, imie, xfac, SPECOUT)
+    lib.ansfm_cirsrad_ck_scatter_batch.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci,
+                                                   vp, ci, vp, vp, ci, ci, ci, ci, vp, vp]
+    lib.ansfm_last_scatter_cache.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.ansfm_upload_lbltable.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, ci, vp]
     lib.ansfm_calc_klbl.argtypes = [vp, ci, vp, vp, vp, vp]
     lib.ansfm_add_line_set_monochromatic_absorption.argtypes = [vp, ci, vp, ci, ci, vp, cd, vp, cd, vp, cd, cd, ci, vp, ci, vp,

@@ -78,6 +78,8 @@ struct ansfm_ctx {
     int map_dims[4] = {0, 0, 0, 0};     // W, NPAR, NPRO, P of map_out
     DevBuf gscratch, perm, dkbuf, trold_ws, dspec_i, dcont_t, tmp_in2, tmp_out2, lbl_li;
     DevBuf ms_taus, ms_omegas, ms_bnu;   // scattering branch of CIRSrad: TAUTOT / OMEGA (W,G,L) and BB (W,L) in HBM
+    DevBuf ms_cache, ms_orders, ms_same; // batched scattering Jacobian: doubled layers of model 0, orders cached, layer flags
+    long ms_cache_hits = 0, ms_cache_layers = 0;   // (model, layer) pairs taken from the cache / all, last batch call
     DevBuf hb[24];  // staging buffers of the host-pointer entry points
     int last_n = 0, last_L = 0;
 
@@ -151,7 +153,8 @@ void ansfm_destroy(ansfm_ctx *ctx)
     DevBuf *bufs[] = {&ctx->lnK, &ctx->d_press, &ctx->d_temp, &ctx->d_wave, &ctx->d_delg, &ctx->d_flag,
                       &ctx->li, &ctx->tau, &ctx->scratch, &ctx->cont_t, &ctx->tmp_in, &ctx->tmp_out,
                       &ctx->misc, &ctx->gscratch, &ctx->dkbuf, &ctx->trold_ws, &ctx->dspec_i, &ctx->dcont_t,
-                      &ctx->tmp_in2, &ctx->tmp_out2, &ctx->lbl_li, &ctx->ms_taus, &ctx->ms_omegas, &ctx->ms_bnu, &ctx->dcont_gas};
+                      &ctx->tmp_in2, &ctx->tmp_out2, &ctx->lbl_li, &ctx->ms_taus, &ctx->ms_omegas, &ctx->ms_bnu, &ctx->dcont_gas,
+                      &ctx->ms_cache, &ctx->ms_orders, &ctx->ms_same};
     for (auto *b : bufs) b->release();
     for (auto &b : ctx->hb) b.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -2087,7 +2090,7 @@ int ansfm_kdist_bins(ansfm_ctx *ctx, int ncalc, const double *wavecalc, const do
 // angles are filled in here.  Leaves rad[ngeom][ng][nwave] in ctx->tmp_out (asynchronous).
 static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth, int ngeom, const double *sol_angs,
                      const double *emiss_angs, const double *aphis, int lowbc, int nmu, const double *mu1, const double *wt1,
-                     int nf, int ng, int nlay, int nphi, int iray, int imie)
+                     int nf, int ng, int nlay, int nphi, int iray, int imie, bool prepare_only = false)
 {
     if (nmu > 20 || ngeom > kMsMaxPath || ncont > 60)
         FAIL(ANSFM_ERR_UNSUPPORTED, "scloud11wave_core: nmu <= 20, npath <= 16 per call supported");
@@ -2099,6 +2102,7 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     p.ncont = ncont; p.ncomp = ncont + 1; p.nwave = nwave; p.nth = nth; p.ngeom = ngeom; p.lowbc = lowbc; p.nmu = nmu;
     p.nf = nf; p.ng = ng; p.nlay = nlay; p.nphi = nphi; p.iray = iray; p.imie = imie;
     p.lookup = (nmore == ngeom) ? 1 : 0;
+    p.w0 = 0; p.wcount = nwave; p.m0 = 0; p.n_launch = 1;      // one model, the whole spectral axis
     double xs = 0.0;
     for (int k = 0; k < nmu; ++k) { xs += mu1[k] * wt1[k]; p.mu[k] = mu1[nmu - 1 - k]; p.wtmu[k] = wt1[nmu - 1 - k]; }
     p.xfac = 0.5 / xs;                                          // :720-722
@@ -2130,6 +2134,15 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
         HIPCHK(hipGetLastError());
     }
     p.hansen_comp0 = 0;
+    if (prepare_only) {
+        // the batch path (ansfm_cirsrad_ck_scatter_batch) launches its own chains: phase matrices above, and the whole Hansen
+        // walk -- it depends on the phase functions only, not on the model -- in one launch
+        if (ncomp_run > 0) {
+            hipLaunchKernelGGL(k_ms_hansen_seq<16>, dim3((unsigned)ncomp_run), dim3(64), 0, ctx->stream, p);
+            HIPCHK(hipGetLastError());
+        }
+        return ANSFM_OK;
+    }
     if (nmu == 16) {
         // matrix-core products (v_mfma_f64_16x16x4_f64), 4 LDS matrices with leading dimension 17; one block per (wavenumber,
         // g) works through the Fourier orders and stops at the reference's convergence break (writes rad itself).
@@ -2335,6 +2348,210 @@ int ansfm_cirsrad_ck_scatter(ansfm_ctx *ctx, int ISPACE, int L, const double *la
     HIPCHK(hipMemcpyAsync(SPECOUT, d_spec, nspec * D, hipMemcpyDeviceToHost, ctx->stream));
     if (SPEC_G) HIPCHK(hipMemcpyAsync(SPEC_G, d_specg, nspec * G * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* batched scattering branch: the forward models of a numerical Jacobian (jacobian_nemesis :2251-2252)   */
+/* ------------------------------------------------------------------------------------------ */
+int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int L, const double *lay_press_pa,
+                                   const double *lay_temp, const double *amount, const double *taucia, const double *taudust,
+                                   const double *tauray, const double *tauscat, int ncont, int nth, const double *phasarr,
+                                   const double *lfrac, const double *radg, int ngeom, const double *sol_angs,
+                                   const double *emiss_angs, const double *aphis, const double *solar, int lowbc,
+                                   const double *brdf_matrix, int nmu, const double *mu1, const double *wt1, int nf, int nphi,
+                                   int iray, int imie, const double *xfac, double *SPECOUT)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "cirsrad_ck_scatter_batch: upload a k-table first");
+    if (ctx->is_lbl) FAIL(ANSFM_ERR_UNSUPPORTED, "cirsrad_ck_scatter_batch: k-tables only (ILBL = K_TABLES)");
+    if (n_models <= 0 || L <= 0 || !lay_press_pa || !lay_temp || !amount || ncont < 0 || ngeom <= 0 || nmu < 2 || nf < 0 ||
+        nphi <= 0 || !radg || !sol_angs || !emiss_angs || !aphis || !solar || !brdf_matrix || !mu1 || !wt1 || !SPECOUT ||
+        (ISPACE != 0 && ISPACE != 1) || (ncont > 0 && (!phasarr || !lfrac || nth < 3)))
+        FAIL(ANSFM_ERR_INVALID, "cirsrad_ck_scatter_batch: bad argument");
+    const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, S = ctx->S;
+    const size_t D = sizeof(double), WL = (size_t)W * L;
+    ctx->ms_cache_hits = 0; ctx->ms_cache_layers = (long)n_models * L;
+    const char *ev_off = getenv("ANSFM_MS_LAYER_CACHE");
+    const bool use_cache = nmu == 16 && n_models > 1 && ctx->dedup && !(ev_off && atoi(ev_off) == 0);
+    if (!use_cache) {
+        // other stream counts, a single model, or de-duplication switched off (ansfm_set_layer_dedup): model by model
+        for (int m = 0; m < n_models; ++m) {
+            auto at = [&](const double *a, size_t per) { return a ? a + (size_t)m * per : nullptr; };
+            const int rc = ansfm_cirsrad_ck_scatter(ctx, ISPACE, L, lay_press_pa + (size_t)m * L, lay_temp + (size_t)m * L,
+                                                    amount + (size_t)m * S * L, at(taucia, WL), at(taudust, WL), at(tauray, WL),
+                                                    at(tauscat, WL), ncont, nth, phasarr, at(lfrac, WL * ncont),
+                                                    radg + (size_t)m * W * nmu, ngeom, sol_angs, emiss_angs, aphis, solar, lowbc,
+                                                    brdf_matrix, nmu, mu1, wt1, nf, nphi, iray, imie, xfac,
+                                                    SPECOUT + (size_t)m * W * ngeom, nullptr);
+            if (rc) return rc;
+        }
+        ctx->last_n = n_models; ctx->last_L = L; ctx->last_rows = n_models * L; ctx->last_dedup = 0;
+        return ANSFM_OK;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const void *d[16];
+    int i = 0, rc;
+#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+    UP(lay_press_pa, (size_t)n_models * L * D);                 // 0
+    UP(lay_temp, (size_t)n_models * L * D);                     // 1
+    UP(amount, (size_t)n_models * S * L * D);                   // 2
+    UP(taucia, (size_t)n_models * WL * D);                      // 3
+    UP(taudust, (size_t)n_models * WL * D);                     // 4
+    UP(tauray, (size_t)n_models * WL * D);                      // 5
+    UP(tauscat, (size_t)n_models * WL * D);                     // 6
+    UP(phasarr, (size_t)ncont * W * 2 * nth * D);               // 7
+    UP(lfrac, (size_t)n_models * W * ncont * L * D);            // 8
+    UP(radg, (size_t)n_models * W * nmu * D);                   // 9
+    UP(solar, (size_t)W * D);                                   // 10
+    UP(brdf_matrix, (size_t)W * nmu * nmu * (nf + 1) * D);      // 11
+    UP(xfac, (size_t)W * D);                                    // 12
+#undef UP
+    const double *d_tauray = (const double *)d[5];
+    size_t st_wl = WL;
+    if (!d_tauray) {                                            // the chain kernels read TAURAY even when there is none
+        HIPCHK(ctx->cont_t.reserve(WL * D));
+        HIPCHK(hipMemsetAsync(ctx->cont_t.p, 0, WL * D, ctx->stream));
+        d_tauray = ctx->cont_t.as<double>();
+        st_wl = 0;
+    }
+    // ---- vertical gas opacities of the distinct (model, layer) rows: calc_k + k_overlap ---------------------------------
+    const size_t nl = (size_t)n_models * L;
+    HIPCHK(ctx->dd_slot.reserve(nl * sizeof(int32_t)));
+    HIPCHK(ctx->dd_work.reserve(nl * sizeof(int32_t)));
+    int *counter = ctx->d_flag.as<int>() + 12;
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_dedup_mark, dim3(nblk(nl, 128)), dim3(128), 0, ctx->stream, n_models, L, S, (const double *)d[0],
+                       (const double *)d[1], (const double *)d[2], ctx->dd_slot.as<int32_t>(), ctx->dd_work.as<int32_t>(), counter);
+    HIPCHK(hipGetLastError());
+    int extra = 0;
+    HIPCHK(hipMemcpyAsync(&extra, counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int rows = L + extra;
+    HIPCHK(ctx->dd_in.reserve((size_t)rows * (S + 2) * D));
+    double *pw = ctx->dd_in.as<double>(), *tw = pw + rows, *aw = tw + rows;
+    hipLaunchKernelGGL(k_dedup_gather, dim3(nblk((size_t)rows, 128)), dim3(128), 0, ctx->stream, rows, L, S,
+                       ctx->dd_work.as<int32_t>(), (const double *)d[0], (const double *)d[1], (const double *)d[2], pw, tw, aw);
+    HIPCHK(hipGetLastError());
+    HIPCHK(ctx->li.reserve((size_t)rows * sizeof(LayerInterp)));
+    HIPCHK(ctx->tau.reserve((size_t)rows * G * Wpad * D));
+    for (int pass = 0; pass < 2; ++pass) {
+        ctx->force_generic = pass;
+        HIPCHK(hipMemsetAsync(ctx->d_flag.as<int>() + 1, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_layer_prep, dim3(nblk((size_t)rows, 128)), dim3(128), 0, ctx->stream, rows, (const double *)pw,
+                           (const double *)tw, ctx->NP, ctx->d_press.as<double>(), ctx->NT, ctx->d_temp.as<double>(), 101325.0,
+                           ctx->grid_f32, ctx->li.as<LayerInterp>());
+        HIPCHK(hipGetLastError());
+        rc = launch_overlap(ctx, false, nullptr, W, Wpad, G, S, rows, 1, ctx->li.as<LayerInterp>(), aw, ctx->d_delg.as<double>(),
+                            ctx->h_delg.data(), ctx->tau.as<double>());
+        ctx->force_generic = 0;
+        if (rc) return rc;
+        int flag = 0;
+        if ((rc = read_unsorted(ctx, &flag))) return rc;
+        if (!flag) break;
+    }
+    ctx->last_n = n_models; ctx->last_L = L; ctx->last_rows = rows; ctx->last_dedup = 1;
+    // ---- which layers equal model 0's in EVERY input --------------------------------------------------------------------
+    HIPCHK(ctx->ms_same.reserve(nl));
+    unsigned char *same = ctx->ms_same.as<unsigned char>();
+    hipLaunchKernelGGL(k_ms_same_init, dim3(nblk(nl, 128)), dim3(128), 0, ctx->stream, n_models, L, ctx->dd_slot.as<int32_t>(), same);
+    for (int a = 3; a <= 6; ++a)
+        if (d[a])
+            hipLaunchKernelGGL(k_ms_same_cols, dim3(nblk((size_t)(n_models - 1) * W, 128)), dim3(128), 0, ctx->stream, n_models, W,
+                               1, L, (const double *)d[a], same);
+    if (d[8] && ncont > 0)
+        hipLaunchKernelGGL(k_ms_same_cols, dim3(nblk((size_t)(n_models - 1) * W * ncont, 128)), dim3(128), 0, ctx->stream,
+                           n_models, W, ncont, L, (const double *)d[8], same);
+    HIPCHK(hipGetLastError());
+    {
+        std::vector<unsigned char> hs(nl);
+        HIPCHK(hipMemcpyAsync(hs.data(), same, nl, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        long hits = 0;
+        for (size_t k = (size_t)L; k < nl; ++k) hits += hs[k];
+        ctx->ms_cache_hits = hits; ctx->ms_cache_layers = (long)(n_models - 1) * L;
+    }
+    // ---- phase matrices and Hansen factors: once, they do not depend on the model -----------------------------------------
+    MsParams p;
+    memset(&p, 0, sizeof p);
+    p.phasarr = (const double *)d[7]; p.radg = (const double *)d[9]; p.solar = (const double *)d[10];
+    p.brdf = (const double *)d[11]; p.tauray = d_tauray; p.lfrac = (const double *)d[8];
+    if ((rc = ms_launch(ctx, p, ncont, W, nth, ngeom, sol_angs, emiss_angs, aphis, lowbc, nmu, mu1, wt1, nf, G, L, nphi, iray,
+                        imie, true)))
+        return rc;
+    // ---- slabs of the spectral axis sized by the layer cache ----------------------------------------------------------------
+    const size_t per_w = (size_t)G * (nf + 1) * L * kMsCacheEntry * D;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    free_b += ctx->ms_cache.bytes;
+    size_t budget = std::min<size_t>(free_b / 2, (size_t)96 << 30);
+    long Ws = (long)(budget / per_w);
+    if (const char *ev = getenv("ANSFM_MS_SLAB")) { const long v = atol(ev); if (v >= 1) Ws = std::min(Ws, v); }
+    if (Ws < 1) FAIL(ANSFM_ERR_HIP, "cirsrad_ck_scatter_batch: no memory for the layer cache of one wavenumber");
+    if (Ws > W) Ws = W;
+    const int mchunk = std::min(n_models - 1, 64);
+    HIPCHK(ctx->ms_cache.reserve((size_t)Ws * per_w));
+    HIPCHK(ctx->ms_orders.reserve((size_t)Ws * G * sizeof(int)));
+    const size_t opt_models = (size_t)std::max(1, mchunk);
+    HIPCHK(ctx->ms_taus.reserve(opt_models * Ws * G * L * D));
+    HIPCHK(ctx->ms_omegas.reserve(opt_models * Ws * G * L * D));
+    HIPCHK(ctx->ms_bnu.reserve(opt_models * Ws * L * D));
+    HIPCHK(ctx->tmp_out.reserve((size_t)n_models * ngeom * G * W * D));
+    p.rad = ctx->tmp_out.as<double>();
+    p.taus = ctx->ms_taus.as<double>(); p.omegas = ctx->ms_omegas.as<double>(); p.bnu = ctx->ms_bnu.as<double>();
+    p.cache = ctx->ms_cache.as<double>(); p.cache_orders = ctx->ms_orders.as<int>(); p.same = same;
+    p.st_wl = st_wl; p.st_wcl = (size_t)W * ncont * L; p.st_wm = (size_t)W * nmu; p.st_rad = (size_t)ngeom * G * W;
+    p.phase_lds = 0; p.ig0 = 0; p.ng_launch = G;
+    MsOpticsBatchParams o;
+    memset(&o, 0, sizeof o);
+    o.taugas = ctx->tau.as<double>(); o.slot = ctx->dd_slot.as<int32_t>();
+    o.taucia = (const double *)d[3]; o.taudust = (const double *)d[4]; o.tauray = (const double *)d[5]; o.tauscat = (const double *)d[6];
+    o.wave = ctx->d_wave.as<double>(); o.lay_temp = (const double *)d[1];
+    o.taus = ctx->ms_taus.as<double>(); o.omegas = ctx->ms_omegas.as<double>(); o.bnu = ctx->ms_bnu.as<double>();
+    o.W = W; o.Wpad = Wpad; o.G = G; o.L = L; o.ispace = ISPACE;
+    const size_t lds16 = (4 * 16 * 17 + 5 * 16) * D;
+    for (long w0 = 0; w0 < W; w0 += Ws) {
+        const int wc = (int)std::min<long>(Ws, W - w0);
+        p.w0 = (int)w0; p.wcount = wc;
+        o.w0 = (int)w0; o.wcount = wc;
+        // model 0: the ordinary chain, which also fills the cache
+        o.m0 = 0; o.nm = 1;
+        hipLaunchKernelGGL(k_ms_optics_batch, dim3(nblk((size_t)wc, 128), (unsigned)L, 1), dim3(128), 0, ctx->stream, o);
+        p.m0 = 0; p.n_launch = 1;
+        hipLaunchKernelGGL((k_ms_chain16<false, 1>), dim3((unsigned)((size_t)wc * G)), dim3(64), lds16, ctx->stream, p);
+        HIPCHK(hipGetLastError());
+        // models 1 .. n-1 in chunks: the adding sweep over cached layers, changed layers computed in place
+        for (int m0 = 1; m0 < n_models; m0 += mchunk) {
+            const int nm = std::min(mchunk, n_models - m0);
+            o.m0 = m0; o.nm = nm;
+            hipLaunchKernelGGL(k_ms_optics_batch, dim3(nblk((size_t)wc, 128), (unsigned)L, (unsigned)nm), dim3(128), 0, ctx->stream, o);
+            p.m0 = m0; p.n_launch = nm;
+            const size_t pairs8 = ((size_t)wc * G + 7) / 8;
+            const size_t grid = pairs8 * 8 * (size_t)nm;
+            if (grid > 0x7FFFFFFFull) FAIL(ANSFM_ERR_UNSUPPORTED, "cirsrad_ck_scatter_batch: slab x models too large for one launch");
+            hipLaunchKernelGGL((k_ms_chain16<false, 2>), dim3((unsigned)grid), dim3(64), lds16, ctx->stream, p);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    // ---- g-quadrature (:4504), model by model ------------------------------------------------------------------------------
+    const size_t nspec = (size_t)W * ngeom;
+    HIPCHK(ctx->tmp_out2.reserve((size_t)n_models * nspec * D));
+    for (int m = 0; m < n_models; ++m)
+        hipLaunchKernelGGL(k_ms_gquad, dim3(nblk(nspec, 128)), dim3(128), 0, ctx->stream,
+                           ctx->tmp_out.as<double>() + (size_t)m * p.st_rad, ctx->d_delg.as<double>(), (const double *)d[12],
+                           ctx->tmp_out2.as<double>() + (size_t)m * nspec, (double *)nullptr, W, G, ngeom);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(SPECOUT, ctx->tmp_out2.p, (size_t)n_models * nspec * D, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ANSFM_OK;
+}
+
+int ansfm_last_scatter_cache(const ansfm_ctx *ctx, int64_t *layers_from_cache, int64_t *layers_total)
+{
+    if (!ctx) return ANSFM_ERR_INVALID;
+    if (layers_from_cache) *layers_from_cache = ctx->ms_cache_hits;
+    if (layers_total) *layers_total = ctx->ms_cache_layers;
     return ANSFM_OK;
 }
 

@@ -52,7 +52,17 @@ struct MsParams {
     int ig0, ng_launch;      // k_ms_hansen_seq / k_ms_chain16: the g-ordinates [ig0, ig0 + ng_launch) of this launch
     int phase_tab;           // k_ms_phase: the cos(ic phi) table fits in LDS (else the cosines are evaluated in place)
     int phase_lds;           // k_ms_chain16: the phase matrices of the components in use fit in LDS beside the operators
+    // Batched Jacobian of the scattering branch (ansfm_cirsrad_ck_scatter_batch; k_ms_chain16<.., CACHE>).  A launch covers
+    // the wavenumbers [w0, w0 + wcount) (0 / nwave outside the batch path); taus / omegas / bnu of such a launch are laid out
+    // [model of the launch][wcount][..] relative to w0, every other per-wavenumber array keeps the whole axis.
+    int w0, wcount;
+    int m0, n_launch;        // CACHE = 2: models [m0, m0 + n_launch) of the batch, one block per (model, wavenumber, g)
+    double *cache;           // [wcount][ng][nf+1][nlay][528]: doubled (r, t, j) of every scattering layer of model 0
+    int *cache_orders;       // [wcount][ng]: Fourier orders model 0 worked through (those are in the cache)
+    const unsigned char *same;   // [n_models][nlay]: the layer's inputs are bit-identical to model 0's
+    size_t st_wl, st_wcl, st_wm, st_rad;   // strides between models: tauray [W][L], lfrac [W][ncont][L], radg [W][nmu], rad
 };
+constexpr int kMsCacheEntry = 528;   // doubles per cached layer: r (256) and t (256) in the MFMA accumulator layout, j (16)
 
 __device__ __forceinline__ double ms_interp(double x, const double *xp, const double *fp, int n)
 {   // np.interp
@@ -745,7 +755,14 @@ __device__ __attribute__((noinline)) double ms_cos_ni(double x) { return cos(x);
 // onto r1 / t1 (4 instead of 6 LDS matrices) and a cap of 168 = three waves per SIMD, 0.59-0.60 s.  PHASE_LDS = true keeps the
 // phase matrices of the Fourier order in LDS (17.5 KB: nine blocks per CU, no spills); PHASE_LDS = false reads them from HBM / L2
 // in every layer (9.3 KB: twelve blocks, 65 registers spilled in the layer set-up) and is 2-4 % faster: the default.
-template <bool PHASE_LDS>
+// CACHE (the batched numerical Jacobian of the scattering configuration, ForwardModel_0.py:2251-2252: NX + 1 forward models
+// that differ from the first in a few layers): the doubled (r, t, j) of a layer (calc_rtj_matrix :566-650) depend on that
+// layer's inputs only and are 92 % of a chain's work (about twelve doublings of five products and an inverse each, against
+// one adding step).  CACHE = 1: model 0's pass stores them per (wavenumber, g, Fourier order, layer) -- in the accumulator
+// layout, 64 lanes x 8 doubles, coalesced -- and the number of orders it worked through.  CACHE = 2: one block per (model,
+// wavenumber, g) re-runs the adding sweep (addp :481-533) and takes every layer whose inputs are bit-identical to model 0's
+// from that cache; a changed layer, or an order beyond the cached ones, is computed as usual.  Same numbers either way.
+template <bool PHASE_LDS, int CACHE = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ms_chain16(MsParams p)
 {
     extern __shared__ double sm[];
@@ -753,8 +770,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     constexpr int n = 16, nn = 256, ld = 17, msz = 16 * 17;
     const Ms16 L{lane & 15, lane >> 4};
     const int c = L.c, q = L.q;
-    const int ig = p.ig0 + (int)(blockIdx.x % p.ng_launch);
-    const int widx = blockIdx.x / p.ng_launch;
+    int ig, widx, ml = 0;
+    if constexpr (CACHE == 2) {
+        // blocks of one (wavenumber, g) pair -- they read the same cache lines -- sit 8 apart in the launch order: consecutive
+        // workgroups go round the 8 XCDs, so the models of a pair share ONE XCD's L2
+        const long grp = (long)(blockIdx.x >> 3), slot = (long)(blockIdx.x & 7);
+        const long pair = (grp / p.n_launch) * 8 + slot;
+        ml = (int)(grp % p.n_launch);
+        if (pair >= (long)p.wcount * p.ng) return;
+        ig = (int)(pair % p.ng);
+        widx = p.w0 + (int)(pair / p.ng);
+    } else {
+        ig = p.ig0 + (int)(blockIdx.x % p.ng_launch);
+        widx = p.w0 + (int)(blockIdx.x / p.ng_launch);
+    }
+    const int wl = widx - p.w0, mg = p.m0 + ml;
+    int ncached = 0;
+    if constexpr (CACHE == 2) ncached = p.cache_orders[(size_t)wl * p.ng + ig];
+    int ndone = 0;
     const double pi = 3.141592653589793;
     // rc / tc: the stack below; r1 / t1: the layer's operators as LEFT operands (their right-operand form stays in registers).
     // The same two matrices are the scratch of the inverse and of the chained products (mA / mB): every step reads its left
@@ -793,7 +826,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             MS_AT(rc, i, j) = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * mu_c * wt_c) * p.xfac;
             MS_AT(tc, i, j) = 0.0;
         }
-        if (lane < n) jc[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];
+        if (lane < n) jc[lane] = p.radg[(size_t)mg * p.st_wm + (size_t)widx * n + (n - 1 - lane)];
         defined = true;
     }
     MS16_FENCE();
@@ -813,8 +846,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
 
     // the layer's scalars are fetched one layer ahead
-    const double *taus_w = p.taus + ((size_t)widx * p.ng + ig) * p.nlay, *omegas_w = p.omegas + ((size_t)widx * p.ng + ig) * p.nlay;
-    const double *bnu_w = p.bnu + (size_t)widx * p.nlay, *tauray_w = p.tauray + (size_t)widx * p.nlay;
+    const size_t wrow = (size_t)ml * p.wcount + wl;       // taus / omegas / bnu: [model of the launch][wavenumber of the slab]
+    const double *taus_w = p.taus + (wrow * p.ng + ig) * p.nlay, *omegas_w = p.omegas + (wrow * p.ng + ig) * p.nlay;
+    const double *bnu_w = p.bnu + wrow * p.nlay, *tauray_w = p.tauray + (size_t)mg * p.st_wl + (size_t)widx * p.nlay;
+    const double *lfrac_m = p.lfrac + (size_t)mg * p.st_wcl;
     const int kfirst = lookup ? p.nlay - 1 : 0;
     double n_taut = taus_w[kfirst], n_bc = bnu_w[kfirst], n_omega = omegas_w[kfirst], n_taur = tauray_w[kfirst];
     for (int l = 0; l < p.nlay; ++l) {
@@ -847,6 +882,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             for (int r = 0; r < 4; ++r) { MS_AT(r1, q + 4 * r, c) = 0.0; MS_AT(t1, q + 4 * r, c) = (q + 4 * r == c) ? tt : 0.0; }
             if (lane < n) j1[lane] = bc * (1.0 - tt);
             MS16_FENCE();
+        } else if (CACHE == 2 && ic < ncached && p.same[(size_t)mg * p.nlay + k]) {
+            // the layer of model 0, as its own pass left it (wave-uniform branch)
+            iscl = 1;
+            const double *ce = p.cache + ((((size_t)wl * p.ng + ig) * (p.nf + 1) + ic) * p.nlay + k) * kMsCacheEntry;
+            ms_v4f64 bR, bT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bR[r] = ce[r * 64 + lane]; bT[r] = ce[(4 + r) * 64 + lane]; }
+            const double jv = ce[512 + c];
+            L.store_d(r1, bR); L.store_d(t1, bT);
+            if (q == 0) j1[c] = jv;
+            MS16_FENCE();
         } else {
             iscl = 1;
             const double fr = taur / (tauscat + taur), fs = tauscat / (tauscat + taur);
@@ -864,7 +910,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     a = (p.iray > 0) ? fr * phl[((p.ncont * 2 + 0) * 4 + r) * 64 + lane] : 0.0;
                     b = (p.iray > 0) ? fr * phl[((p.ncont * 2 + 1) * 4 + r) * 64 + lane] : 0.0;
                     for (int cc = 0; cc < p.ncont; ++cc) {
-                        const double f = p.lfrac[((size_t)widx * p.ncont + cc) * p.nlay + k];
+                        const double f = lfrac_m[((size_t)widx * p.ncont + cc) * p.nlay + k];
                         a += fs * phl[((cc * 2 + 0) * 4 + r) * 64 + lane] * f;
                         b += fs * phl[((cc * 2 + 1) * 4 + r) * 64 + lane] * f;
                     }
@@ -877,7 +923,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     a = (p.iray > 0) ? fr * (at(PPL, p.ncont) * at(FC, p.ncont)) : 0.0;
                     b = (p.iray > 0) ? fr * at(PMI, p.ncont) : 0.0;
                     for (int cc = 0; cc < p.ncont; ++cc) {
-                        const double f = p.lfrac[((size_t)widx * p.ncont + cc) * p.nlay + k];
+                        const double f = lfrac_m[((size_t)widx * p.ncont + cc) * p.nlay + k];
                         a += fs * (at(PPL, cc) * at(FC, cc)) * f;
                         b += fs * at(PMI, cc) * f;
                     }
@@ -930,6 +976,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 L.store_d(r1, bR); L.store_d(t1, bT);
                 if (q == 0) j1[c] = jv;
                 MS16_FENCE();
+            }
+            if constexpr (CACHE == 1) {
+                double *ce = p.cache + ((((size_t)wl * p.ng + ig) * (p.nf + 1) + ic) * p.nlay + k) * kMsCacheEntry;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ce[r * 64 + lane] = bR[r]; ce[(4 + r) * 64 + lane] = bT[r]; }
+                if (q == 0) ce[512 + c] = jv;
             }
         }
         // ---- combine with the stack below :868-875 ------------------------------------------------------------
@@ -996,7 +1048,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
     }
     if (ic != 0 && lane < n) jc[lane] = 0.0;   // :881-882
-    if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // j1 is free until the next order's first layer
+    if (lane < n) radg[lane] = p.radg[(size_t)mg * p.st_wm + (size_t)widx * n + (n - 1 - lane)];   // j1 is free until the next order's first layer
     __syncthreads();
     if (lookup && p.lowbc > 0) {
         // idown (:366-420) with rb = rs, tb = 0, jb = radg (js is set for every ic, :822):
@@ -1062,10 +1114,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             fconv1 = (conv < 1e-5);
         }
     }
+    ++ndone;
     if (__builtin_amdgcn_ballot_w64(!fdone) == 0) break;
     __syncthreads();                                    // the LDS matrices are rebuilt by the next order
     }
-    if (lane < p.ngeom) p.rad[((size_t)lane * p.ng + ig) * p.nwave + widx] = frad;
+    if constexpr (CACHE == 1) { if (lane == 0) p.cache_orders[(size_t)wl * p.ng + ig] = ndone; }
+    if (lane < p.ngeom) p.rad[(size_t)mg * p.st_rad + ((size_t)lane * p.ng + ig) * p.nwave + widx] = frad;
 #undef MS_AT
 }
 
@@ -1129,6 +1183,63 @@ __global__ __launch_bounds__(128) void k_ms_optics(MsOpticsParams p)
     if (p.ispace == 0) { y = wv; a = c1 * (y * y * y); }
     else { y = 1.0e4 / wv; a = c1 * (y * y * y * y * y) / 1.0e4; }
     p.bnu[wl] = a / (exp(c2 * y / p.lay_temp[l]) - 1.0);
+}
+
+// The same for the models [m0, m0 + nm) of a batch on the wavenumbers [w0, w0 + wcount): the gas opacity of (model, layer)
+// is row slot[model][layer] of the merge kernel's output (rows shared with model 0 where the layer inputs are identical),
+// the continuum arrays carry a model axis, the outputs are laid out [model of the launch][wavenumber of the slab][..].
+struct MsOpticsBatchParams {
+    const double *taugas;       // [rows][G][Wpad]
+    const int32_t *slot;        // [n][L]
+    const double *taucia, *taudust, *tauray, *tauscat;   // [n][W][L] or null
+    const double *wave;         // [W]
+    const double *lay_temp;     // [n][L]
+    double *taus, *omegas;      // [nm][wcount][G][L]
+    double *bnu;                // [nm][wcount][L]
+    int W, Wpad, G, L, ispace, w0, wcount, m0, nm;
+};
+__global__ __launch_bounds__(128) void k_ms_optics_batch(MsOpticsBatchParams p)
+{
+    const int wl = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, ml = blockIdx.z;
+    if (wl >= p.wcount) return;
+    const int w = p.w0 + wl, m = p.m0 + ml;
+    const size_t in = ((size_t)m * p.W + w) * p.L + l;
+    const double cia = p.taucia ? p.taucia[in] : 0.0, dust = p.taudust ? p.taudust[in] : 0.0;
+    const double ray = p.tauray ? p.tauray[in] : 0.0, sca = p.tauscat ? p.tauscat[in] : 0.0;
+    const size_t row = (size_t)p.slot[(size_t)m * p.L + l];
+    const size_t wrow = (size_t)ml * p.wcount + wl;
+    for (int g = 0; g < p.G; ++g) {
+        const double tt = ((p.taugas[(row * p.G + g) * p.Wpad + w] + cia) + dust) + ray;             // the sum order of :3989
+        const size_t o = (wrow * p.G + g) * p.L + l;
+        p.taus[o] = tt;
+        p.omegas[o] = (tt > 0.0) ? (ray + sca) / tt : 0.0;
+    }
+    const double c1 = 1.1911e-12, c2 = 1.439;
+    const double wv = p.wave[w];
+    double y, a;
+    if (p.ispace == 0) { y = wv; a = c1 * (y * y * y); }
+    else { y = 1.0e4 / wv; a = c1 * (y * y * y * y * y) / 1.0e4; }
+    p.bnu[wrow * p.L + l] = a / (exp(c2 * y / p.lay_temp[(size_t)m * p.L + l]) - 1.0);
+}
+
+// same[m][l] = 1 when every input of layer l of model m is bit-identical to model 0's: the gas opacity row is shared (which
+// covers pressure, temperature and the gas amounts) ...
+__global__ void k_ms_same_init(int n_models, int L, const int32_t *__restrict__ slot, unsigned char *__restrict__ same)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_models * L) same[i] = (slot[i] == i % L) ? 1 : 0;
+}
+// ... and so are its columns of the (wavenumber, layer) arrays: arr [n][W][X][L] (X = 1 for the continuum opacities, ncont
+// for the aerosol fractions).  One thread per (model, wavenumber, x); a differing element clears the layer's flag.
+__global__ void k_ms_same_cols(int n_models, int W, int X, int L, const double *__restrict__ arr, unsigned char *__restrict__ same)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)W * X;
+    if (i >= (size_t)(n_models - 1) * per) return;
+    const size_t m = 1 + i / per, r = i % per;
+    const double *a = arr + (m * per + r) * L, *b = arr + r * L;
+    for (int l = 0; l < L; ++l)
+        if (__double_as_longlong(a[l]) != __double_as_longlong(b[l])) same[m * L + l] = 0;
 }
 
 // CIRSrad's g-quadrature of the scattering branch (:4504): SPECOUT[w][path] = xfac[w] * sum_g rad[path][g][w] * DELG[g];

@@ -457,6 +457,43 @@ class AnsfmEngine:
         self._check(rc, "cirsrad_ck_scatter")
         return (out, spec_g) if return_spec_g else out
 
+    def cirsrad_ck_scatter_batch(self, ISPACE, lay_press_pa, lay_temp, amount, TAUCIA, TAUDUST, TAURAY, TAUSCAT, phasarr, lfrac,
+                                 radg, sol_angs, emiss_angs, aphis, solar, lowbc, brdf_matrix, mu1, wt1, nf, nphi, iray, imie,
+                                 xfac=None):
+        """The scattering branch of CIRSrad for the n forward models of a numerical Jacobian (ansfm_cirsrad_ck_scatter_batch):
+        lay_press_pa / lay_temp (n, NLAY), amount (n, NGAS, NLAY), TAUCIA / TAUDUST / TAURAY / TAUSCAT (n, NWAVE, NLAY) or None,
+        lfrac (n, NWAVE, NDUST, NLAY), radg (n, NWAVE, NMU); the rest as `cirsrad_ck_scatter` -> SPECOUT (n, NWAVE, NPATH).
+        Layers whose inputs equal model 0's are taken from model 0's doubling results (`last_scatter_cache()`)."""
+        dims, _ = self.ktable_info()
+        W, G, S = dims[0], dims[1], dims[4]
+        lp = _np(lay_press_pa); n, L = lp.shape
+        am = _np(amount)
+        if am.shape != (n, S, L):
+            raise ValueError("amount must be (n_models, NGAS, NLAY)")
+        nwl = lambda a: None if a is None else _np(a).reshape(n, W, L)
+        phasarr = None if phasarr is None else _np(phasarr)
+        ncont = 0 if phasarr is None else phasarr.shape[0]
+        nth = 0 if phasarr is None else phasarr.shape[3]
+        sol = _np(np.atleast_1d(sol_angs)); emi = _np(np.atleast_1d(emiss_angs)); aph = _np(np.atleast_1d(aphis))
+        P = sol.shape[0]
+        mu1 = _np(mu1); nmu = mu1.shape[0]
+        lf = None if lfrac is None else _np(lfrac).reshape(n, W, ncont, L)
+        rg = _np(radg).reshape(n, W, nmu)
+        out = np.empty((n, W, P))
+        rc = self._lib.ansfm_cirsrad_ck_scatter_batch(
+            self._ctx, int(ISPACE), n, L, _ptr(lp), _ptr(_np(lay_temp).reshape(n, L)), _ptr(am), _ptr(nwl(TAUCIA)), _ptr(nwl(TAUDUST)),
+            _ptr(nwl(TAURAY)), _ptr(nwl(TAUSCAT)), ncont, nth, _ptr(phasarr), _ptr(lf), _ptr(rg), P, _ptr(sol), _ptr(emi), _ptr(aph),
+            _ptr(_np(solar)), int(lowbc), _ptr(_np(brdf_matrix)), nmu, _ptr(mu1), _ptr(_np(wt1)), int(nf), int(nphi), int(iray),
+            int(imie), _ptr(_np(xfac)), _ptr(out))
+        self._check(rc, "cirsrad_ck_scatter_batch")
+        return out
+
+    def last_scatter_cache(self):
+        """(layers of models 1..n-1 taken from model 0's doubling results, all such layers) of the last batched scatter call"""
+        a = C.c_int64(); b = C.c_int64()
+        self._check(self._lib.ansfm_last_scatter_cache(self._ctx, C.byref(a), C.byref(b)), "last_scatter_cache")
+        return int(a.value), int(b.value)
+
     def add_line_set_monochromatic_absorption(self, wn_grid, lineshape_id, t_calc, t_ref, p_calc, p_ref, q_ratio,
                                               isotopic_abundance, isotopic_mass, mol_mix_frac, broadening_params, nu, sw,
                                               e_lower, stimulated_emission_at_t_ref, out, store=None, s_floor=0.0,

@@ -383,10 +383,23 @@ class CIRSradGPU:
         else:
             PHASE[:, :, 0, :] = np.transpose(Sc.calc_phase(THETA, WAVE), (2, 0, 1))
         PHASE[:, :, 1, :] = np.cos(THETA * np.pi / 180)
-        return eng.cirsrad_ck_scatter(
-            ISPACE, np.asarray(L.PRESS, dtype=np.float64), np.asarray(L.TEMP, dtype=np.float64), f_gas, TAUCIA, TAUDUST,
-            TAURAY, TAUSCAT, np.ascontiguousarray(PHASE[:, :, :, ::-1]), FRAC, RADGROUND, P.SOL_ANG, P.EMISS_ANG, P.AZI_ANG,
-            solar, int(Su.LOWBC), BRDF, Sc.MU, Sc.WTMU, int(Sc.NF), int(Sc.NPHI), int(Sc.IRAY), int(Sc.IMIE))
+        args = dict(ISPACE=ISPACE, lp=np.array(L.PRESS, dtype=np.float64), lt=np.array(L.TEMP, dtype=np.float64), f_gas=f_gas,
+                    TAUCIA=np.asarray(TAUCIA, dtype=np.float64), TAUDUST=np.asarray(TAUDUST, dtype=np.float64),
+                    TAURAY=np.asarray(TAURAY, dtype=np.float64), TAUSCAT=np.asarray(TAUSCAT, dtype=np.float64),
+                    PHASE=np.ascontiguousarray(PHASE[:, :, :, ::-1]), FRAC=FRAC, RADGROUND=RADGROUND,
+                    SOL_ANG=np.array(P.SOL_ANG, dtype=np.float64).reshape(-1), EMISS_ANG=np.array(P.EMISS_ANG, dtype=np.float64).reshape(-1),
+                    AZI_ANG=np.array(P.AZI_ANG, dtype=np.float64).reshape(-1), solar=solar, LOWBC=int(Su.LOWBC), BRDF=BRDF,
+                    MU=np.array(Sc.MU, dtype=np.float64), WTMU=np.array(Sc.WTMU, dtype=np.float64), NF=int(Sc.NF), NPHI=int(Sc.NPHI),
+                    IRAY=int(Sc.IRAY), IMIE=int(Sc.IMIE))
+        if eng is None:                  # the staged Jacobian route keeps the arguments and batches the call
+            return args
+        return self._ansfm_scatter_call(eng, args)
+
+    @staticmethod
+    def _ansfm_scatter_call(eng, a):
+        return eng.cirsrad_ck_scatter(a["ISPACE"], a["lp"], a["lt"], a["f_gas"], a["TAUCIA"], a["TAUDUST"], a["TAURAY"], a["TAUSCAT"],
+                                      a["PHASE"], a["FRAC"], a["RADGROUND"], a["SOL_ANG"], a["EMISS_ANG"], a["AZI_ANG"], a["solar"],
+                                      a["LOWBC"], a["BRDF"], a["MU"], a["WTMU"], a["NF"], a["NPHI"], a["IRAY"], a["IMIE"])
 
     # ---- the seam ---------------------------------------------------------------------------------
     def CIRSrad(self, return_grad=False):

@@ -200,12 +200,14 @@ class JacobianGPU:
                 V.XN = xnx[:, col]                                                  # execute_fm :2154
                 for IAV in range(NAV):
                     self._ansfm_stage_one(IGEOM, IAV)
-                    rec = self._ansfm_thermal_inputs()
-                    if rec is None:                  # a CIRSrad branch without a batch axis: this state runs on its own
-                        rec = dict(alone=self.CIRSrad())
                     if int(self.PathX.NPATH) > 1:    # nemesisfm's several-paths branch (:521-527) fails on a shape mismatch
                         info["why_not_staged"] = "NPATH > 1"     # in the reference: let its own code say so ("loop")
                         return None
+                    rec = self._ansfm_thermal_inputs()
+                    if rec is None:
+                        rec = self._ansfm_scatter_inputs()
+                    if rec is None:                  # a CIRSrad branch without a batch axis: this state runs on its own
+                        rec = dict(alone=self.CIRSrad())
                     staged[k][IAV] = rec
             SPEC = np.zeros((len(states), W))
             for IAV in range(NAV):
@@ -271,6 +273,27 @@ class JacobianGPU:
             TSURF=float(self.SurfaceX.TSURF), emissivity=emissivity, xfac=xfac,
             SOL_ANG=np.asarray(P.SOL_ANG, dtype=np.float64).reshape(NPATH), EMISS_ANG=np.asarray(P.EMISS_ANG, dtype=np.float64).reshape(NPATH))
 
+    def _ansfm_scatter_inputs(self):
+        """What CIRSrad's multiple-scattering branch hands to the engine (CIRSradGPU._ansfm_cirsrad_scatter), kept instead of
+        run; None when the staged state is not on that branch."""
+        if not self._ansfm_supported(False):
+            return None
+        imod = int(np.unique(np.asarray(self.PathX.IMOD).astype(int))[0])
+        if not self._ansfm_scatter_branch(imod):
+            return None
+        TAUCIA, TAUDUST, TAURAY, _ = self._ansfm_continuum(False)
+        rec = self._ansfm_cirsrad_scatter(None, TAUCIA, TAUDUST, TAURAY, self._ansfm_layer_inputs())
+        rec["scatter"] = True
+        return rec
+
+    @staticmethod
+    def _ansfm_scatter_key(r):
+        """States that may share one batched scattering call: everything without a model axis in ansfm_cirsrad_ck_scatter_batch"""
+        b = lambda a: np.ascontiguousarray(a, dtype=np.float64).tobytes()
+        return ("scatter", r["ISPACE"], r["lp"].shape, r["PHASE"].shape, b(r["PHASE"]), b(r["SOL_ANG"]), b(r["EMISS_ANG"]),
+                b(r["AZI_ANG"]), b(r["solar"]), r["LOWBC"], b(r["BRDF"]), b(r["MU"]), b(r["WTMU"]), r["NF"], r["NPHI"], r["IRAY"],
+                r["IMIE"])
+
     @staticmethod
     def _ansfm_batch_key(r):
         """States that may share one batched call: same path structure and same per-wavenumber boundary vectors."""
@@ -285,13 +308,29 @@ class JacobianGPU:
         for k, r in enumerate(recs):
             if "alone" in r:
                 out[k] = np.asarray(r["alone"]).reshape(W, -1)
+            elif r.get("scatter"):
+                groups.setdefault(self._ansfm_scatter_key(r), []).append(k)
             else:
                 groups.setdefault(self._ansfm_batch_key(r), []).append(k)
         self._ansfm_upload_table(eng)
         rc = rt = 0
-        for ks in groups.values():
+        for key, ks in groups.items():
             r0 = recs[ks[0]]
             st = lambda name: np.stack([recs[k][name] for k in ks])
+            if key[0] == "scatter":
+                # the NX + 1 multiple-scattering forward models the reference runs when ISCAT != THERMAL_EMISSION (:2251-2252)
+                spec = eng.cirsrad_ck_scatter_batch(r0["ISPACE"], st("lp"), st("lt"), st("f_gas"), st("TAUCIA"), st("TAUDUST"),
+                                                    st("TAURAY"), st("TAUSCAT"), r0["PHASE"], st("FRAC"), st("RADGROUND"), r0["SOL_ANG"],
+                                                    r0["EMISS_ANG"], r0["AZI_ANG"], r0["solar"], r0["LOWBC"], r0["BRDF"], r0["MU"],
+                                                    r0["WTMU"], r0["NF"], r0["NPHI"], r0["IRAY"], r0["IMIE"])
+                spec = np.asarray(spec).reshape(len(ks), W, -1)
+                if hasattr(eng, "last_scatter_cache"):
+                    a, b = eng.last_scatter_cache()           # layers of models 1.. taken from model 0's doublings / all of them
+                    nlay = int(r0["lp"].shape[0])
+                    rc += (b - a) + nlay; rt += b + nlay
+                for j, k in enumerate(ks):
+                    out[k] = spec[j]
+                continue
             spec = eng.cirsrad_ck_thermal(r0["ISPACE"], st("lp"), st("lt"), st("f_gas"), st("taucont"), r0["NLAYIN"], r0["LAYINC"],
                                           st("SCALE"), st("EMTEMP"), np.array([recs[k]["TSURF"] for k in ks]),
                                           EMISSIVITY=r0["emissivity"], SOL_ANG=r0["SOL_ANG"], EMISS_ANG=r0["EMISS_ANG"], xfac=r0["xfac"])

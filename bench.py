@@ -54,7 +54,7 @@ def torch_ktable(torch, dev, W, G, NP, NT, S, seed):
     return PRESS.cpu().numpy(), TEMP.cpu().numpy(), K
 
 
-def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, delg, do_cpu, K_sample=None, PRESS=None, TEMP=None):
+def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, delg, do_cpu, K_sample=None, PRESS=None, TEMP=None, jac_model=None):
     """Numbers for the other BASELINE configs and the north-star variant, OUTSIDE the timed region of the headline
     metric (rank 0, one GPU).  Each entry says what it timed; profiles/README.md names the rocprofv3 run it can be
     reproduced from."""
@@ -154,6 +154,44 @@ def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, d
         ex["c4_scatter"]["max_rel_err_vs_oracle"] = float(np.max(np.abs(sg[:nq, 0, 0] - ref) / np.abs(ref)))
         ex["c4_scatter"]["oracle_sample"] = (f"{nq} (wavenumber, g) chains (first {nq} wavenumbers, first g-ordinate: 16 streams x {L} "
                                              f"layers x {NF + 1} orders each) through oracle/ansfm_oracle_ms.c, {time.perf_counter() - t0:.1f} s")
+
+    # ---- numerical Jacobian of the scattering configuration at C4 size: jacobian_nemesis forces NX + 1 multiple-scattering
+    #      forward models when ISCAT != THERMAL_EMISSION (ForwardModel_0.py:2251-2252) -- its most expensive case.  The state
+    #      vector of the C3 row (T and ln VMR of one absorber at 100 levels through Curtis-Godson layer_average), 201 forward
+    #      models in ONE ansfm_cirsrad_ck_scatter_batch call: model 0's doubled layers are cached per (wavenumber, g, order,
+    #      layer), the others re-run the adding sweep and recompute only the layers their level perturbation changed.
+    if jac_model is not None:
+        from archnemesis_dist_amd.jacobian import perturbed_states
+        stj = jac_model.state
+        Xj = perturbed_states(stj.XN, 0.05 * stj.XN).T
+        layj = jac_model.layers(Xj)
+        nj = Xj.shape[0]
+        rep = lambda a: np.ascontiguousarray(np.broadcast_to(a[None], (nj,) + a.shape))
+        radg_j = np.stack([np.repeat((c1 * WAVE ** 3 / (np.exp(c2 * WAVE / layj["TEMP"][m, 0]) - 1.0))[:, None], NMU, 1) for m in range(nj)])
+        tail = ([30.0], [20.0], [45.0], np.full(W, 1e-8), 0, np.zeros((W, NMU, NMU, NF + 1)), MU, WT, NF, 101, 1, 1)
+        aj = (0, layj["PRESS"], layj["TEMP"], layj["amount"], None, rep(TAUDUST), rep(TAURAY), rep(TAUSCAT), ph, rep(np.ones((W, 1, L))), radg_j)
+        t0 = time.perf_counter()
+        spec_j = eng.cirsrad_ck_scatter_batch(*aj, *tail)
+        tj = time.perf_counter() - t0
+        hits, tot = eng.last_scatter_cache()
+        rows_g = eng.last_layer_rows()
+        fs1 = lambda m: eng.cirsrad_ck_scatter(0, layj["PRESS"][m], layj["TEMP"][m], layj["amount"][m], None, TAUDUST, TAURAY, TAUSCAT, ph,
+                                               np.ones((W, 1, L)), radg_j[m], *tail)
+        t0 = time.perf_counter(); one0 = fs1(0); t_one = time.perf_counter() - t0
+        pick = [0, 37, 101, 163, nj - 1]
+        same = all(np.array_equal(fs1(m), spec_j[m]) for m in pick)
+        xn1 = stj.XN * 1.05
+        KKj = ((spec_j[1:, :, 0] - spec_j[0:1, :, 0]) / (xn1 - stj.XN)[:, None]).T
+        ex["c4_jacobian"] = {
+            "what": "numerical Jacobian of the C4 scattering configuration (1e4 wavenumbers x 20 g x 100 layers, 16 streams, NF = 8): "
+                    "%d multiple-scattering forward models (T and ln VMR of one absorber at 100 levels) in one "
+                    "ansfm_cirsrad_ck_scatter_batch call, host arrays in / out" % nj,
+            "forward_models": nj, "kk_shape": list(KKj.shape), "wall_s": tj, "s_per_forward_model": tj / nj,
+            "one_forward_model_on_its_own_s": t_one, "speedup_vs_separate_calls": t_one * nj / tj,
+            "layers_from_cache": int(hits), "layers_of_models_1_to_n": int(tot), "layers_doubled": int(tot - hits + L),
+            "layers_total": int(nj * L), "gas_opacity_rows_computed": int(rows_g[0]), "gas_opacity_rows_all": int(rows_g[1]),
+            "bit_identical_to_separate_calls": bool(same), "models_compared": pick}
+        del spec_j, aj, radg_j
 
     # ---- C5: runtime line-by-line, 1e6 wavenumbers x 50 layers x 1e5 lines (Voigt, windows 25 / 75 cm-1) --------------
     nw, N, Ll = 1000000, 100000, 50
@@ -542,7 +580,7 @@ def main():
 
     extras = None
     if world == 1 and not args.no_extras and (W, G, S, L) == (10000, 20, 8, 100):
-        extras = run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, delg, do_cpu, K_sample, PRESS, TEMP)
+        extras = run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, delg, do_cpu, K_sample, PRESS, TEMP, model)
 
     line = {
         "metric": "forward-models/sec (10k nu x 100 layers)", "value": value, "unit": "forward-models/s",

@@ -312,6 +312,28 @@ int ansfm_cirsrad_ck_scatter(ansfm_ctx *ctx, int ISPACE, int L, const double *la
                              const double *mu1, const double *wt1, int nf, int nphi, int iray, int imie, const double *xfac,
                              double *SPECOUT, double *SPEC_G);
 
+/* The same branch for the n_models forward models of a numerical Jacobian: jacobian_nemesis forces the numerical route
+ * whenever ISCAT != THERMAL_EMISSION (ForwardModel_0.py:2251-2252), i.e. NX + 1 multiple-scattering forward models that
+ * differ from the first in the few layers one state-vector element touches.  Arrays that depend on the state carry a
+ * leading model axis: lay_press_pa / lay_temp [n][L], amount [n][S][L], taucia / taudust / tauray / tauscat [n][W][L] (NULL =
+ * zeros), lfrac [n][W][ncont][L], radg [n][W][nmu]; phasarr, solar, brdf_matrix, xfac and the geometry are shared
+ * -> SPECOUT [n][W][ngeom].
+ * 16 streams: the doubled (R, T, J) of a layer (calc_rtj_matrix, Multiple_Scattering_Core.py:566-650) depend on that
+ * layer's inputs only and are ~92 % of a chain's work; model 0's pass keeps them per (wavenumber, g, Fourier order,
+ * layer) in HBM (slabs of the spectral axis sized to the free memory), every other model re-runs the adding sweep
+ * (addp :481-533) over them and recomputes only the layers whose inputs differ from model 0's in any bit -- the same
+ * numbers as n_models separate calls, bit for bit.  ansfm_set_layer_dedup(ctx, 0) (or another stream count) runs the
+ * models one after the other through ansfm_cirsrad_ck_scatter.  ansfm_last_scatter_cache: (model, layer) pairs taken
+ * from the cache / all pairs of models 1..n-1 in the last call; ansfm_last_layer_rows: gas opacity rows computed. */
+int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int L, const double *lay_press_pa,
+                                   const double *lay_temp, const double *amount, const double *taucia, const double *taudust,
+                                   const double *tauray, const double *tauscat, int ncont, int nth, const double *phasarr,
+                                   const double *lfrac, const double *radg, int ngeom, const double *sol_angs,
+                                   const double *emiss_angs, const double *aphis, const double *solar, int lowbc,
+                                   const double *brdf_matrix, int nmu, const double *mu1, const double *wt1, int nf, int nphi,
+                                   int iray, int imie, const double *xfac, double *SPECOUT);
+int ansfm_last_scatter_cache(const ansfm_ctx *ctx, int64_t *layers_from_cache, int64_t *layers_total);
+
 /* ---- runtime line-by-line (ILBL = LINE_BY_LINE_RUNTIME) -------------------------------------------
  * LineData_0.add_line_set_monochromatic_absorption (LineData_0.py:280-357), batched over L (T,p) points
  * (L = 1 is the reference's signature).  lineshape_id = SpectroscopicLineProfileEnum value: 0 VOIGT

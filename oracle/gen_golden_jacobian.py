@@ -26,10 +26,11 @@ NKEEP = 40                                                    # convolution poin
 FREE = (2, 9, 16, 23, 30, 37, 44, 51, 58, 65, 72, 79)         # state-vector elements left free (temperature levels)
 
 
-def setup_c1(ans, work, seed=1):
-    """Copies the C1 inputs to `work`, writes the synthetic .kta tables of gen_golden_c1.py there, points the .kls at them."""
+def setup_c1(ans, work, seed=1, case="Jupiter_CIRS_nadir_thermal_emission"):
+    """Copies the inputs of one of the reference's test cases to `work`, writes the synthetic .kta tables of gen_golden_c1.py
+    there, points the .kls at them."""
     sp_mod = sys.modules["archnemesis.Spectroscopy_0"]
-    src = os.path.join(REFERENCE_ROOT, "tests", "files", "Jupiter_CIRS_nadir_thermal_emission")
+    src = os.path.join(REFERENCE_ROOT, "tests", "files", case)
     for f in os.listdir(src):
         shutil.copy(os.path.join(src, f), os.path.join(work, f))
         os.chmod(os.path.join(work, f), 0o644)

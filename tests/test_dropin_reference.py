@@ -83,6 +83,16 @@ class OracleEngineDouble:
         out = np.tensordot(spec, np.asarray(D, dtype=float), axes=([1], [0]))
         return (out, spec) if return_spec_g else out
 
+    def cirsrad_ck_scatter_batch(self, ISPACE, lp, lt, am, TAUCIA, TAUDUST, TAURAY, TAUSCAT, phasarr, lfrac, radg, sol, emi, aph,
+                                 solar, lowbc, brdf, mu1, wt1, nf, nphi, iray, imie, xfac=None):
+        """ansfm_cirsrad_ck_scatter_batch: model by model through the single-model answer"""
+        n = np.shape(lp)[0]
+        self.scatter_batches = getattr(self, "scatter_batches", []) + [n]
+        at = lambda a, m: None if a is None else np.asarray(a)[m]
+        return np.stack([self.cirsrad_ck_scatter(ISPACE, lp[m], lt[m], am[m], at(TAUCIA, m), at(TAUDUST, m), at(TAURAY, m),
+                                                 at(TAUSCAT, m), phasarr, at(lfrac, m), radg[m], sol, emi, aph, solar, lowbc, brdf,
+                                                 mu1, wt1, nf, nphi, iray, imie, xfac=xfac) for m in range(n)])
+
     def cirsrad_ck_singlescatt(self, ISPACE, lp, lt, am, taucont, tausca, phase, NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMIS,
                                BRDF, SOLF, sol, emi, xfac=None):
         """ansfm_cirsrad_ck_singlescatt answered by the oracle's pieces (:3989, :4276-4283, :4006, :6509, :4504)."""

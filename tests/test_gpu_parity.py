@@ -1151,6 +1151,56 @@ def test_cirsrad_scatter_vs_oracle(eng, oracle, NMU, NF, ncont, imie, iray, lowb
     assert np.max(np.abs(out - ref)) / np.max(np.abs(ref)) < 1e-8
 
 
+@pytest.mark.parametrize("ncont,imie,iray,lowbc,up,slab", [(2, 0, 1, 0, False, None), (1, 1, 1, 1, False, 5), (1, 1, 0, 1, True, 7),
+                                                           (0, 0, 1, 0, False, 3)])
+def test_cirsrad_scatter_batch_equals_separate_calls(eng, monkeypatch, ncont, imie, iray, lowbc, up, slab):
+    """ansfm_cirsrad_ck_scatter_batch -- the forward models of a numerical Jacobian of the scattering configuration: model 0
+    plus models that differ from it in one or two layers (temperature, one gas amount, the aerosol opacity, the Rayleigh
+    opacity of a layer) and one that differs everywhere.  Model 0's doubled layers are cached, the others re-run the
+    adding sweep over them: every spectrum is bit-identical to a call of its own, with one slab and with several
+    (ANSFM_MS_SLAB), and the bookkeeping says which layers came from the cache."""
+    rng = np.random.default_rng(7700 + ncont + 3 * imie + 7 * lowbc)
+    W, G, L, S, NMU, NF = 20, 5, 9, 3, 16, 3
+    z = _scatter_inputs(rng, W, G, L, S, NMU, NF, max(ncont, 1), imie, iray, lowbc)
+    if ncont == 0:
+        z["TAUSCAT"] = np.zeros((W, L)); z["TAUDUST"] = 10.0 ** rng.uniform(-5, -3, (W, L))
+    sol = np.array([30.0, 120.0]); emi = np.array([160.0, 130.0]) if up else np.array([20.0, 50.0]); azi = np.array([45.0, 0.0])
+    eng.upload_ktable(z["K"], z["TPRESS"], z["TTEMP"], z["WAVE"], z["DELG"])
+    n = 7
+    rep = lambda a: np.repeat(np.asarray(a)[None], n, 0).copy()
+    lp, lt, am = rep(z["lay_p"]), rep(z["lay_t"]), rep(z["amount"])
+    cia, dust, ray, sca = rep(z["TAUCIA"]), rep(z["TAUDUST"]), rep(z["TAURAY"]), rep(z["TAUSCAT"])
+    lf, rg = rep(z["lfrac"]), rep(z["radg"])
+    lt[1, 4] *= 1.05                                   # a layer temperature (gas opacity and Planck function of that layer)
+    am[2, 1, 6] *= 1.05                                # a gas amount
+    sca[3, :, 3] *= 1.05; dust[3, :, 3] *= 1.05        # the aerosol of a layer
+    ray[4, :, 0] *= 1.05                               # Rayleigh opacity of the bottom layer
+    lt[5, 0] *= 1.02; rg[5] *= 1.1                     # bottom temperature: layer 0 and the lower boundary radiance
+    lt[6] *= 1.01; am[6] *= 1.03                       # everything: nothing can come from the cache
+    common = (z["phasarr"] if ncont else None,)
+    tail = (sol, emi, azi, z["solar"], lowbc, z["brdf"], z["MU"], z["WT"], NF, 101, iray, imie)
+    one = lambda m: eng.cirsrad_ck_scatter(0, lp[m], lt[m], am[m], cia[m], dust[m], ray[m] if iray else None, sca[m], common[0],
+                                           lf[m] if ncont else None, rg[m], *tail)
+    ref = np.stack([one(m) for m in range(n)])
+    if slab is not None:
+        monkeypatch.setenv("ANSFM_MS_SLAB", str(slab))
+    got = eng.cirsrad_ck_scatter_batch(0, lp, lt, am, cia, dust, ray if iray else None, sca, common[0], lf if ncont else None, rg, *tail)
+    assert np.array_equal(got, ref)
+    hits, total = eng.last_scatter_cache()
+    assert total == (n - 1) * L
+    changed = 1 + 1 + 1 + (1 if iray else 0) + 1 + L   # layers that differ from model 0, per model 1..6
+    assert hits == total - changed
+    rows, allrows = eng.last_layer_rows()
+    assert allrows == n * L and rows == L + 1 + 1 + 0 + 0 + 1 + L          # gas opacity rows: T / amount changes only
+    eng.set_layer_dedup(False)                         # model by model through the single entry point
+    try:
+        again = eng.cirsrad_ck_scatter_batch(0, lp, lt, am, cia, dust, ray if iray else None, sca, common[0], lf if ncont else None,
+                                             rg, *tail)
+    finally:
+        eng.set_layer_dedup(True)
+    assert np.array_equal(again, ref)
+
+
 def test_cirsrad_scatter_fine_azimuth_grid_vs_oracle(eng, oracle):
     """NPHI = 701 with NF = 8: the cos(ic phi) table of k_ms_phase (56 KB) does not fit its LDS budget, the cosines are
     evaluated in place -- same sums as the table path and as the oracle."""

@@ -20,8 +20,8 @@ needs_reference = [pytest.mark.needs_reference,
                    pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")]
 
 
-def _load(golden_dir):
-    return np.load(os.path.join(golden_dir, "jacobian_c1.npz"))
+def _load(golden_dir, name="jacobian_c1.npz"):
+    return np.load(os.path.join(golden_dir, name))
 
 
 def _kk_from_spectra(z, SPECOUT):
@@ -114,6 +114,61 @@ def test_gpu_batched_replay_of_the_reference_jacobian(golden_dir):
     assert np.array_equal(spec, spec2)
 
 
+# ---- the scattering configuration: ISCAT = 1 forces the numerical route (ForwardModel_0.py:2251-2252) -------------------------
+def _scatter_oracle_spectra(oracle, z):
+    """CIRSrad's scattering branch for every recorded forward model through the oracle's restatements (calc_k + k_overlap,
+    TAUTOT :3989, OMEGA / BB :5099-5119, scloud11wave_core, g-quadrature :4504)."""
+    out = []
+    for m in range(z["LAY_PRESS"].shape[0]):
+        k = oracle.calc_k(z["K"], z["TPRESS"], z["TTEMP"], z["LAY_PRESS"][m] / 101325.0, z["LAY_TEMP"][m])
+        tg = oracle.k_overlap(z["DELG"], k, np.ascontiguousarray(z["LAY_AMOUNT"][m].T) * 1.0e-4)
+        tautot = tg + z["TAUCIA"][m][:, None, :] + z["TAUDUST"][m][:, None, :] + z["TAURAY"][m][:, None, :]
+        omega = np.zeros_like(tautot)
+        pos = tautot > 0
+        omega[pos] = np.broadcast_to((z["TAURAY"][m] + z["TAUSCAT"][m])[:, None, :], tautot.shape)[pos] / tautot[pos]
+        bnu = np.stack([oracle.planck(int(z["ISPACE"]), z["WAVE"], t) for t in z["LAY_TEMP"][m]], axis=1)
+        rad = oracle.scloud11wave_core(z["PHASARR"][m], z["RADG"][m], z["SOL_ANG"], z["EMISS_ANG"], z["SOLAR"], z["AZI_ANG"],
+                                       int(z["LOWBC"]), z["BRDF"], z["MU"], z["WTMU"], int(z["NF"]), z["WAVE"], bnu, tautot,
+                                       z["TAURAY"][m], omega, int(z["NPHI"]), int(z["IRAY"]), int(z["IMIE"]), z["LFRAC"][m])
+        out.append(np.tensordot(np.transpose(rad, (2, 1, 0)), np.asarray(z["DELG"], dtype=float), axes=([1], [0])))
+    return np.stack(out)
+
+
+def test_scattering_fixture_and_oracle_chain(oracle, golden_dir):
+    """jacobian_c4.npz: the reference's jacobian_nemesis on its multiple-scattering inputs (three temperature levels, two
+    parameters of the aerosol profile; six multiple-scattering forward models).  The oracle's chain on the recorded inputs
+    gives the reference's spectra and, through the quotient, its KK."""
+    z = _load(golden_dir, "jacobian_c4.npz")
+    assert int(z["IMOD"][0]) & 256 and z["KK"].shape == (6, 92) and z["SPECOUT"].shape[0] == 6
+    Y, KK = _kk_from_spectra(z, z["SPECOUT"])
+    np.testing.assert_allclose(Y, z["YNtot"], rtol=1e-13)
+    _assert_kk(KK, z, 1e-12)
+    spec = _scatter_oracle_spectra(oracle, z)
+    np.testing.assert_allclose(spec, z["SPECOUT"], rtol=5e-7)          # float32 table grids (2e-7 on k) through the core
+    _assert_kk(_kk_from_spectra(z, spec)[1], z, 1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_batched_scattering_jacobian_replays_the_reference(golden_dir):
+    """The six multiple-scattering forward models of the reference's run as ONE ansfm_cirsrad_ck_scatter_batch call -> KK within
+    1e-4 of each column of the reference's; every spectrum equal to a call of its own, bit for bit."""
+    from archnemesis_dist_amd.engine import AnsfmEngine
+    z = _load(golden_dir, "jacobian_c4.npz")
+    eng = AnsfmEngine(0)
+    eng.upload_ktable(z["K"], z["TPRESS"], z["TTEMP"], z["WAVE"], z["DELG"])
+    amount = np.ascontiguousarray(np.transpose(z["LAY_AMOUNT"], (0, 2, 1))) * 1.0e-4
+    tail = (z["SOL_ANG"], z["EMISS_ANG"], z["AZI_ANG"], z["SOLAR"], int(z["LOWBC"]), z["BRDF"], z["MU"], z["WTMU"], int(z["NF"]),
+            int(z["NPHI"]), int(z["IRAY"]), int(z["IMIE"]))
+    spec = eng.cirsrad_ck_scatter_batch(int(z["ISPACE"]), z["LAY_PRESS"], z["LAY_TEMP"], amount, z["TAUCIA"], z["TAUDUST"], z["TAURAY"],
+                                        z["TAUSCAT"], z["PHASARR"][0], z["LFRAC"], z["RADG"], *tail)
+    np.testing.assert_allclose(spec, z["SPECOUT"], rtol=5e-7)
+    _assert_kk(_kk_from_spectra(z, spec)[1], z, 1e-4)
+    for m in range(spec.shape[0]):
+        one = eng.cirsrad_ck_scatter(int(z["ISPACE"]), z["LAY_PRESS"][m], z["LAY_TEMP"][m], amount[m], z["TAUCIA"][m], z["TAUDUST"][m],
+                                     z["TAURAY"][m], z["TAUSCAT"][m], z["PHASARR"][0], z["LFRAC"][m], z["RADG"][m], *tail)
+        assert np.array_equal(one, spec[m])
+
+
 @pytest.fixture()
 def c1_cut(oracle, monkeypatch):
     """The cut C1 case in a scratch directory, the reference imported, the adapter's engine replaced by the oracle double."""
@@ -178,3 +233,31 @@ class _nullcontext:
 test_jacobian_nemesis_through_the_subclass_matches_the_reference = pytest.mark.needs_reference(
     pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")(
         test_jacobian_nemesis_through_the_subclass_matches_the_reference))
+
+
+def _scattering_dropin(c1_cut, golden_dir, route):
+    import shutil
+    ans, gj, fmod, double = c1_cut
+    from oracle import gen_golden_jacobian_ms as gm
+    z = _load(golden_dir, "jacobian_c4.npz")
+    work = os.getcwd()
+    gj.setup_c1(ans, work, seed=4, case=gm.CASE)                # the scattering inputs over the scratch directory
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    fm = gj.cut_case(ans, cls=FMGPU, nkeep=gm.NKEEP, free=gm.FREE)
+    fm.ansfm_jacobian_route = route
+    YN, KK = fm.jacobian_nemesis(NCores=1, analytical_gradient=True)      # ISCAT = 1: numerical whatever is asked (:2251)
+    info = fm.ansfm_last_jacobian
+    assert info["nfm"] == 6 and info["analytic_columns"] == 0
+    np.testing.assert_allclose(YN, z["YN"], rtol=5e-7)
+    _assert_kk(KK, z, 1e-4, tight=1e-6)
+    return info, double
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_scattering_jacobian_through_the_subclass_matches_the_reference(c1_cut, golden_dir):
+    """ISCAT = MULTIPLE_SCATTERING: `auto` cannot take the profile route (scattering, an aerosol model) and lands on the staged
+    one -- the reference's subprofretg / calc_path / continuum per state, then ONE batched scattering call for the six
+    forward models (here: the engine double) -- with the reference's KK."""
+    info, double = _scattering_dropin(c1_cut, golden_dir, "auto")
+    assert info["route"] == "staged" and double.scatter_batches == [6]
