@@ -1240,7 +1240,8 @@ static int launch_overlapg(ansfm_ctx *ctx, bool from_k, const double *kin, const
     pg.dk = dk;
     pg.gas_mask = from_k ? 0xFFFFFFFFu : ctx->grad_gas_mask;      // the array-level seam returns every slot
     const int NP1 = S + 1;
-    if (NP1 > 21) FAIL(ANSFM_ERR_UNSUPPORTED, "gradient path supports at most 20 spectroscopic gases");
+    // the gas selection mask (ansfm_set_gradient_gases) has one bit per gas and bit 31 for temperature
+    if (NP1 > 32) FAIL(ANSFM_ERR_UNSUPPORTED, "gradient path supports at most 31 spectroscopic gases");
     // fast path: every k(g) non-decreasing (tables: checked at upload; array-level seam: in the kernel, rerun otherwise)
     const bool sorted = !ctx->force_generic && (from_k || ctx->monotone);
     ctx->force_generic = 0;            // one-shot request of the rerun wrappers: never survives an error return
@@ -1318,7 +1319,7 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
     if (n_models <= 0 || L <= 0 || P <= 0 || LIMAX <= 0 || !lay_press_pa || !lay_temp || !amount || !NLAYIN || !LAYINC ||
         !SCALE || !EMTEMP || !TSURF || !SPECOUT || !dSPECOUT || !dTSURF || !igas_map_host || NPAR <= 0 ||
         NPAR > kMaxPar || NVMR < 0 || NVMR >= NPAR || (ISPACE != 0 && ISPACE != 1))
-        FAIL(ANSFM_ERR_INVALID, "cirsradg: bad argument (NPAR <= 64)");
+        FAIL(ANSFM_ERR_INVALID, "cirsradg: bad argument (NPAR <= 256)");
     HIPCHK(hipSetDevice(ctx->device));
     const int W = ctx->W, Wpad = ctx->Wpad, G = ctx->G, S = ctx->S, NP1 = S + 1;
     HIPCHK(ctx->li.reserve((size_t)n_models * L * sizeof(LayerInterp)));
@@ -1390,7 +1391,8 @@ int ansfm_cirsradg_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int 
     for (int k = 0; k < kMaxPar; ++k) q.slot_of_param[k] = -1;
     for (int i = 0; i < S; ++i) {   // assignment order of :3868-3870: a later gas overwrites an earlier one
         if (igas_map_host[i] < 0 || igas_map_host[i] >= NPAR) FAIL(ANSFM_ERR_INVALID, "cirsradg: igas_map out of range");
-        q.slot_of_param[igas_map_host[i]] = ((q.gas_mask >> i) & 1u) ? (signed char)i : (signed char)-1;
+        // a gas that is not selected leaves the parameter to an earlier selected gas of the same column (isotopologues)
+        if ((q.gas_mask >> i) & 1u) q.slot_of_param[igas_map_host[i]] = (signed char)i;
     }
     q.slot_of_param[NVMR] = (q.gas_mask >> 31) ? (signed char)S : (signed char)-1;   // :3872 (written last)
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));

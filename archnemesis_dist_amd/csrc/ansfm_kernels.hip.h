@@ -1513,7 +1513,7 @@ __global__ __launch_bounds__(kWave *kGY) __attribute__((amdgpu_waves_per_eu(BATC
 // so neither dTAUTOT_LAYINC (W,G,NPAR,Li,P) nor dSPECOUT (W,G,NPAR,Li) is materialised.
 // Block = 64 wavenumbers x 4 g-groups; pass 1 stores trold_j per (g) to a workspace.
 // ------------------------------------------------------------------------------------------------
-constexpr int kMaxPar = 64;
+constexpr int kMaxPar = 256;   // parameters of dSPECOUT (NVMR + 2 + NDUST): sizes the slot table in the kernel arguments only
 struct RtGParams {
     RtParams r;              // r.out = SPECOUT [n][W][P]
     const double *dk;        // [n][L][NP1][G][Wpad]

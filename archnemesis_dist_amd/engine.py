@@ -99,6 +99,10 @@ class AnsfmEngine:
         """Spectroscopic gases (indices into the uploaded table) whose amount gradients `cirsradg_ck_*` computes; None = all
         (the reference's behaviour).  The others' parameters come back without their gas part.  temperature=False also
         leaves out the k-table part of the temperature gradient (a state vector without temperature elements).  Sticky."""
+        if gases is not None:
+            bad = [int(g) for g in gases if not 0 <= int(g) < 31]
+            if bad:
+                raise ValueError("set_gradient_gases: gas indices must lie in [0, 31) (bit 31 is the temperature slot): %s" % bad)
         mask = 0xFFFFFFFF if gases is None else sum(1 << int(g) for g in set(int(g) for g in gases))
         mask = (mask | 0x80000000) if temperature else (mask & 0x7FFFFFFF)
         self._check(self._lib.ansfm_set_gradient_gases(self._ctx, C.c_uint(mask & 0xFFFFFFFF)), "set_gradient_gases")
@@ -419,6 +423,14 @@ class AnsfmEngine:
         ncont, nwave, _, nth = phasarr.shape
         nmu = len(mu1); ngeom = len(emiss_angs)
         _, ng, nlay = taus.shape
+        if ngeom > self.MS_PATHS_PER_CALL:      # the chain kernels keep one path per lane of a 16-lane row: groups of paths
+            emi = np.asarray(emiss_angs, dtype=float)
+            if not (np.all(emi < 90) or np.all(emi > 90)):
+                raise ValueError("scloud11wave_core: INVALID: Emission angles are a mix of values above and below 90 degrees.")
+            parts = [self.scloud11wave_core(phasarr, radg, np.asarray(sol_angs)[g], emi[g], solar, np.asarray(aphis)[g], lowbc,
+                                            brdf_matrix, mu1, wt1, nf, vwaves, bnu, taus, tauray, omegas_s, nphi, iray, imie, lfrac)
+                     for g in self._path_groups(ngeom)]
+            return np.concatenate(parts, axis=0)
         rad = np.empty((ngeom, ng, nwave))
         rc = self._lib.ansfm_scloud11wave_core(
             self._ctx, ncont, nwave, nth, _ptr(phasarr), _ptr(_np(radg)), ngeom, _ptr(_np(sol_angs)),
@@ -427,6 +439,12 @@ class AnsfmEngine:
             _ptr(_np(omegas_s)), int(nphi), int(iray), int(imie), _ptr(_np(lfrac)), _ptr(rad))
         self._check(rc, "scloud11wave_core")
         return rad
+
+    MS_PATHS_PER_CALL = 16
+
+    def _path_groups(self, ngeom):
+        n = self.MS_PATHS_PER_CALL
+        return [slice(i, min(i + n, ngeom)) for i in range(0, ngeom, n)]
 
     def cirsrad_ck_scatter(self, ISPACE, lay_press_pa, lay_temp, amount, TAUCIA, TAUDUST, TAURAY, TAUSCAT, phasarr, lfrac,
                            radg, sol_angs, emiss_angs, aphis, solar, lowbc, brdf_matrix, mu1, wt1, nf, nphi, iray, imie,
@@ -447,6 +465,15 @@ class AnsfmEngine:
         nth = 0 if phasarr is None else phasarr.shape[3]
         sol = _np(np.atleast_1d(sol_angs)); emi = _np(np.atleast_1d(emiss_angs)); aph = _np(np.atleast_1d(aphis))
         P = sol.shape[0]
+        if P > self.MS_PATHS_PER_CALL:          # more paths than one call takes: groups of paths, the chains of each re-run
+            if not (np.all(emi < 90) or np.all(emi > 90)):
+                raise ValueError("cirsrad_ck_scatter: INVALID: Emission angles are a mix of values above and below 90 degrees.")
+            parts = [self.cirsrad_ck_scatter(ISPACE, lay_press_pa, lay_temp, amount, TAUCIA, TAUDUST, TAURAY, TAUSCAT, phasarr, lfrac,
+                                             radg, sol[g], emi[g], aph[g], solar, lowbc, brdf_matrix, mu1, wt1, nf, nphi, iray, imie,
+                                             xfac=xfac, return_spec_g=return_spec_g) for g in self._path_groups(P)]
+            if return_spec_g:
+                return np.concatenate([p_[0] for p_ in parts], axis=1), np.concatenate([p_[1] for p_ in parts], axis=2)
+            return np.concatenate(parts, axis=1)
         mu1 = _np(mu1); nmu = mu1.shape[0]
         out = np.empty((W, P)); spec_g = np.empty((W, G, P)) if return_spec_g else None
         rc = self._lib.ansfm_cirsrad_ck_scatter(

@@ -176,8 +176,8 @@ class CIRSradGPU:
         S = self.SpectroscopyX
         if S.NGAS <= 0 or int(S.ILBL) not in (ILBL_K_TABLES, ILBL_LBL_TABLES) or S.K is None:
             return False
-        if return_grad and (self.AtmosphereX.NVMR + 2 + self.ScatterX.NDUST > 64 or S.NGAS > 20):
-            return False
+        if return_grad and (self.AtmosphereX.NVMR + 2 + self.ScatterX.NDUST > 256 or S.NGAS > 31):
+            return False                   # kMaxPar of the gradient kernels' slot table; one mask bit per gas
         if getattr(self, "EmissionsX", None) is not None:
             return False
         imod = np.unique(np.asarray(self.PathX.IMOD).astype(int))
@@ -505,8 +505,8 @@ def install_gpu_scattering_core(device=0):
 
     ForwardModel_0.scloud11wave (ForwardModel_0.py:5018) prepares RADGROUND/BB/FRAC/OMEGA/PHASE_ARRAY on the host
     and imports `scloud11wave_core` from archnemesis.Multiple_Scattering_Core at call time (:5050); replacing that
-    module attribute keeps all of the reference's host preparation and swaps only the core (K7).  Sizes outside the
-    GPU core's limits (nmu > 20, more than 16 paths per call) go to the reference's own function."""
+    module attribute keeps all of the reference's host preparation and swaps only the core (K7).  More than 16 paths are run
+    in groups of 16 by the engine; more than 20 streams (nmu > 20) go to the reference's own function."""
     import importlib
     msc = importlib.import_module("archnemesis.Multiple_Scattering_Core")
     eng = get_engine(device)
@@ -518,7 +518,7 @@ def install_gpu_scattering_core(device=0):
             return eng.scloud11wave_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, int(lowbc), brdf_matrix, mu1, wt1,
                                          nf, vwaves, bnu, taus, tauray, omegas_s, nphi, int(iray), int(imie), lfrac)
         except NotImplementedError:
-            _delegate("scloud11wave_core size (nmu > 20 or > 16 paths)")
+            _delegate("scloud11wave_core with more than 20 streams (nmu > 20)")
             return ref_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, lowbc, brdf_matrix, mu1, wt1, nf, vwaves, bnu,
                             taus, tauray, omegas_s, nphi, iray, imie, lfrac)
 
@@ -846,10 +846,25 @@ def install_gpu_table_reader(device=0):
     return read_tables
 
 
+class Installed(list):
+    """What install_all() returns: the names installed, and `summary()` -- every case that left the GPU path since then
+    (DELEGATED: case -> count; each is also announced once as a RuntimeWarning) and every deliberate difference (NOTES)."""
+
+    @staticmethod
+    def summary():
+        return summary()
+
+    def __repr__(self):
+        s = summary()
+        return "Installed(%s; delegated to the reference so far: %s; notes: %s)" % (list.__repr__(self), s["delegated"] or "nothing",
+                                                                                     s["notes"] or "none")
+
+
 def install_all(device=0, oe_linalg=True, ktable_generator=True):
     """Every replacement this package has for the imported reference, in one call; returns the
-    names installed.  `make_gpu_forward_model` stays explicit: it returns a class."""
-    done = []
+    names installed as an `Installed` list whose `summary()` reports what was handed to the reference's CPU code since.
+    `make_gpu_forward_model` stays explicit: it returns a class."""
+    done = Installed()
     for f in (install_gpu_gradient_maps, install_gpu_scattering_core, install_gpu_line_kernel, install_gpu_layering,
               install_gpu_convolution, install_gpu_continuum, install_gpu_table_reader):
         f(device); done.append(f.__name__)

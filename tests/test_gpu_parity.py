@@ -361,9 +361,11 @@ def test_k_overlapg_golden(eng, golden_dir, name):
     assert np.max(np.abs(dk - z["dk"]) / scale) < tol
 
 
-@pytest.mark.parametrize("W,G,S,L,f32", [(96, 20, 8, 20, True), (70, 10, 3, 9, False), (40, 16, 12, 6, False)])
-def test_cirsradg_vs_oracle(eng, oracle, W, G, S, L, f32):
-    """Fused CIRSrad(return_grad=True) for a 2-model batch vs the CPU oracle (literal O(Li^2) recursion)."""
+@pytest.mark.parametrize("W,G,S,L,f32,NDUST", [(96, 20, 8, 20, True, 1), (70, 10, 3, 9, False, 1), (40, 16, 12, 6, False, 1),
+                                               (24, 8, 24, 5, False, 60)])
+def test_cirsradg_vs_oracle(eng, oracle, W, G, S, L, f32, NDUST):
+    """Fused CIRSrad(return_grad=True) for a 2-model batch vs the CPU oracle (literal O(Li^2) recursion).  Last case: 24
+    spectroscopic gases and NPAR = 88 -- beyond the 20 gases / 64 parameters the gradient path was capped at until round 3."""
     from archnemesis_dist_amd import synthetic as syn
     NP, NT = 8, 6
     _, delg = syn.gauss_legendre_01(G, as_float32=f32)
@@ -374,7 +376,7 @@ def test_cirsradg_vs_oracle(eng, oracle, W, G, S, L, f32):
     atm["amount"][0, 1, 3] = 0.0
     NLAYIN, LAYINC, SCALE = syn.nadir_path(L, emiss_ang=25.0)
     cont = syn.synth_continuum(W, L, n_models=n)
-    NVMR, NDUST = S + 2, 1                      # more atmospheric gases than spectroscopic ones
+    NVMR = S + 2                                # more atmospheric gases than spectroscopic ones
     NPAR = NVMR + 2 + NDUST
     rng = np.random.default_rng(3)
     igas_map = rng.permutation(NVMR)[:S].astype(np.int32)
@@ -1199,6 +1201,28 @@ def test_cirsrad_scatter_batch_equals_separate_calls(eng, monkeypatch, ncont, im
     finally:
         eng.set_layer_dedup(True)
     assert np.array_equal(again, ref)
+
+
+def test_cirsrad_scatter_more_than_sixteen_paths(eng):
+    """Twenty paths -- four more than one call of the chain kernels takes (one path per lane of a 16-lane row): the engine
+    runs them in groups, each path's spectrum equal to the one it gets in a call of its own group of <= 16."""
+    rng = np.random.default_rng(1616)
+    W, G, L, S, NMU, NF = 10, 4, 6, 2, 16, 2
+    z = _scatter_inputs(rng, W, G, L, S, NMU, NF, 1, 1, 1, 0)
+    P = 20
+    sol = rng.uniform(10.0, 70.0, P); emi = rng.uniform(5.0, 75.0, P); azi = rng.uniform(0.0, 180.0, P)
+    eng.upload_ktable(z["K"], z["TPRESS"], z["TTEMP"], z["WAVE"], z["DELG"])
+    run = lambda sel: eng.cirsrad_ck_scatter(0, z["lay_p"], z["lay_t"], z["amount"], z["TAUCIA"], z["TAUDUST"], z["TAURAY"], z["TAUSCAT"],
+                                             z["phasarr"], z["lfrac"], z["radg"], sol[sel], emi[sel], azi[sel], z["solar"], 0, z["brdf"],
+                                             z["MU"], z["WT"], NF, 101, 1, 1, return_spec_g=True)
+    out, spec_g = run(slice(None))
+    assert out.shape == (W, P) and spec_g.shape == (W, G, P)
+    a, ag = run(slice(0, 16)); b, bg = run(slice(16, 20))
+    assert np.array_equal(out, np.concatenate([a, b], axis=1)) and np.array_equal(spec_g, np.concatenate([ag, bg], axis=2))
+    with pytest.raises(ValueError):
+        emi2 = emi.copy(); emi2[18] = 120.0
+        eng.cirsrad_ck_scatter(0, z["lay_p"], z["lay_t"], z["amount"], z["TAUCIA"], z["TAUDUST"], z["TAURAY"], z["TAUSCAT"], z["phasarr"],
+                               z["lfrac"], z["radg"], sol, emi2, azi, z["solar"], 0, z["brdf"], z["MU"], z["WT"], NF, 101, 1, 1)
 
 
 def test_cirsrad_scatter_fine_azimuth_grid_vs_oracle(eng, oracle):
