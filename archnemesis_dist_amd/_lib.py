@@ -208,9 +208,11 @@ def read_lbltable_header(path):
     lib = load()
     dims = (C.c_int64 * 3)(); ids = (C.c_int32 * 2)(); hdr = (C.c_double * 2)()
     if lib.ansfm_lbltable_file_header(os.fsencode(path), dims, ids, hdr, None, None, None) != ANSFM_OK:
-        raise ValueError("not a readable .lta table (or one with NT < 0): %s" % path)
+        raise ValueError("not a readable .lta table: %s" % path)
     nwave, npress, ntemp = (int(d) for d in dims)
-    wave = np.empty(nwave); press = np.empty(npress, np.float32); temp = np.empty(ntemp, np.float32)
+    # NT < 0: one grid of -NT temperatures per pressure level (the reference's reader returns them as (npress, -NT), :2480-2483)
+    tshape = (npress, -ntemp) if ntemp < 0 else (ntemp,)
+    wave = np.empty(nwave); press = np.empty(npress, np.float32); temp = np.empty(tshape, np.float32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     lib.ansfm_lbltable_file_header(os.fsencode(path), dims, ids, hdr, p(wave), p(press), p(temp))
     return nwave, float(hdr[0]), float(hdr[1]), npress, ntemp, int(ids[0]), int(ids[1]), press, temp, wave

@@ -263,6 +263,7 @@ struct KtaHeader {
     double vmin = 0, delv = 0, fwhm = 0;
     std::vector<float> g_ord, del_g, press, temp;
     std::vector<double> wave;
+    bool temp2d = false;      // .lta with NT < 0 in the file: one grid of |NT| temperatures per pressure level, temp[npress][ntemp]
 };
 
 static double round7(double x) { return std::nearbyint(x * 1e7) / 1e7; }   // np.round(x, decimals=7)
@@ -321,13 +322,17 @@ static bool lta_read_header(const char *path, KtaHeader &h, std::string &err)
         h.irec0 = i2[0]; h.nwave = i2[1];
         h.vmin = round7((double)f2[0]); h.delv = round7((double)f2[1]); h.fwhm = 0.0;
         h.npress = j4[0]; h.ntemp = j4[1]; h.ng = 1; h.gasID = j4[2]; h.isoID = j4[3];
+        // NT < 0: the pressure levels are followed by one grid of -NT temperatures per level (:2480-2483, :2684-2687)
+        h.temp2d = h.ntemp < 0;
+        if (h.temp2d) h.ntemp = -h.ntemp;
         ok = h.nwave > 0 && h.npress > 0 && h.ntemp > 0 && h.irec0 > 0;
-        if (!ok) err = "not an LBL-table header, or NT < 0 (one temperature grid per pressure level: not streamed): " + fn;
+        if (!ok) err = "not an LBL-table header: " + fn;
     } else
         err = "truncated header: " + fn;
     if (ok) {
-        h.g_ord.assign(1, 0.0f); h.del_g.assign(1, 1.0f); h.press.resize(h.npress); h.temp.resize(h.ntemp);
-        ok = rd(h.press.data(), 4, h.npress) && rd(h.temp.data(), 4, h.ntemp);
+        const size_t ntv = h.temp2d ? (size_t)h.npress * h.ntemp : (size_t)h.ntemp;
+        h.g_ord.assign(1, 0.0f); h.del_g.assign(1, 1.0f); h.press.resize(h.npress); h.temp.resize(ntv);
+        ok = rd(h.press.data(), 4, h.npress) && rd(h.temp.data(), 4, ntv);
         h.wave.resize(h.nwave);
         const double vmax = h.vmin + h.delv * (h.nwave - 1);
         const double step = h.nwave > 1 ? (vmax - h.vmin) / (h.nwave - 1) : 0.0;
@@ -346,12 +351,12 @@ int ansfm_lbltable_file_header(const char *path, int64_t dims[3], int32_t ids[2]
     if (!path) return ANSFM_ERR_INVALID;
     KtaHeader h; std::string err;
     if (!lta_read_header(path, h, err)) return ANSFM_ERR_INVALID;
-    if (dims) { dims[0] = h.nwave; dims[1] = h.npress; dims[2] = h.ntemp; }
+    if (dims) { dims[0] = h.nwave; dims[1] = h.npress; dims[2] = h.temp2d ? -h.ntemp : h.ntemp; }    // NT as the file has it
     if (ids) { ids[0] = h.gasID; ids[1] = h.isoID; }
     if (hdr) { hdr[0] = h.vmin; hdr[1] = h.delv; }
     if (wave) memcpy(wave, h.wave.data(), h.wave.size() * sizeof(double));
     if (press) memcpy(press, h.press.data(), h.npress * sizeof(float));
-    if (temp) memcpy(temp, h.temp.data(), h.ntemp * sizeof(float));
+    if (temp) memcpy(temp, h.temp.data(), h.temp.size() * sizeof(float));        // [npress][|NT|] when NT < 0
     return ANSFM_OK;
 }
 
@@ -386,6 +391,7 @@ static int upload_table_files(ansfm_ctx *ctx, int S, const char *const *paths, d
         if (hs[s].npress != hs[0].npress) FAIL(ANSFM_ERR_INVALID, "error :: Number of pressure levels in all .kta files must be the same");
         if (hs[s].ntemp != hs[0].ntemp) FAIL(ANSFM_ERR_INVALID, "error :: Number of temperature levels in all .kta files must be the same");
         if (hs[s].ng != hs[0].ng) FAIL(ANSFM_ERR_INVALID, "error :: Number of g-ordinates in all .kta files must be the same");
+        if (hs[s].temp2d != hs[0].temp2d) FAIL(ANSFM_ERR_INVALID, "error :: Number of temperature levels in all .kta files must be the same");
     }
     // read_header keeps the grids of the LAST table (:1311-1334); read_tables then cuts WAVE to [wavemin, wavemax]
     // with searchsorted (:1486-1494) and every gas is read over [WAVE.min(), WAVE.max()] of that cut (:1502)
@@ -407,12 +413,12 @@ static int upload_table_files(ansfm_ctx *ctx, int S, const char *const *paths, d
     const size_t total = (size_t)NP * NT * S * G * Wpad;
     HIPCHK(ctx->lnK.reserve(total * sizeof(double)));
     HIPCHK(ctx->d_press.reserve(NP * sizeof(double)));
-    HIPCHK(ctx->d_temp.reserve(NT * sizeof(double)));
+    HIPCHK(ctx->d_temp.reserve(TEMP.size() * sizeof(double)));                 // [NP][NT] for a table with NT < 0
     HIPCHK(ctx->d_wave.reserve((size_t)W * sizeof(double)));
     HIPCHK(ctx->d_delg.reserve(kMaxG * sizeof(double)));
     HIPCHK(ctx->d_flag.reserve(16 * sizeof(int)));
     HIPCHK(hipMemcpyAsync(ctx->d_press.p, PRESS.data(), NP * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_temp.p, TEMP.data(), NT * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_temp.p, TEMP.data(), TEMP.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_wave.p, WAVE.data(), (size_t)W * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_delg.p, DELG.data(), G * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_flag.p, 0, 16 * sizeof(int), ctx->stream));
@@ -448,7 +454,7 @@ static int upload_table_files(ansfm_ctx *ctx, int S, const char *const *paths, d
     ctx->monotone = (flag & 1) ? 0 : 1;
     ctx->h_delg = DELG; ctx->h_wave = WAVE; ctx->h_press = PRESS; ctx->h_temp = TEMP;
     ctx->have_table = true;
-    ctx->is_lbl = lta ? 1 : 0; ctx->temp2d = 0;
+    ctx->is_lbl = lta ? 1 : 0; ctx->temp2d = (lta && hl.temp2d) ? 1 : 0;
     if (lta) ctx->monotone = 1;
     ctx->grid_f32 = 1; ctx->delg_f32 = lta ? 0 : 1;   // PRESS / TEMP / DELG come out of the file as float32 arrays (:2544-2559)
     return ANSFM_OK;

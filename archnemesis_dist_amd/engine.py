@@ -157,7 +157,8 @@ class AnsfmEngine:
         self.dims, _ = self.ktable_info()
         self.grid_f32 = True
         W, G, NP, NT, S = self.dims
-        WAVE, PRESS, TEMP, DELG = np.empty(W), np.empty(NP), np.empty(NT), np.empty(G)
+        per_level = _lib.read_lbltable_header(paths[-1])[4] < 0          # NT < 0 in the file: TEMP comes back (NP, |NT|)
+        WAVE, PRESS, TEMP, DELG = np.empty(W), np.empty(NP), np.empty((NP, NT) if per_level else NT), np.empty(G)
         self._check(self._lib.ansfm_ktable_grids(self._ctx, _ptr(WAVE), _ptr(PRESS), _ptr(TEMP), _ptr(DELG)), "ktable_grids")
         self.WAVE, self.DELG = WAVE, np.array([1.0])
         return WAVE, PRESS.astype(np.float32), TEMP.astype(np.float32)

@@ -815,8 +815,6 @@ def install_gpu_table_reader(device=0):
         ext = {ILBL_K_TABLES: "kta", ILBL_LBL_TABLES: "lta"}.get(int(self.ILBL))
         binary = (ext is not None and self.LOCATION is not None and not getattr(self, "ONLINE", False)
                   and len(self.LOCATION) > 0 and all(str(p).endswith(ext) for p in self.LOCATION))
-        if binary and ext == "lta" and self.NT is not None and int(self.NT) < 0:
-            binary = False                           # one temperature grid per pressure level: not streamed
         if not binary:
             _delegate("read_tables for tables that are not binary .kta / .lta files")
             return ref(self, wavemin, wavemax, wavedelta)
@@ -832,11 +830,8 @@ def install_gpu_table_reader(device=0):
         self.NWAVE = len(wave1)
         self.WAVE = wave1
         if ext == "lta":
-            if int(self.NT) < 0:                      # header only known now (read_header ran above)
-                _delegate("read_tables for .lta tables with one temperature grid per pressure level")
-                return ref(self, wavemin, wavemax, wavedelta)
-            self.K = KtaTableOnDevice(self.LOCATION, self.WAVE.min(), self.WAVE.max(),
-                                      (self.NWAVE, self.NP, self.NT, self.NGAS), sp.read_lbltable, ".lta", 8)
+            self.K = KtaTableOnDevice(self.LOCATION, self.WAVE.min(), self.WAVE.max(),       # NT < 0: |NT| temperatures per level
+                                      (self.NWAVE, self.NP, abs(int(self.NT)), self.NGAS), sp.read_lbltable, ".lta", 8)
         else:
             self.K = KtaTableOnDevice(self.LOCATION, self.WAVE.min(), self.WAVE.max(),
                                       (self.NWAVE, self.NG, self.NP, self.NT, self.NGAS), sp.read_ktable)

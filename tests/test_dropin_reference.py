@@ -649,3 +649,21 @@ def test_read_tables_keeps_lbl_tables_in_their_files(c1_run, golden_dir, monkeyp
     assert isinstance(S.K, fmod.KtaTableOnDevice) and S.K.ext == ".lta"
     assert S.K.shape == Sref.K.shape and np.array_equal(S.WAVE, Sref.WAVE)
     assert np.array_equal(np.asarray(S.K), Sref.K)
+
+
+def test_reference_conv_with_positive_fwhm_cannot_run(c1_run):
+    """Why the cubic-spline branch of Measurement_0.conv (FWHM > 0, Measurement_0.py:2347-2411) has no GPU counterpart: the
+    reference's own branch raises before it computes anything -- `VCONV[NCONV[IGEOM], IGEOM]` (:2357) is one past the last row
+    whenever the geometry fills the array (IndexError), and with fewer points `self.NWAVE` (:2372) does not exist
+    (AttributeError); where it could run, its 'trapezoid' sums differences, `(yi[j] - yold) * delx / 2` (:2405), i.e. it
+    telescopes to (y(x2) - y(x1)) delx / 2.  `install_gpu_convolution` hands the case to the reference, which raises."""
+    ans = c1_run
+    Atm, Meas, Spec, Scat, Stel, Surf, CIA, Lay, Var, Ret = ans.Files.read_input_files("cirstest")
+    Wave = np.linspace(0.0, 1500.0, 601)
+    y = 1e-7 * (1.0 + np.sin(Wave / 50.0))
+    Meas.FWHM = 2.0
+    with pytest.raises(IndexError):
+        Meas.conv(Wave, y, IGEOM=0)
+    Meas.NCONV = np.array([int(Meas.NCONV[0]) - 5], dtype="int32")
+    with pytest.raises(AttributeError):
+        Meas.conv(Wave, y, IGEOM=0)

@@ -45,3 +45,35 @@ def test_upload_from_files_equals_upload_of_reference_arrays(golden_dir, rng_nam
     k2, d2 = e2.calc_klbl(press, temp, grad=True)
     assert np.array_equal(k1, k2) and np.array_equal(d1, d2)
     assert k1.max() > 0
+
+
+def test_per_level_temperature_grids_header(golden_dir):
+    """NT < 0 in the file: one grid of |NT| temperatures per pressure level (read_ltahead :2480-2483)."""
+    from archnemesis_dist_amd._lib import read_lbltable_header
+    z = np.load(os.path.join(golden_dir, "lta_read.npz"))
+    h = read_lbltable_header(os.path.join(golden_dir, "kta", "lbl_perlevel.lta"))
+    for n, v in zip(HEAD, h):
+        ref = z[f"pl_head_{n}"]
+        assert np.array_equal(np.asarray(v, dtype=ref.dtype), ref), n
+    assert h[4] == -2 and h[8].shape == (5, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rng_name", ["all", "sub"])
+def test_per_level_table_streamed_equals_reference_arrays(golden_dir, rng_name):
+    """The NT < 0 table streamed from the file == the same table uploaded from what the reference's read_lbltable returned
+    (calc_klbl / calc_klblg bit-identical, incl. the per-level temperature brackets)."""
+    import archnemesis_dist_amd as pkg
+    z = np.load(os.path.join(golden_dir, "lta_read.npz"))
+    lo, hi = z[f"pl_{rng_name}_range"]
+    e1 = pkg.AnsfmEngine(0)
+    WAVE, PRESS, TEMP = e1.upload_lbltable_files([os.path.join(golden_dir, "kta", "lbl_perlevel.lta")], lo, hi)
+    assert np.array_equal(WAVE, z[f"pl_{rng_name}_wave"]) and TEMP.shape == (5, 2)
+    assert np.array_equal(TEMP, z["pl_head_templevels"].astype(np.float32))
+    e2 = pkg.AnsfmEngine(0)
+    e2.upload_lbltable(z[f"pl_{rng_name}_k"][..., None], z["pl_head_presslevels"], z["pl_head_templevels"].astype(np.float32),
+                       z[f"pl_{rng_name}_wave"])
+    press = np.array([3e-4, 0.02, 0.5, 2.0]); temp = np.array([90.0, 150.0, 250.0, 360.0])
+    k1, d1 = e1.calc_klbl(press, temp, grad=True)
+    k2, d2 = e2.calc_klbl(press, temp, grad=True)
+    assert np.array_equal(k1, k2) and np.array_equal(d1, d2) and k1.max() > 0
