@@ -2100,8 +2100,8 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
                      const double *emiss_angs, const double *aphis, int lowbc, int nmu, const double *mu1, const double *wt1,
                      int nf, int ng, int nlay, int nphi, int iray, int imie, bool prepare_only = false)
 {
-    if (nmu > 20 || ngeom > kMsMaxPath || ncont > 60)
-        FAIL(ANSFM_ERR_UNSUPPORTED, "scloud11wave_core: nmu <= 20, npath <= 16 per call supported");
+    if (nmu > kMsMaxMu || ngeom > kMsMaxPath || ncont > 60)
+        FAIL(ANSFM_ERR_UNSUPPORTED, "scloud11wave_core: nmu <= 32, npath <= 16 per call supported");
     int nless = 0, nmore = 0;
     for (int i = 0; i < ngeom; ++i) { if (emiss_angs[i] < 90) ++nless; if (emiss_angs[i] > 90) ++nmore; }
     if (nless != ngeom && nmore != ngeom)

@@ -215,7 +215,7 @@ __device__ __forceinline__ double ms_wave_max(double x)
 // __syncthreads() also waits for every outstanding GLOBAL access (vmcnt(0)) -- here that is the prefetch of the matrices two
 // steps ahead and the store of the factors, i.e. a full memory round trip in every step of a walk that is nothing but latency.
 #define MS_WAVE_SYNC() __atomic_signal_fence(__ATOMIC_SEQ_CST)
-template <int NMU>   // NMU = 16: compile-time size (unrolled sums, all LDS reads in flight); 0: any nmu <= 20
+template <int NMU>   // NMU = 16: compile-time size (unrolled sums, all LDS reads in flight); 0: any nmu <= kMsMaxMu
 __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
 {
     __shared__ double ppl_s[2][kMsMaxMu * kMsMaxMu], pmi_s[2][kMsMaxMu * kMsMaxMu], fc[kMsMaxMu * kMsMaxMu];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
     const int comp = blockIdx.x + p.hansen_comp0;
     const int n = NMU ? NMU : p.nmu, nn = n * n, tid = threadIdx.x;
     const double x1 = 2.0 * 3.141592653589793;
-    constexpr int NE = NMU ? (NMU * NMU + 63) / 64 : (20 * 20 + 63) / 64;   // matrix elements per lane
+    constexpr int NE = NMU ? (NMU * NMU + 63) / 64 : (kMsMaxMu * kMsMaxMu + 63) / 64;   // matrix elements per lane
     double nppl[NE], npmi[NE];
     // The walk is latency-bound: matrices are fetched two iterations ahead (registers), staged into the
     // other LDS buffer one iteration ahead.
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
     }
 }
 
-// ---- small dense helpers on LDS matrices (one wavefront = one block), any nmu <= 20 -------------------
+// ---- small dense helpers on LDS matrices (one wavefront = one block), any nmu <= kMsMaxMu = 32 -------------------
 typedef double ms_v4f64 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void ms_mm(int n, int ld, const double *A, const double *B, double *C, int lane)
@@ -344,7 +344,7 @@ __device__ __forceinline__ void ms_inv(int n, int ld, double *A, double *Ainv, d
         double best = (lane >= c && lane < n) ? fabs(A[lane * ld + c]) : -1.0;
         int piv = lane;
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {     // n <= 20 < 32: lanes 0..31 hold every candidate
+        for (int off = 16; off > 0; off >>= 1) {     // n <= 32: lanes 0..31 hold every candidate
             const double ob = __shfl_xor(best, off, 64);
             const int op = __shfl_xor(piv, off, 64);
             if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }

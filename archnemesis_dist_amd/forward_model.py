@@ -506,7 +506,7 @@ def install_gpu_scattering_core(device=0):
     ForwardModel_0.scloud11wave (ForwardModel_0.py:5018) prepares RADGROUND/BB/FRAC/OMEGA/PHASE_ARRAY on the host
     and imports `scloud11wave_core` from archnemesis.Multiple_Scattering_Core at call time (:5050); replacing that
     module attribute keeps all of the reference's host preparation and swaps only the core (K7).  More than 16 paths are run
-    in groups of 16 by the engine; more than 20 streams (nmu > 20) go to the reference's own function."""
+    in groups of 16 by the engine; more than 32 streams go to the reference's own function."""
     import importlib
     msc = importlib.import_module("archnemesis.Multiple_Scattering_Core")
     eng = get_engine(device)
@@ -518,7 +518,7 @@ def install_gpu_scattering_core(device=0):
             return eng.scloud11wave_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, int(lowbc), brdf_matrix, mu1, wt1,
                                          nf, vwaves, bnu, taus, tauray, omegas_s, nphi, int(iray), int(imie), lfrac)
         except NotImplementedError:
-            _delegate("scloud11wave_core with more than 20 streams (nmu > 20)")
+            _delegate("scloud11wave_core with more than 32 streams")
             return ref_core(phasarr, radg, sol_angs, emiss_angs, solar, aphis, lowbc, brdf_matrix, mu1, wt1, nf, vwaves, bnu,
                             taus, tauray, omegas_s, nphi, iray, imie, lfrac)
 

@@ -1130,6 +1130,7 @@ def _scatter_oracle(oracle, z, sol, emi, azi, lowbc, NF, nphi, iray, imie):
 
 
 @pytest.mark.parametrize("NMU,NF,ncont,imie,iray,lowbc,up", [(5, 2, 2, 0, 1, 0, False), (16, 3, 1, 1, 1, 1, False),
+                                                             (24, 2, 1, 1, 1, 1, False), (32, 1, 1, 0, 1, 0, True),   # beyond the old cap of 20
                                                              (5, 1, 1, 1, 0, 0, True), (16, 2, 0, 0, 1, 0, False),
                                                              (16, 2, 2, 0, 1, 0, False),      # three components: phase matrices stay in HBM
                                                              (16, 1, 2, 1, 0, 1, True)])
