@@ -78,7 +78,7 @@ struct ansfm_ctx {
     int map_dims[4] = {0, 0, 0, 0};     // W, NPAR, NPRO, P of map_out
     DevBuf gscratch, perm, dkbuf, trold_ws, dspec_i, dcont_t, tmp_in2, tmp_out2, lbl_li;
     DevBuf ms_taus, ms_omegas, ms_bnu;   // scattering branch of CIRSrad: TAUTOT / OMEGA (W,G,L) and BB (W,L) in HBM
-    DevBuf ms_cache, ms_orders, ms_same; // batched scattering Jacobian: doubled layers of model 0, orders cached, layer flags
+    DevBuf ms_cache, ms_orders, ms_same, ms_pcache, ms_lstart; // batched scattering Jacobian: doubled layers / prefix stacks of model 0, orders cached, layer flags, sweep starts
     long ms_cache_hits = 0, ms_cache_layers = 0;   // (model, layer) pairs taken from the cache / all, last batch call
     DevBuf hb[24];  // staging buffers of the host-pointer entry points
     int last_n = 0, last_L = 0;
@@ -154,7 +154,7 @@ void ansfm_destroy(ansfm_ctx *ctx)
                       &ctx->li, &ctx->tau, &ctx->scratch, &ctx->cont_t, &ctx->tmp_in, &ctx->tmp_out,
                       &ctx->misc, &ctx->gscratch, &ctx->dkbuf, &ctx->trold_ws, &ctx->dspec_i, &ctx->dcont_t,
                       &ctx->tmp_in2, &ctx->tmp_out2, &ctx->lbl_li, &ctx->ms_taus, &ctx->ms_omegas, &ctx->ms_bnu, &ctx->dcont_gas,
-                      &ctx->ms_cache, &ctx->ms_orders, &ctx->ms_same};
+                      &ctx->ms_cache, &ctx->ms_orders, &ctx->ms_same, &ctx->ms_pcache, &ctx->ms_lstart};
     for (auto *b : bufs) b->release();
     for (auto &b : ctx->hb) b.release();
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -2472,6 +2472,12 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
         hipLaunchKernelGGL(k_ms_same_cols, dim3(nblk((size_t)(n_models - 1) * W * ncont, 128)), dim3(128), 0, ctx->stream,
                            n_models, W, ncont, L, (const double *)d[8], same);
     HIPCHK(hipGetLastError());
+    // where a model's adding sweep may start: below its first changed layer (in sweep order: bottom first when the paths look
+    // down, top first when they look up) the stack equals model 0's, kept after every kMsPrefixStep-th layer
+    int nmore_up = 0;
+    for (int k = 0; k < ngeom; ++k) if (emiss_angs[k] > 90) ++nmore_up;
+    const bool lookup = nmore_up == ngeom;
+    const int npre = L / kMsPrefixStep;
     {
         std::vector<unsigned char> hs(nl);
         HIPCHK(hipMemcpyAsync(hs.data(), same, nl, hipMemcpyDeviceToHost, ctx->stream));
@@ -2479,6 +2485,21 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
         long hits = 0;
         for (size_t k = (size_t)L; k < nl; ++k) hits += hs[k];
         ctx->ms_cache_hits = hits; ctx->ms_cache_layers = (long)(n_models - 1) * L;
+        std::vector<int> lstart((size_t)n_models, 0);
+        const char *ev_pre = getenv("ANSFM_MS_PREFIX");
+        const bool use_prefix = !(ev_pre && atoi(ev_pre) == 0);
+        for (int m = 1; m < n_models && use_prefix; ++m) {
+            int lf = 0;
+            while (lf < L && hs[(size_t)m * L + (lookup ? L - 1 - lf : lf)]) ++lf;
+            // the lower boundary sits at the bottom of a look-down stack: its radiance must be model 0's too
+            if (lowbc > 0 && !lookup &&
+                memcmp(radg + (size_t)m * W * nmu, radg, (size_t)W * nmu * D) != 0)
+                lf = 0;
+            lstart[m] = std::min(lf / kMsPrefixStep, npre) * kMsPrefixStep;
+        }
+        HIPCHK(ctx->ms_lstart.reserve((size_t)n_models * sizeof(int)));
+        HIPCHK(hipMemcpyAsync(ctx->ms_lstart.p, lstart.data(), (size_t)n_models * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     // ---- phase matrices and Hansen factors: once, they do not depend on the model -----------------------------------------
     MsParams p;
@@ -2489,17 +2510,19 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
                         imie, true)))
         return rc;
     // ---- slabs of the spectral axis sized by the layer cache ----------------------------------------------------------------
-    const size_t per_w = (size_t)G * (nf + 1) * L * kMsCacheEntry * D;
+    const size_t per_w_layers = (size_t)G * (nf + 1) * L * kMsCacheEntry * D, per_w_pre = (size_t)G * (nf + 1) * npre * kMsCacheEntry * D;
+    const size_t per_w = per_w_layers + per_w_pre;
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    free_b += ctx->ms_cache.bytes;
+    free_b += ctx->ms_cache.bytes + ctx->ms_pcache.bytes;
     size_t budget = std::min<size_t>(free_b / 2, (size_t)96 << 30);
     long Ws = (long)(budget / per_w);
     if (const char *ev = getenv("ANSFM_MS_SLAB")) { const long v = atol(ev); if (v >= 1) Ws = std::min(Ws, v); }
     if (Ws < 1) FAIL(ANSFM_ERR_HIP, "cirsrad_ck_scatter_batch: no memory for the layer cache of one wavenumber");
     if (Ws > W) Ws = W;
     const int mchunk = std::min(n_models - 1, 64);
-    HIPCHK(ctx->ms_cache.reserve((size_t)Ws * per_w));
+    HIPCHK(ctx->ms_cache.reserve((size_t)Ws * per_w_layers));
+    HIPCHK(ctx->ms_pcache.reserve(std::max<size_t>((size_t)Ws * per_w_pre, 8)));
     HIPCHK(ctx->ms_orders.reserve((size_t)Ws * G * sizeof(int)));
     const size_t opt_models = (size_t)std::max(1, mchunk);
     HIPCHK(ctx->ms_taus.reserve(opt_models * Ws * G * L * D));
@@ -2509,6 +2532,7 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
     p.rad = ctx->tmp_out.as<double>();
     p.taus = ctx->ms_taus.as<double>(); p.omegas = ctx->ms_omegas.as<double>(); p.bnu = ctx->ms_bnu.as<double>();
     p.cache = ctx->ms_cache.as<double>(); p.cache_orders = ctx->ms_orders.as<int>(); p.same = same;
+    p.pcache = ctx->ms_pcache.as<double>(); p.lstart = ctx->ms_lstart.as<int>(); p.npre = npre;
     p.st_wl = st_wl; p.st_wcl = (size_t)W * ncont * L; p.st_wm = (size_t)W * nmu; p.st_rad = (size_t)ngeom * G * W;
     p.phase_lds = 0; p.ig0 = 0; p.ng_launch = G;
     MsOpticsBatchParams o;

@@ -60,9 +60,13 @@ struct MsParams {
     double *cache;           // [wcount][ng][nf+1][nlay][528]: doubled (r, t, j) of every scattering layer of model 0
     int *cache_orders;       // [wcount][ng]: Fourier orders model 0 worked through (those are in the cache)
     const unsigned char *same;   // [n_models][nlay]: the layer's inputs are bit-identical to model 0's
+    double *pcache;          // [wcount][ng][nf+1][npre][528]: model 0's STACK (rc, tc, jc) after every kMsPrefixStep-th layer of the sweep
+    const int *lstart;       // [n_models]: sweep index (multiple of kMsPrefixStep) a model's adding sweep may start from
+    int npre;
     size_t st_wl, st_wcl, st_wm, st_rad;   // strides between models: tauray [W][L], lfrac [W][ncont][L], radg [W][nmu], rad
 };
 constexpr int kMsCacheEntry = 528;   // doubles per cached layer: r (256) and t (256) in the MFMA accumulator layout, j (16)
+constexpr int kMsPrefixStep = 4;     // the stack below is kept after sweep layers 3, 7, 11, ...
 
 __device__ __forceinline__ double ms_interp(double x, const double *xp, const double *fp, int n)
 {   // np.interp
@@ -850,9 +854,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const double *taus_w = p.taus + (wrow * p.ng + ig) * p.nlay, *omegas_w = p.omegas + (wrow * p.ng + ig) * p.nlay;
     const double *bnu_w = p.bnu + wrow * p.nlay, *tauray_w = p.tauray + (size_t)mg * p.st_wl + (size_t)widx * p.nlay;
     const double *lfrac_m = p.lfrac + (size_t)mg * p.st_wcl;
-    const int kfirst = lookup ? p.nlay - 1 : 0;
+    // CACHE = 2: every layer of the sweep below lstart is model 0's, and so is the stack they add up to (the lower boundary
+    // included: the host leaves lstart at 0 when the boundary radiance differs) -- take it from model 0's pass and start there
+    int lbeg = 0;
+    if constexpr (CACHE == 2) {
+        if (ic < ncached) lbeg = p.lstart[mg];
+        if (lbeg > 0) {
+            const double *pe = p.pcache + ((((size_t)wl * p.ng + ig) * (p.nf + 1) + ic) * p.npre + (lbeg / kMsPrefixStep - 1)) * kMsCacheEntry;
+            ms_v4f64 sR, sT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sR[r] = pe[r * 64 + lane]; sT[r] = pe[(4 + r) * 64 + lane]; }
+            const double sj = pe[512 + c];
+            MS16_FENCE();
+            L.store_d(rc, sR); L.store_d(tc, sT);
+            if (q == 0) jc[c] = sj;
+            MS16_FENCE();
+            defined = true;
+        }
+    }
+    const int kfirst = lookup ? p.nlay - 1 - lbeg : lbeg;
     double n_taut = taus_w[kfirst], n_bc = bnu_w[kfirst], n_omega = omegas_w[kfirst], n_taur = tauray_w[kfirst];
-    for (int l = 0; l < p.nlay; ++l) {
+    for (int l = lbeg; l < p.nlay; ++l) {
         const int k = lookup ? p.nlay - 1 - l : l;  // look-down: bottom layer first (:842-845)
         const double taut = n_taut, bc = n_bc;
         double omega = n_omega;
@@ -1045,6 +1067,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             L.store_d(tc, tn); L.store_d(rc, rn);
             if (q == 0) jc[c] = jn;
             MS16_FENCE();
+        }
+        if constexpr (CACHE == 1) {
+            if ((l % kMsPrefixStep) == kMsPrefixStep - 1 && l / kMsPrefixStep < p.npre) {
+                double *pe = p.pcache + ((((size_t)wl * p.ng + ig) * (p.nf + 1) + ic) * p.npre + l / kMsPrefixStep) * kMsCacheEntry;
+                const ms_v4f64 sR = L.load_d(rc), sT = L.load_d(tc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pe[r * 64 + lane] = sR[r]; pe[(4 + r) * 64 + lane] = sT[r]; }
+                if (q == 0) pe[512 + c] = jc[c];
+            }
         }
     }
     if (ic != 0 && lane < n) jc[lane] = 0.0;   // :881-882

@@ -1160,8 +1160,9 @@ def test_cirsrad_scatter_batch_equals_separate_calls(eng, monkeypatch, ncont, im
     """ansfm_cirsrad_ck_scatter_batch -- the forward models of a numerical Jacobian of the scattering configuration: model 0
     plus models that differ from it in one or two layers (temperature, one gas amount, the aerosol opacity, the Rayleigh
     opacity of a layer) and one that differs everywhere.  Model 0's doubled layers are cached, the others re-run the
-    adding sweep over them: every spectrum is bit-identical to a call of its own, with one slab and with several
-    (ANSFM_MS_SLAB), and the bookkeeping says which layers came from the cache."""
+    adding sweep over them -- from the cached stack below their first changed layer where there is one: every spectrum is
+    bit-identical to a call of its own, with one slab and with several (ANSFM_MS_SLAB), and the bookkeeping says which layers
+    came from the cache."""
     rng = np.random.default_rng(7700 + ncont + 3 * imie + 7 * lowbc)
     W, G, L, S, NMU, NF = 20, 5, 9, 3, 16, 3
     z = _scatter_inputs(rng, W, G, L, S, NMU, NF, max(ncont, 1), imie, iray, lowbc)
@@ -1169,7 +1170,7 @@ def test_cirsrad_scatter_batch_equals_separate_calls(eng, monkeypatch, ncont, im
         z["TAUSCAT"] = np.zeros((W, L)); z["TAUDUST"] = 10.0 ** rng.uniform(-5, -3, (W, L))
     sol = np.array([30.0, 120.0]); emi = np.array([160.0, 130.0]) if up else np.array([20.0, 50.0]); azi = np.array([45.0, 0.0])
     eng.upload_ktable(z["K"], z["TPRESS"], z["TTEMP"], z["WAVE"], z["DELG"])
-    n = 7
+    n = 8
     rep = lambda a: np.repeat(np.asarray(a)[None], n, 0).copy()
     lp, lt, am = rep(z["lay_p"]), rep(z["lay_t"]), rep(z["amount"])
     cia, dust, ray, sca = rep(z["TAUCIA"]), rep(z["TAUDUST"]), rep(z["TAURAY"]), rep(z["TAUSCAT"])
@@ -1180,6 +1181,8 @@ def test_cirsrad_scatter_batch_equals_separate_calls(eng, monkeypatch, ncont, im
     ray[4, :, 0] *= 1.05                               # Rayleigh opacity of the bottom layer
     lt[5, 0] *= 1.02; rg[5] *= 1.1                     # bottom temperature: layer 0 and the lower boundary radiance
     lt[6] *= 1.01; am[6] *= 1.03                       # everything: nothing can come from the cache
+    rg[7] *= 1.2                                       # only the lower boundary radiance: every layer cached, but the stack of a
+                                                       # look-down sweep over a reflecting surface starts from it (no prefix)
     common = (z["phasarr"] if ncont else None,)
     tail = (sol, emi, azi, z["solar"], lowbc, z["brdf"], z["MU"], z["WT"], NF, 101, iray, imie)
     one = lambda m: eng.cirsrad_ck_scatter(0, lp[m], lt[m], am[m], cia[m], dust[m], ray[m] if iray else None, sca[m], common[0],
