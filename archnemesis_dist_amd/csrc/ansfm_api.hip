@@ -2180,6 +2180,20 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
             HIPCHK(hipEventRecord(ctx->ms_ev[ng], ctx->stream));                    // phase matrices (and every input) ready
             HIPCHK(hipStreamWaitEvent(ctx->ms_stream, ctx->ms_ev[ng], 0));
             HIPCHK(hipStreamWaitEvent(ctx->ms_stream2, ctx->ms_ev[ng], 0));
+            // from here on work is queued on the side streams: whatever way this function is left -- an error return of any
+            // launch below included -- the main stream waits for them, so the next entry point cannot reuse ctx->misc / tmp_*
+            // while a side stream still reads or writes them
+            struct Rejoin {
+                ansfm_ctx *c; int ng; bool done = false;
+                void now()
+                {
+                    if (done) return;
+                    done = true;
+                    if (hipEventRecord(c->ms_ev[ng + 1], c->ms_stream) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->ms_ev[ng + 1], 0);
+                    if (hipEventRecord(c->ms_ev[ng + 2], c->ms_stream2) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->ms_ev[ng + 2], 0);
+                }
+                ~Rejoin() { now(); }
+            } rejoin{ctx, ng};
             for (int g = 0; g < ng; ++g) {
                 MsParams ph = p;
                 ph.ig0 = g; ph.ng_launch = 1;
@@ -2199,10 +2213,7 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
                 HIPCHK(hipGetLastError());
             }
             // the side streams must not run into the next call's buffers: they rejoin the main one here
-            HIPCHK(hipEventRecord(ctx->ms_ev[ng + 1], ctx->ms_stream));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ms_ev[ng + 1], 0));
-            HIPCHK(hipEventRecord(ctx->ms_ev[ng + 2], ctx->ms_stream2));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ms_ev[ng + 2], 0));
+            rejoin.now();
         } else {
             launch_chain((unsigned)((size_t)nwave * ng), ctx->stream, p);
             HIPCHK(hipGetLastError());
