@@ -502,6 +502,33 @@ def main():
             jac["analytic_route"] = {"what": "YN, KK (NY x NX) of the same state vector by analytic gradients; the layer- and level-level "
                                              "gradients (80 MB each) stay on the device, KK (16 MB) comes back", "wall_s": sorted(ts)[1], "kk_shape": list(ka.shape)}
 
+    # ---- what one rank of an 8-GPU wavenumber-sharded Jacobian does, measured on THIS GPU: a second context holds the first
+    #      1/8 of the spectral axis (chunk_range(W, 8, 0)) and runs all 201 states on it (bench.py --gpus 8 does exactly this on
+    #      every rank, plus one all_gather of 2 MB per rank).  Reported beside the one-GPU wall time; not a scaling measurement.
+    if jac is not None and world == 1 and rank == 0 and not args.no_extras:
+        w1 = chunk_range(W, 8, 0)[1]
+        eng8 = pkg.AnsfmEngine(local_rank)
+        eng8.set_stream(stream.cuda_stream)
+        PRESS8, TEMP8, K8 = torch_ktable(torch, dev, W, G, NP, NT, S, seed=20260704)
+        eng8.upload_ktable(K8[:w1].contiguous(), PRESS8.astype(np.float32), TEMP8.astype(np.float32), WAVE[:w1], delg)
+        del K8
+        torch.cuda.empty_cache()
+        m8 = BatchedCKThermalModel(eng8, st, pr["RADIUS"], pr["ID"], pr["ISO"], list(range(2, S + 2)),
+                                   layering_args=dict(NLAY=L, LAYINT=1, NINT=101), IRAY=4)
+        m8.global_waves = W
+        ts8 = []
+        for _ in range(6):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            y8, k8 = jacobian_nemesis_batched(m8)
+            torch.cuda.synchronize(); ts8.append(time.perf_counter() - t0)
+        jac["one_rank_of_eight"] = {
+            "what": "the work of ONE rank of an 8-GPU run sharded over the spectral axis, measured on this GPU: all %d states on "
+                    "%d of %d wavenumbers (its own slice of the k-table); the 8-GPU wall time is this plus one all_gather of "
+                    "%.1f MB per rank and the full-size KK assembly" % (st.NX + 1, w1, W, (st.NX + 1) * w1 * 8 / 1e6),
+            "wall_s": sorted(ts8[1:])[2], "same_kk_rows_as_the_whole_axis": bool(np.array_equal(k8, KK_j[:w1])),
+            "ratio_to_one_gpu_wall_s": jt / sorted(ts8[1:])[2]}
+        eng8.close()
+
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
