@@ -261,3 +261,75 @@ def test_scattering_jacobian_through_the_subclass_matches_the_reference(c1_cut, 
     forward models (here: the engine double) -- with the reference's KK."""
     info, double = _scattering_dropin(c1_cut, golden_dir, "auto")
     assert info["route"] == "staged" and double.scatter_batches == [6]
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_routes_agree_on_two_geometries_with_fov_averaging(c1_cut):
+    """NGEOM = 2 with different numbers of convolution points, the second geometry a field-of-view average of two emission
+    angles (NAV = 2, weights 0.3 / 0.7): the measurement vector packs the geometries one after the other (execute_fm
+    :2171-2174), SPEC is the weighted sum over the averaging points (:531).  The profile route (everything batched), the staged
+    route (the reference's host code per state) and the loop route (the reference's nemesisfm per column) give the same KK."""
+    ans, gj, fmod, double = c1_cut
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    free = (5, 30, 60)
+    res = {}
+    for route in ("profile", "staged", "loop"):
+        fm = gj.cut_case(ans, cls=FMGPU, nkeep=12, free=free)
+        M = fm.Measurement
+        n0, n1 = 12, 9
+        two = lambda a, b: np.stack([a, b], axis=1)
+        pad = lambda v: np.concatenate([v[:n1], np.zeros(n0 - n1)])
+        M.NGEOM = 2
+        M.NCONV = np.array([n0, n1], dtype="int32")
+        M.NAV = np.array([1, 2], dtype="int32")
+        M.VCONV = two(M.VCONV[:n0, 0], pad(M.VCONV[:n0, 0] + 1.0))
+        M.MEAS = two(M.MEAS[:n0, 0], pad(M.MEAS[:n0, 0])); M.ERRMEAS = two(M.ERRMEAS[:n0, 0], pad(M.ERRMEAS[:n0, 0]))
+        z2 = np.zeros((2, 2))
+        M.FLAT, M.FLON, M.SOL_ANG, M.AZI_ANG = z2.copy(), z2.copy(), z2.copy(), z2.copy()
+        M.EMISS_ANG = np.array([[0.0, 0.0], [25.0, 40.0]])
+        M.WGEOM = np.array([[1.0, 0.0], [0.3, 0.7]])
+        M.NY = n0 + n1
+        fm.ansfm_jacobian_route = route
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            YN, KK = fm.jacobian_nemesis(NCores=1, analytical_gradient=False)
+        assert fm.ansfm_last_jacobian["route"] == route and YN.shape == (n0 + n1,) and KK.shape == (n0 + n1, 81)
+        res[route] = (YN, KK)
+    assert np.array_equal(res["staged"][0], res["loop"][0]) and np.array_equal(res["staged"][1], res["loop"][1])
+    np.testing.assert_allclose(res["profile"][0], res["staged"][0], rtol=1e-13)
+    for ix in free:
+        sc = np.abs(res["staged"][1][:, ix]).max()
+        assert sc > 0 and np.abs(res["profile"][1][:, ix] - res["staged"][1][:, ix]).max() <= 1e-9 * sc
+    assert not np.array_equal(res["staged"][0][:9], res["staged"][0][12:])      # the second geometry is a different spectrum
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_routes_agree_on_a_limb_geometry(c1_cut):
+    """EMISS_ANG < 0 is the reference's limb flag (calc_path :2995-2999: LAYHT = tangent height, LAYANG = 90, the ray goes
+    down to the tangent layer and up again).  With the hydrostatic re-adjustment on, every state has its own heights, layer
+    grid and slant factors; the three routes give the same KK."""
+    ans, gj, fmod, double = c1_cut
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    free = (20, 45, 70)
+    res = {}
+    for route in ("profile", "staged", "loop"):
+        fm = gj.cut_case(ans, cls=FMGPU, nkeep=10, free=free)
+        M = fm.Measurement
+        M.EMISS_ANG = np.array([[-1.0]]); M.TANHE = np.array([[60.0]]); M.SOL_ANG = np.array([[60.0]])
+        fm.ansfm_jacobian_route = route
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            YN, KK = fm.jacobian_nemesis(NCores=1, analytical_gradient=False)
+        assert fm.ansfm_last_jacobian["route"] == route
+        res[route] = (YN, KK)
+    assert np.array_equal(res["staged"][1], res["loop"][1])
+    np.testing.assert_allclose(res["profile"][0], res["staged"][0], rtol=1e-12)
+    XN = np.array(fm.Variables.XN)
+    for ix in free:      # 1e-8 of the column, or the floor of a finite difference: a few units of round-off of YN over the step
+        sc = np.abs(res["staged"][1][:, ix]).max()
+        floor = 64 * np.finfo(float).eps * np.abs(res["staged"][0]).max() / abs(0.05 * XN[ix])
+        assert np.abs(res["profile"][1][:, ix] - res["staged"][1][:, ix]).max() <= 1e-8 * sc + floor, ix
