@@ -333,3 +333,37 @@ def test_routes_agree_on_a_limb_geometry(c1_cut):
         sc = np.abs(res["staged"][1][:, ix]).max()
         floor = 64 * np.finfo(float).eps * np.abs(res["staged"][0]).max() / abs(0.05 * XN[ix])
         assert np.abs(res["profile"][1][:, ix] - res["staged"][1][:, ix]).max() <= 1e-8 * sc + floor, ix
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_routes_agree_with_a_gas_profile_carried_as_logarithm(c1_cut):
+    """A second model-0 variable, the NH3 mixing-ratio profile: read_apr carries it as ln(vmr) (LX = 1; model_0.py
+    from_apr_to_state_vector), subprofretg un-logs it.  State vector of 162 elements, two temperature levels and two ln(vmr)
+    levels free: the profile route (exp where LX = 1, the gas column found from VARIDENT) against the reference's host code."""
+    ans, gj, fmod, double = c1_cut
+    Atm = ans.Files.read_input_files("cirstest")[0]
+    j = int(np.nonzero((np.asarray(Atm.ID) == 11) & (np.asarray(Atm.ISO) == 0))[0][0])
+    with open("nh3apr.dat", "w") as f:
+        f.write("%d 1.5\n" % Atm.NP)
+        for p_, v in zip(Atm.P / 101325.0, Atm.VMR[:, j]):
+            v = max(float(v), 1.0e-20)                 # the profile is zero above the cloud: ln needs a positive value
+            f.write("%.6e %.6e %.6e\n" % (p_, v, 0.5 * v))
+    with open("cirstest.apr", "w") as f:
+        f.write("header\n2\n0 0 0\ntestapr.dat\n11 0 0\nnh3apr.dat\n")
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    free = (8, 40, 81 + 3, 81 + 9)
+    res = {}
+    for route in ("profile", "staged"):
+        fm = gj.cut_case(ans, cls=FMGPU, nkeep=14, free=free)
+        assert fm.Variables.NX == 162 and np.all(fm.Variables.LX[81:] == 1) and np.all(fm.Variables.LX[:81] == 0)
+        fm.ansfm_jacobian_route = route
+        YN, KK = fm.jacobian_nemesis(NCores=1, analytical_gradient=False)
+        assert fm.ansfm_last_jacobian["route"] == route and fm.ansfm_last_jacobian["nfm"] == 5
+        res[route] = (YN, KK, np.array(fm.Variables.XN))
+    np.testing.assert_allclose(res["profile"][0], res["staged"][0], rtol=1e-13)
+    XN = res["staged"][2]
+    for ix in free:
+        sc = np.abs(res["staged"][1][:, ix]).max()
+        floor = 64 * np.finfo(float).eps * np.abs(res["staged"][0]).max() / abs(0.05 * XN[ix])
+        assert sc > 0 and np.abs(res["profile"][1][:, ix] - res["staged"][1][:, ix]).max() <= 1e-8 * sc + floor, ix
