@@ -12,6 +12,7 @@ EmissionsX), so tests drive it with plain namespaces rebuilt from the C1 golden 
 """
 import hashlib
 import os
+import sys
 
 import numpy as np
 
@@ -500,6 +501,41 @@ def make_gpu_forward_model(reference_forward_model_cls, device=0):
                 {"ansfm_device": device, "__doc__": reference_forward_model_cls.__doc__})
 
 
+def install_gpu_forward_model(device=0):
+    """Make the retrieval drivers build the GPU forward model: `coreretOE` imports the class at call time (`from archnemesis
+    import ForwardModel_0`, OptimalEstimation_0.py:1255) and `Retrievals` / `NestedSampling_0` build `ans.ForwardModel_0(...)`
+    (Retrievals.py:102, :181, :256), so the package attribute `archnemesis.ForwardModel_0` is what has to name the subclass
+    (the submodule of the same name stays reachable through importlib / sys.modules).  The reference's class is kept as
+    `archnemesis._ansfm_reference_ForwardModel_0`; calling this twice is harmless.  Returns the subclass."""
+    import importlib
+    pkg = importlib.import_module("archnemesis")
+    ref = getattr(pkg, "_ansfm_reference_ForwardModel_0", None)
+    if ref is None:
+        ref = pkg.ForwardModel_0
+        if not isinstance(ref, type):          # the attribute named the submodule (no star import of the class): take the class
+            ref = importlib.import_module("archnemesis.ForwardModel_0").ForwardModel_0
+        pkg._ansfm_reference_ForwardModel_0 = ref
+    cls = make_gpu_forward_model(ref, device)
+    pkg.ForwardModel_0 = cls
+    for modname in ("archnemesis.OptimalEstimation_0", "archnemesis.Retrievals", "archnemesis.NestedSampling_0"):
+        mod = sys.modules.get(modname)
+        if mod is not None and isinstance(getattr(mod, "ForwardModel_0", None), type):
+            mod.ForwardModel_0 = cls               # module-level `from archnemesis import ForwardModel_0` bindings
+    return cls
+
+
+def uninstall_gpu_forward_model():
+    import importlib
+    pkg = importlib.import_module("archnemesis")
+    ref = getattr(pkg, "_ansfm_reference_ForwardModel_0", None)
+    if ref is not None:
+        pkg.ForwardModel_0 = ref
+        for modname in ("archnemesis.OptimalEstimation_0", "archnemesis.Retrievals", "archnemesis.NestedSampling_0"):
+            mod = sys.modules.get(modname)
+            if mod is not None and isinstance(getattr(mod, "ForwardModel_0", None), type):
+                mod.ForwardModel_0 = ref
+
+
 def install_gpu_scattering_core(device=0):
     """Route the reference's multiple-scattering core through the GPU.
 
@@ -855,11 +891,14 @@ class Installed(list):
                                                                                      s["notes"] or "none")
 
 
-def install_all(device=0, oe_linalg=True, ktable_generator=True):
+def install_all(device=0, oe_linalg=True, ktable_generator=True, forward_model=True):
     """Every replacement this package has for the imported reference, in one call; returns the
     names installed as an `Installed` list whose `summary()` reports what was handed to the reference's CPU code since.
-    `make_gpu_forward_model` stays explicit: it returns a class."""
+    forward_model=True also makes `archnemesis.ForwardModel_0` name the GPU subclass (install_gpu_forward_model), so that
+    `coreretOE` / `retrieval_nemesis` build it."""
     done = Installed()
+    if forward_model:
+        install_gpu_forward_model(device); done.append("install_gpu_forward_model")
     for f in (install_gpu_gradient_maps, install_gpu_scattering_core, install_gpu_line_kernel, install_gpu_layering,
               install_gpu_convolution, install_gpu_continuum, install_gpu_table_reader):
         f(device); done.append(f.__name__)

@@ -367,3 +367,46 @@ def test_routes_agree_with_a_gas_profile_carried_as_logarithm(c1_cut):
         sc = np.abs(res["staged"][1][:, ix]).max()
         floor = 64 * np.finfo(float).eps * np.abs(res["staged"][0]).max() / abs(0.05 * XN[ix])
         assert sc > 0 and np.abs(res["profile"][1][:, ix] - res["staged"][1][:, ix]).max() <= 1e-8 * sc + floor, ix
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_coreretOE_runs_on_the_installed_subclass_and_retrieves_the_same_state(c1_cut):
+    """north_star: "drops into the existing OptimalEstimation_0 retrieval loop".  The reference's own `coreretOE`
+    (OptimalEstimation_0.py:1173-1584: forward model per iteration, jacobian_nemesis, gain matrix, Marquardt brake) is run twice
+    on the C1 case cut to 30 points, one iteration: unmodified, and after `install_gpu_forward_model()` -- coreretOE imports
+    `ForwardModel_0` from the package at call time (:1255), which then names the GPU subclass.  Same YN, KK, retrieved state
+    and cost; nothing delegated (strict mode); the engine (here its oracle double) did the radiative transfer."""
+    import importlib
+    import warnings
+    ans, gj, fmod, double = c1_cut
+    oe = importlib.import_module("archnemesis.OptimalEstimation_0")
+
+    def case():
+        Atm, Meas, Spec, Scat, Stel, Surf, CIA, Lay, Var, Ret = ans.Files.read_input_files("cirstest")
+        nk = 30
+        Meas.NCONV = np.array([nk], dtype="int32")
+        Meas.VCONV = Meas.VCONV[:nk]; Meas.MEAS = Meas.MEAS[:nk]; Meas.ERRMEAS = Meas.ERRMEAS[:nk]
+        Meas.NY = nk; Meas.Y = Meas.Y[:nk]; Meas.SE = Meas.SE[:nk, :nk]
+        return dict(runname="cirstest", Variables=Var, Measurement=Meas, Atmosphere=Atm, Spectroscopy=Spec, Scatter=Scat, Stellar=Stel,
+                    Surface=Surf, CIA=CIA, Layer=Lay, Telluric=None, NITER=1, PHILIMIT=0.1, NCores=1)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = oe.coreretOE(**case())
+        assert set(vars(double)) == {"orc"}                      # the reference ran on its own
+        cls = fmod.install_gpu_forward_model()
+        try:
+            assert ans.ForwardModel_0 is cls and issubclass(cls, ans._ansfm_reference_ForwardModel_0)
+            got = oe.coreretOE(**case())
+        finally:
+            fmod.uninstall_gpu_forward_model()
+    assert ans.ForwardModel_0 is ans._ansfm_reference_ForwardModel_0
+    assert hasattr(double, "t") and getattr(double, "lay_calls", 0) == 0   # the table and CIRSrad went to the engine (layering was not installed)
+    np.testing.assert_allclose(got.YN, ref.YN, rtol=5e-7)
+    sc = np.abs(ref.KK).max(axis=0)
+    big = sc > 1e-6 * sc.max()
+    assert np.max(np.abs(got.KK - ref.KK)[:, big] / sc[big]) < 1e-6     # analytic gradients (NUM = 0: nemesisfmg's route)
+    np.testing.assert_allclose(got.XN, ref.XN, rtol=1e-7)
+    np.testing.assert_allclose(got.PHI, ref.PHI, rtol=1e-5)
+    assert fmod.summary()["delegated"] == {}
