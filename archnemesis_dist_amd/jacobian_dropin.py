@@ -7,11 +7,11 @@ on a GPU that fan-out is the wrong shape: every worker would open its own contex
 override keeps the method's signature, state-vector arithmetic (:2234-2242), NUM / FIX / ISCAT rules (:2251-2255,
 :2291-2302) and quotient (:2348-2359), and replaces the fan-out by three in-process routes, tried in this order:
 
-  "profile"  every variable is a continuous profile (Models/PreRTModels/model_0.py), k-tables, thermal emission, no
-             hydrostatic re-adjustment, Rayleigh-only continuum: the state vector is mapped to
-             profile_state.ContinuousProfileState / BatchedCKThermalModel and ALL forward models are one
-             `layer_average` launch + one Rayleigh launch + one CIRSrad launch (jacobian.jacobian_nemesis_batched; sharded
-             over ranks when a process group is given).
+  "profile"  every variable is a continuous profile (Models/PreRTModels/model_0.py) or a scaling of one (model_2.py,
+             model_3.py) of temperature or a gas, k-tables, thermal emission, radiance units: profile_dropin.py maps the
+             reference's objects to ONE batched evaluation of all forward models -- hydrostatic re-adjustment, CIA / aerosol /
+             Rayleigh continuum, several geometries and averaging points included (sharded over ranks when a process group is
+             given).
   "staged"   any model of the reference's zoo, any continuum, several geometries / averaging points, hydrostatic
              re-adjustment, instrument convolution: the reference's OWN host code (select_Measurement, the deep copies,
              subprofretg, calc_path, the continuum routines) is run per state up to the point where nemesisfm would call

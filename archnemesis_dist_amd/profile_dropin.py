@@ -2,7 +2,8 @@
 jacobian_dropin.JacobianGPU).
 
 `batched_model_from_reference(fm)` looks at a ForwardModel_0 as `coreretOE` builds it (OptimalEstimation_0.py:1318) and,
-when every variable is a continuous profile (Models/PreRTModels/model_0.py) of temperature or of a gas mixing ratio,
+when every variable is a continuous profile (Models/PreRTModels/model_0.py) of temperature or of a gas mixing ratio, or a
+scaling factor of one (model_2.py, model_3.py),
 returns an object that does for n state vectors at once what `nemesisfm` (ForwardModel_0.py:437-589) does for one:
 
     subprofretg (:2397-2560)   hydrostatic re-adjustment of the heights (Atmosphere_0.adjust_hydrostatH :1027 with
@@ -125,18 +126,27 @@ def batched_model_from_reference(fm):
     ix = 0
     for ivar, mdl in enumerate(V.models):
         vid = np.asarray(V.VARIDENT).reshape(-1, 3)[ivar]
-        if int(getattr(mdl, "id", -999)) != 0 or int(vid[2]) != 0 or mdl.n_state_vector_entries != A.NP or mdl.state_vector_start != ix:
-            return None, "a variable that is not a continuous profile (model %s)" % vid[2]
+        mid, nent = int(getattr(mdl, "id", -999)), int(mdl.n_state_vector_entries)
+        # model 0: the profile itself, one element per level (model_0.py); models 2 / 3: ONE element that scales the profile
+        # of the reference atmosphere, carried as it is / as its logarithm (model_2.py, model_3.py: `profile *= scf`)
+        if mid == 0 and int(vid[2]) == 0 and nent == A.NP:
+            how = "profile"
+        elif mid in (2, 3) and int(vid[2]) == mid and nent == 1:
+            how = "scale"
+        else:
+            return None, "a variable that is neither a continuous profile nor a scaling of one (model %s)" % vid[2]
+        if mdl.state_vector_start != ix:
+            return None, "state vector not laid out variable after variable"
         if vid[0] == 0:
-            blocks.append(("T", None))
+            blocks.append(("T", None, how, ix, nent))
         elif vid[0] > 0:
             j = np.nonzero((np.asarray(A.ID) == vid[0]) & (np.asarray(A.ISO) == vid[1]))[0]
             if len(j) != 1:
                 return None, "gas of a variable not found once in the atmosphere"
-            blocks.append(("VMR", int(j[0])))
+            blocks.append(("VMR", int(j[0]), how, ix, nent))
         else:
             return None, "aerosol / para-H2 / cloud-fraction profile"
-        ix += mdl.n_state_vector_entries
+        ix += nent
     if ix != V.NX:
         return None, "state vector longer than its models"
     try:
@@ -176,12 +186,14 @@ class ReferenceProfileBatch:
         vals = np.where(self.LX[None, :] > 0, np.exp(X), X)         # ModelBase.get_parameter_values_from_state_vector
         T = np.repeat(self.T0[None], n, 0)
         VMR = np.repeat(self.VMR0[None], n, 0)
-        for b, (kind, j) in enumerate(self.blocks):
-            xb = vals[:, b * self.NP:(b + 1) * self.NP]
+        for kind, j, how, ix, nent in self.blocks:        # in the order of the variables, like subprofretg's loop (:2500-2510)
+            xb = vals[:, ix:ix + nent]
             if kind == "T":
-                T = xb.copy()
-            else:
+                T = xb.copy() if how == "profile" else T * xb
+            elif how == "profile":
                 VMR[:, :, j] = xb
+            else:
+                VMR[:, :, j] = VMR[:, :, j] * xb
         H = np.repeat(self.H1[None], n, 0)
         if self.hydro:                                               # second adjustment, with the state's temperatures
             H = adjust_hydrostat_heights(H, self.P, T, self.MOLWT[None], self.grav)

@@ -410,3 +410,30 @@ def test_coreretOE_runs_on_the_installed_subclass_and_retrieves_the_same_state(c
     np.testing.assert_allclose(got.XN, ref.XN, rtol=1e-7)
     np.testing.assert_allclose(got.PHI, ref.PHI, rtol=1e-5)
     assert fmod.summary()["delegated"] == {}
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_routes_agree_with_scaling_models(c1_cut):
+    """Models 2 and 3 of the reference (one state-vector element scaling a profile of the reference atmosphere, carried as it
+    is / as its logarithm): a temperature profile (model 0), a CH4 scaling (model 2) and a log scaling of PH3 (model 3).  The
+    profile route restates them (`profile *= value`, exp where LX = 1) -- same KK as the reference's own subprofretg."""
+    ans, gj, fmod, double = c1_cut
+    with open("cirstest.apr", "w") as f:
+        f.write("header\n3\n0 0 0\ntestapr.dat\n6 1 2\n1.1 0.3\n28 0 3\n0.9 0.4\n")
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    free = (12, 50, 81, 82)
+    res = {}
+    for route in ("profile", "staged"):
+        fm = gj.cut_case(ans, cls=FMGPU, nkeep=14, free=free)
+        assert fm.Variables.NX == 83 and [int(m.id) for m in fm.Variables.models] == [0, 2, 3]
+        fm.ansfm_jacobian_route = route
+        YN, KK = fm.jacobian_nemesis(NCores=1, analytical_gradient=False)
+        assert fm.ansfm_last_jacobian["route"] == route and fm.ansfm_last_jacobian["nfm"] == 5
+        res[route] = (YN, KK, np.array(fm.Variables.XN))
+    np.testing.assert_allclose(res["profile"][0], res["staged"][0], rtol=1e-13)
+    XN = res["staged"][2]
+    for ix in free:
+        sc = np.abs(res["staged"][1][:, ix]).max()
+        floor = 64 * np.finfo(float).eps * np.abs(res["staged"][0]).max() / abs(0.05 * XN[ix] if XN[ix] != 0 else 0.05)
+        assert sc > 0 and np.abs(res["profile"][1][:, ix] - res["staged"][1][:, ix]).max() <= 1e-8 * sc + floor, ix
