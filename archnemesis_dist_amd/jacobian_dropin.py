@@ -102,7 +102,19 @@ class JacobianGPU:
         if want not in ("auto", "loop") and not routes:
             raise ValueError("jacobian_nemesis: route %r is not available for these flags" % (want,))
         for name, fn in routes:
-            Y = fn(xnx, ixrun, info)
+            if want == name:                     # a forced route fails loudly
+                Y = fn(xnx, ixrun, info)
+            else:
+                # "auto": a route that stumbles over something it did not foresee must not take the retrieval down -- the next
+                # route is closer to the reference's own code, and the last one IS the reference's code, which raises
+                # whatever the reference would have raised
+                try:
+                    Y = fn(xnx, ixrun, info)
+                except Exception as exc:         # noqa: BLE001 -- recorded, announced once, and the next route takes over
+                    info["error_" + name] = "%s: %s" % (type(exc).__name__, exc)
+                    _fm._note("jacobian_nemesis: the %s route failed (%s: %s); falling back" % (name, type(exc).__name__, exc))
+                    self.Variables.XN = xnx[:, 0].copy()
+                    Y = None
             if Y is not None:
                 info["route"] = name
                 return Y

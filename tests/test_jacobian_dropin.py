@@ -437,3 +437,26 @@ def test_routes_agree_with_scaling_models(c1_cut):
         sc = np.abs(res["staged"][1][:, ix]).max()
         floor = 64 * np.finfo(float).eps * np.abs(res["staged"][0]).max() / abs(0.05 * XN[ix] if XN[ix] != 0 else 0.05)
         assert sc > 0 and np.abs(res["profile"][1][:, ix] - res["staged"][1][:, ix]).max() <= 1e-8 * sc + floor, ix
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_auto_route_falls_back_when_a_route_stumbles(c1_cut, golden_dir, monkeypatch):
+    """`auto` never takes a retrieval down because a batched route met something it did not foresee: the failure is recorded,
+    announced once as a RuntimeWarning, and the next route (closer to the reference's own code) gives the same KK."""
+    ans, gj, fmod, double = c1_cut
+    import archnemesis_dist_amd.profile_dropin as pd
+    z = _load(golden_dir)
+    monkeypatch.setattr(pd.ReferenceProfileBatch, "spectra_batch", lambda self, X: (_ for _ in ()).throw(KeyError("unforeseen")))
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    fm = gj.cut_case(ans, cls=FMGPU)
+    XN0 = np.array(fm.Variables.XN)
+    with pytest.warns(RuntimeWarning, match="profile route failed"):
+        YN, KK = fm.jacobian_nemesis(NCores=1, analytical_gradient=False)
+    info = fm.ansfm_last_jacobian
+    assert info["route"] == "staged" and "KeyError" in info["error_profile"]
+    assert np.array_equal(fm.Variables.XN, XN0)
+    _assert_kk(KK, z, 1e-4, tight=1e-8)
+    fm.ansfm_jacobian_route = "profile"          # forced: the error surfaces
+    with pytest.raises(KeyError):
+        fm.jacobian_nemesis(NCores=1, analytical_gradient=False)
