@@ -2508,8 +2508,15 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
                 lf = 0;
             lstart[m] = std::min(lf / kMsPrefixStep, npre) * kMsPrefixStep;
         }
-        HIPCHK(ctx->ms_lstart.reserve((size_t)n_models * sizeof(int)));
+        // launch order of models 1 .. n-1: by sweep start, so that the blocks of one launch read the same layers of the cache at
+        // about the same time (position 0 of the list is unused: model 0 has its own launch)
+        std::vector<int> ids((size_t)n_models, 0);
+        for (int m = 0; m < n_models; ++m) ids[m] = m;
+        std::stable_sort(ids.begin() + 1, ids.end(), [&](int a, int b) { return lstart[a] < lstart[b]; });
+        HIPCHK(ctx->ms_lstart.reserve((size_t)2 * n_models * sizeof(int)));
         HIPCHK(hipMemcpyAsync(ctx->ms_lstart.p, lstart.data(), (size_t)n_models * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->ms_lstart.as<int>() + n_models, ids.data(), (size_t)n_models * sizeof(int), hipMemcpyHostToDevice,
+                              ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     // ---- phase matrices and Hansen factors: once, they do not depend on the model -----------------------------------------
@@ -2531,7 +2538,8 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
     if (const char *ev = getenv("ANSFM_MS_SLAB")) { const long v = atol(ev); if (v >= 1) Ws = std::min(Ws, v); }
     if (Ws < 1) FAIL(ANSFM_ERR_HIP, "cirsrad_ck_scatter_batch: no memory for the layer cache of one wavenumber");
     if (Ws > W) Ws = W;
-    const int mchunk = std::min(n_models - 1, 64);
+    int mchunk = std::min(n_models - 1, 64);
+    if (const char *ev = getenv("ANSFM_MS_CHUNK")) { const int v = atoi(ev); if (v >= 1) mchunk = std::min(n_models - 1, v); }
     HIPCHK(ctx->ms_cache.reserve((size_t)Ws * per_w_layers));
     HIPCHK(ctx->ms_pcache.reserve(std::max<size_t>((size_t)Ws * per_w_pre, 8)));
     HIPCHK(ctx->ms_orders.reserve((size_t)Ws * G * sizeof(int)));
@@ -2544,6 +2552,7 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
     p.taus = ctx->ms_taus.as<double>(); p.omegas = ctx->ms_omegas.as<double>(); p.bnu = ctx->ms_bnu.as<double>();
     p.cache = ctx->ms_cache.as<double>(); p.cache_orders = ctx->ms_orders.as<int>(); p.same = same;
     p.pcache = ctx->ms_pcache.as<double>(); p.lstart = ctx->ms_lstart.as<int>(); p.npre = npre;
+    p.model_ids = ctx->ms_lstart.as<int>() + n_models;
     p.st_wl = st_wl; p.st_wcl = (size_t)W * ncont * L; p.st_wm = (size_t)W * nmu; p.st_rad = (size_t)ngeom * G * W;
     p.phase_lds = 0; p.ig0 = 0; p.ng_launch = G;
     MsOpticsBatchParams o;
@@ -2559,7 +2568,7 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
         p.w0 = (int)w0; p.wcount = wc;
         o.w0 = (int)w0; o.wcount = wc;
         // model 0: the ordinary chain, which also fills the cache
-        o.m0 = 0; o.nm = 1;
+        o.m0 = 0; o.nm = 1; o.model_ids = nullptr;
         hipLaunchKernelGGL(k_ms_optics_batch, dim3(nblk((size_t)wc, 128), (unsigned)L, 1), dim3(128), 0, ctx->stream, o);
         p.m0 = 0; p.n_launch = 1;
         hipLaunchKernelGGL((k_ms_chain16<false, 1>), dim3((unsigned)((size_t)wc * G)), dim3(64), lds16, ctx->stream, p);
@@ -2567,7 +2576,7 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
         // models 1 .. n-1 in chunks: the adding sweep over cached layers, changed layers computed in place
         for (int m0 = 1; m0 < n_models; m0 += mchunk) {
             const int nm = std::min(mchunk, n_models - m0);
-            o.m0 = m0; o.nm = nm;
+            o.m0 = m0; o.nm = nm; o.model_ids = p.model_ids;
             hipLaunchKernelGGL(k_ms_optics_batch, dim3(nblk((size_t)wc, 128), (unsigned)L, (unsigned)nm), dim3(128), 0, ctx->stream, o);
             p.m0 = m0; p.n_launch = nm;
             const size_t pairs8 = ((size_t)wc * G + 7) / 8;

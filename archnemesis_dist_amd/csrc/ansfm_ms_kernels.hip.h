@@ -62,6 +62,8 @@ struct MsParams {
     const unsigned char *same;   // [n_models][nlay]: the layer's inputs are bit-identical to model 0's
     double *pcache;          // [wcount][ng][nf+1][npre][528]: model 0's STACK (rc, tc, jc) after every kMsPrefixStep-th layer of the sweep
     const int *lstart;       // [n_models]: sweep index (multiple of kMsPrefixStep) a model's adding sweep may start from
+    const int *model_ids;    // CACHE = 2: the models in launch order (sorted by lstart: the blocks of one launch then walk the same
+                             // layers at about the same time and find model 0's cache lines in L2); model of block ml = ids[m0 + ml]
     int npre;
     size_t st_wl, st_wcl, st_wm, st_rad;   // strides between models: tauray [W][L], lfrac [W][ncont][L], radg [W][nmu], rad
 };
@@ -788,7 +790,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         ig = p.ig0 + (int)(blockIdx.x % p.ng_launch);
         widx = p.w0 + (int)(blockIdx.x / p.ng_launch);
     }
-    const int wl = widx - p.w0, mg = p.m0 + ml;
+    int mg = p.m0 + ml;
+    if constexpr (CACHE == 2) mg = p.model_ids[p.m0 + ml];
+    const int wl = widx - p.w0;
     int ncached = 0;
     if constexpr (CACHE == 2) ncached = p.cache_orders[(size_t)wl * p.ng + ig];
     int ndone = 0;
@@ -1227,13 +1231,14 @@ struct MsOpticsBatchParams {
     const double *lay_temp;     // [n][L]
     double *taus, *omegas;      // [nm][wcount][G][L]
     double *bnu;                // [nm][wcount][L]
+    const int *model_ids;       // launch position -> model (null: position m0 + ml is the model)
     int W, Wpad, G, L, ispace, w0, wcount, m0, nm;
 };
 __global__ __launch_bounds__(128) void k_ms_optics_batch(MsOpticsBatchParams p)
 {
     const int wl = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, ml = blockIdx.z;
     if (wl >= p.wcount) return;
-    const int w = p.w0 + wl, m = p.m0 + ml;
+    const int w = p.w0 + wl, m = p.model_ids ? p.model_ids[p.m0 + ml] : p.m0 + ml;
     const size_t in = ((size_t)m * p.W + w) * p.L + l;
     const double cia = p.taucia ? p.taucia[in] : 0.0, dust = p.taudust ? p.taudust[in] : 0.0;
     const double ray = p.tauray ? p.tauray[in] : 0.0, sca = p.tauscat ? p.tauscat[in] : 0.0;
