@@ -1919,8 +1919,23 @@ int ansfm_calc_tau_rayleigh(ansfm_ctx *ctx, int mode, int ISPACE, int W, const d
     return ANSFM_OK;
 }
 
+static int rayleigh_batch_impl(ansfm_ctx *ctx, int mode, int ISPACE, int n_models, int L, const double *TOTAM,
+                               const double *f4, double *TAURAY_dev, bool dev_in);
+
 int ansfm_calc_tau_rayleigh_batch_dev(ansfm_ctx *ctx, int mode, int ISPACE, int n_models, int L, const double *TOTAM,
                                       const double *f4, double *TAURAY_dev)
+{
+    return rayleigh_batch_impl(ctx, mode, ISPACE, n_models, L, TOTAM, f4, TAURAY_dev, false);
+}
+
+int ansfm_calc_tau_rayleigh_batch_dev_in(ansfm_ctx *ctx, int mode, int ISPACE, int n_models, int L, const double *TOTAM_dev,
+                                         const double *f4_dev, double *TAURAY_dev)
+{
+    return rayleigh_batch_impl(ctx, mode, ISPACE, n_models, L, TOTAM_dev, f4_dev, TAURAY_dev, true);
+}
+
+static int rayleigh_batch_impl(ansfm_ctx *ctx, int mode, int ISPACE, int n_models, int L, const double *TOTAM,
+                               const double *f4, double *TAURAY_dev, bool dev_in)
 {
     CHECK_CTX(ctx);
     if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "calc_tau_rayleigh_batch_dev: upload a table first (its wavenumber grid is used)");
@@ -1931,8 +1946,11 @@ int ansfm_calc_tau_rayleigh_batch_dev(ansfm_ctx *ctx, int mode, int ISPACE, int 
     const size_t D = sizeof(double), nl = (size_t)n_models * L;
     const void *d[2] = {nullptr, nullptr};
     int rc;
-    if ((rc = h2d(ctx, ctx->hb[1], TOTAM, nl * D, &d[0]))) return rc;
-    if ((rc = h2d(ctx, ctx->hb[2], f4, mode == 4 ? nl * 4 * D : 0, &d[1]))) return rc;
+    if (dev_in) { d[0] = TOTAM; d[1] = (mode == 4) ? f4 : nullptr; }
+    else {
+        if ((rc = h2d(ctx, ctx->hb[1], TOTAM, nl * D, &d[0]))) return rc;
+        if ((rc = h2d(ctx, ctx->hb[2], f4, mode == 4 ? nl * 4 * D : 0, &d[1]))) return rc;
+    }
     RayParams p;
     memset(&p, 0, sizeof p);
     p.wavec = ctx->d_wave.as<double>(); p.totam = (const double *)d[0]; p.f4 = (const double *)d[1];
@@ -1940,7 +1958,7 @@ int ansfm_calc_tau_rayleigh_batch_dev(ansfm_ctx *ctx, int mode, int ISPACE, int 
     p.W = ctx->W; p.L = (int)nl; p.mode = mode; p.ispace = ISPACE; p.Lm = L;
     hipLaunchKernelGGL(k_tau_rayleigh, dim3(nblk((size_t)ctx->W * nl, 128)), dim3(128), 0, ctx->stream, p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));       // the pinned-size host staging buffers are reused by the next call
+    if (!dev_in) HIPCHK(hipStreamSynchronize(ctx->stream));       // the host staging buffers are reused by the next call
     return ANSFM_OK;
 }
 
@@ -2780,9 +2798,13 @@ static int layer_average_impl(ansfm_ctx *ctx, int n_models, double RADIUS, int N
                               int NINT, const int32_t *DUST_UNITS, const double *XMOLWT, double *HEIGHT, double *PRESS,
                               double *TEMP, double *TOTAM, double *AMOUNT, double *PP, double *CONT, double *FRAC,
                               double *DELH, double *BASET, double *LAYSF, bool with_grad, double *DTE, double *DAM,
-                              double *DCO, double *DPH)
+                              double *DCO, double *DPH, double *dev_out = nullptr)
 {
+    // dev_out != nullptr: H .. XMOLWT and BASEH are DEVICE arrays and the results stay in dev_out (layout of
+    // ansfm_layer_average_dev); the host result pointers are not used
     CHECK_CTX(ctx);
+    const bool dev = dev_out != nullptr;
+    if (dev) HEIGHT = PRESS = TEMP = TOTAM = AMOUNT = PP = FRAC = DELH = BASET = LAYSF = CONT = dev_out;
     int any_units = 0;
     if (DUST_UNITS) for (int j = 0; j < NDUST; ++j) if (DUST_UNITS[j] == -1) any_units = 1;
     if (with_grad) {
@@ -2805,19 +2827,19 @@ static int layer_average_impl(ansfm_ctx *ctx, int n_models, double RADIUS, int N
     const size_t D = sizeof(double), n = n_models;
     const void *d[10];
     int i = 0, rc;
-#define UP(ptr, bytes) do { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; ++i; } while (0)
+#define UP(ptr, bytes) do { if (dev) d[i] = ptr; else { rc = h2d(ctx, ctx->hb[i], ptr, bytes, &d[i]); if (rc) return rc; } ++i; } while (0)
     UP(H, n * NPRO * D); UP(P, n * NPRO * D); UP(T, n * NPRO * D);              // 0 1 2
     UP(VMR, n * NPRO * NVMR * D);                                               // 3
     UP(DUST, n * NPRO * NDUST * D);                                             // 4
     UP(PARAH2, n * NPRO * D);                                                   // 5
     UP(XMOLWT, n * NPRO * D);                                                   // 6
     UP(BASEH, n * NLAY * D);                                                    // 7
-    UP(DUST_UNITS, (size_t)NDUST * sizeof(int32_t));                            // 8
 #undef UP
+    rc = h2d(ctx, ctx->hb[8], DUST_UNITS, (size_t)NDUST * sizeof(int32_t), &d[8]); if (rc) return rc;   // always a host array
     const size_t nl = n * NLAY;
     const size_t tot = nl * (8 + 2 * (size_t)NVMR + NDUST) + (with_grad ? 4 * nl * NPRO : 0);
-    HIPCHK(ctx->tmp_out.reserve(tot * D));
-    double *o = ctx->tmp_out.as<double>();
+    if (!dev) HIPCHK(ctx->tmp_out.reserve(tot * D));
+    double *o = dev ? dev_out : ctx->tmp_out.as<double>();
     LayerAvgParams p;
     memset(&p, 0, sizeof p);
     p.H = (const double *)d[0]; p.P = (const double *)d[1]; p.T = (const double *)d[2]; p.VMR = (const double *)d[3];
@@ -2832,8 +2854,19 @@ static int layer_average_impl(ansfm_ctx *ctx, int n_models, double RADIUS, int N
         p.DTE = p.CONT + nl * NDUST; p.DAM = p.DTE + nl * NPRO; p.DCO = p.DAM + nl * NPRO; p.DPH = p.DCO + nl * NPRO;
         HIPCHK(hipMemsetAsync(p.DTE, 0, 4 * nl * NPRO * D, ctx->stream));
     }
-    hipLaunchKernelGGL(k_layer_average, dim3((unsigned)NLAY, (unsigned)n_models), dim3(128), 0, ctx->stream, p);
+    // several states without gradients: state 0 first, then the others, which take state 0's layers where their levels agree
+    static const bool share_off = [] { const char *e = getenv("ANSFM_LAYER_SHARE"); return e && e[0] == '0'; }();
+    if (n_models > 1 && !with_grad && !share_off) {
+        hipLaunchKernelGGL(k_layer_average, dim3((unsigned)NLAY, 1u), dim3(128), 0, ctx->stream, p);
+        p.m0 = 1; p.share = 1;
+        hipLaunchKernelGGL(k_layer_average, dim3((unsigned)NLAY, (unsigned)(n_models - 1)), dim3(128), 0, ctx->stream, p);
+    } else
+        hipLaunchKernelGGL(k_layer_average, dim3((unsigned)NLAY, (unsigned)n_models), dim3(128), 0, ctx->stream, p);
     HIPCHK(hipGetLastError());
+    if (dev) {
+        if (DUST_UNITS && NDUST > 0) HIPCHK(hipStreamSynchronize(ctx->stream));   // its staging buffer is reused by the next call
+        return ANSFM_OK;
+    }
     double *outs[8] = {HEIGHT, PRESS, TEMP, TOTAM, FRAC, DELH, BASET, LAYSF};
     for (int k = 0; k < 8; ++k) HIPCHK(hipMemcpyAsync(outs[k], o + k * nl, nl * D, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(AMOUNT, p.AMOUNT, nl * NVMR * D, hipMemcpyDeviceToHost, ctx->stream));
@@ -2871,6 +2904,17 @@ int ansfm_layer_averageg(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, 
     return layer_average_impl(ctx, n_models, RADIUS, NPRO, H, P, T, NVMR, VMR, NDUST, DUST, PARAH2, NLAY, BASEH, LAYANG, LAYINT,
                               LAYHT, NINT, DUST_UNITS, XMOLWT, HEIGHT, PRESS, TEMP, TOTAM, AMOUNT, PP, CONT, FRAC, DELH, BASET,
                               LAYSF, true, DTE, DAM, DCO, DPH);
+}
+
+int ansfm_layer_average_dev(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, const double *H, const double *P,
+                            const double *T, int NVMR, const double *VMR, int NDUST, const double *DUST,
+                            const double *PARAH2, int NLAY, const double *BASEH, double LAYANG, int LAYINT, double LAYHT,
+                            int NINT, const int32_t *DUST_UNITS, const double *XMOLWT, double *out_dev)
+{
+    if (!out_dev) { CHECK_CTX(ctx); FAIL(ANSFM_ERR_INVALID, "layer_average_dev: bad argument"); }
+    return layer_average_impl(ctx, n_models, RADIUS, NPRO, H, P, T, NVMR, VMR, NDUST, DUST, PARAH2, NLAY, BASEH, LAYANG, LAYINT,
+                              LAYHT, NINT, DUST_UNITS, XMOLWT, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, false, nullptr, nullptr, nullptr, nullptr, out_dev);
 }
 
 }  // extern "C"

@@ -34,6 +34,10 @@ struct LayerAvgParams {
     // matrices DTE, DAM, DCO, DPH [n][NLAY][NPRO] (zeroed by the caller)
     int with_grad, any_dust_units;
     double *DTE, *DAM, *DCO, *DPH;
+    // A numerical Jacobian's states differ from state 0 at one profile level or two: m0 = first state of this launch; share != 0
+    // (launched after state 0's own launch, without gradients): a layer whose sub-points read only levels at which the state
+    // holds state 0's very numbers takes state 0's results instead of integrating again -- same bits either way
+    int m0, share;
 };
 
 // Layer_0.interpg (:716-751): j = clip(#{x <= X}, 1, n-1)
@@ -67,9 +71,10 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
     __shared__ int idx[kLayMaxNint], jg[kLayMaxNint];
     __shared__ double FF[kLayMaxNint];
     __shared__ double res[160];
+    __shared__ int lv_lo, lv_hi;
     const bool GR = p.with_grad != 0;
     const double k_B = 1.38065e-23, AVOGAD = 6.02214076e23, PI = 3.141592653589793;
-    const int I = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+    const int I = blockIdx.x, m = blockIdx.y + p.m0, tid = threadIdx.x;
     const int NPRO = p.NPRO, V = p.NVMR, D = p.NDUST, NL = p.NLAY;
     const double *H = p.H + (size_t)m * NPRO, *P = p.P + (size_t)m * NPRO, *T = p.T + (size_t)m * NPRO;
     const double *VMR = p.VMR + (size_t)m * NPRO * V;
@@ -86,6 +91,9 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
     const double DELH = (I < NL - 1) ? BASEH[I + 1] - BASEH[I] : H[NPRO - 1] - BASEH[NL - 1];
     const double LAYSF = DELS / DELH;
     const int npts = (p.LAYINT == 0) ? 1 : p.NINT;
+    const bool sharing = p.share != 0 && m > 0 && !GR;
+    if (sharing && tid == 0) { lv_lo = NPRO; lv_hi = 0; }
+    if (sharing) __syncthreads();
     // ---- phase 1: sub-points -------------------------------------------------------------------------
     for (int k = tid; k < npts; k += blockDim.x) {
         double s;
@@ -104,8 +112,43 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
         S[k] = s; hh[k] = h; idx[k] = ix; pp[k] = pk;
         duds[k] = pk / (k_B * tk);
         mw[k] = XM ? lay_interp(H, XM, 1, ix, h) * 1000. : 0.0;       // XMOLWT *= 1000 :877
+        if (sharing) { atomicMin(&lv_lo, ix - 1); atomicMax(&lv_hi, ix); }
     }
     __syncthreads();
+    if (sharing) {
+        // the levels this layer reads: the brackets of its sub-points and of its base (BASET); the top level enters SMAX
+        const int ib = lay_bracket(H, NPRO, BASEH[I]);
+        const int lo = min(lv_lo, ib - 1), hi = max(lv_hi, ib);
+        const int nlev = hi - lo + 1, per = 4 + V + D + (XM ? 1 : 0);
+        int differs = 0;
+        auto ne = [](double a, double b) { return __double_as_longlong(a) != __double_as_longlong(b); };
+        for (int e = tid; e < nlev * per; e += blockDim.x) {
+            const int lev = lo + e / per, f = e % per;
+            bool d;
+            if (f == 0) d = ne(H[lev], p.H[lev]);
+            else if (f == 1) d = ne(P[lev], p.P[lev]);
+            else if (f == 2) d = ne(T[lev], p.T[lev]);
+            else if (f == 3) d = PH2 ? ne(PH2[lev], p.PARAH2[lev]) : false;
+            else if (f < 4 + V) d = ne(VMR[(size_t)lev * V + (f - 4)], p.VMR[(size_t)lev * V + (f - 4)]);
+            else if (f < 4 + V + D) d = ne(DUST[(size_t)lev * D + (f - 4 - V)], p.DUST[(size_t)lev * D + (f - 4 - V)]);
+            else d = ne(XM[lev], p.XMOLWT[lev]);
+            differs |= d ? 1 : 0;
+        }
+        if (tid == 0) {
+            differs |= ne(H[NPRO - 1], p.H[NPRO - 1]) || ne(BASEH[I], p.BASEH[I]) ||
+                       (I < NL - 1 && ne(BASEH[I + 1], p.BASEH[I + 1]));
+        }
+        if (!__syncthreads_or(differs)) {
+            const size_t o = (size_t)m * NL + I, b = I;
+            if (tid == 0) {
+                p.HEIGHT[o] = p.HEIGHT[b]; p.PRESS[o] = p.PRESS[b]; p.TEMP[o] = p.TEMP[b]; p.TOTAM[o] = p.TOTAM[b];
+                p.FRAC[o] = p.FRAC[b]; p.DELH[o] = p.DELH[b]; p.BASET[o] = p.BASET[b]; p.LAYSF[o] = p.LAYSF[b];
+            }
+            for (int J = tid; J < V; J += blockDim.x) { p.AMOUNT[o * V + J] = p.AMOUNT[b * V + J]; p.PP[o * V + J] = p.PP[b * V + J]; }
+            for (int J = tid; J < D; J += blockDim.x) p.CONT[o * D + J] = p.CONT[b * D + J];
+            return;
+        }
+    }
     // ---- phase 2: one thread per integrated quantity ----------------------------------------------------
     const int NQ = 5 + 2 * V + D;
     for (int q = tid; q < NQ; q += blockDim.x) {

@@ -585,6 +585,33 @@ class AnsfmEngine:
             self._check(self._lib.ansfm_layer_average(*args), "layer_average")
         return tuple(a[0] for a in out) if single else out
 
+    def layer_average_dev(self, RADIUS, H, P, T, VMR, DUST, PARAH2, BASEH, LAYANG=0.0, LAYINT=0, LAYHT=0.0, NINT=101,
+                          DUST_UNITS=None, XMOLWT=None):
+        """Layer_0.layer_average for n states whose profiles are torch device tensors -- H, P, T (n, NPRO), VMR (n, NPRO,
+        NVMR), DUST (n, NPRO, NDUST) / PARAH2 / XMOLWT (n, NPRO) or None, BASEH (n, NLAY), all float64 and contiguous --
+        with the layers left in HBM: dict of device tensors HEIGHT .. LAYSF (n, NLAY), AMOUNT, PP (n, NLAY, NVMR), CONT
+        (n, NLAY, NDUST), views of one buffer.  Asynchronous on the engine's stream."""
+        import torch
+        n, NPRO = H.shape
+        NV = VMR.shape[2]; NL = BASEH.shape[1]
+        ND = 0 if DUST is None else DUST.shape[2]
+        for a in (H, P, T, VMR, DUST, PARAH2, XMOLWT, BASEH):
+            if a is not None and (a.dtype != torch.float64 or not a.is_contiguous() or not a.is_cuda or a.shape[0] != n):
+                raise ValueError("layer_average_dev: contiguous float64 device tensors with the state axis first")
+        nl = n * NL
+        buf = torch.empty(nl * (8 + 2 * NV + ND), dtype=torch.float64, device=H.device)
+        rc = self._lib.ansfm_layer_average_dev(self._ctx, n, float(RADIUS), NPRO, _ptr(H), _ptr(P), _ptr(T), NV, _ptr(VMR), ND,
+                                               _ptr(DUST), _ptr(PARAH2), NL, _ptr(BASEH), float(LAYANG), int(LAYINT), float(LAYHT),
+                                               int(NINT), _ptr(_np(DUST_UNITS, np.int32)), _ptr(XMOLWT), _ptr(buf))
+        self._check(rc, "layer_average_dev")
+        out = {name: buf[k * nl:(k + 1) * nl].view(n, NL)
+               for k, name in enumerate(("HEIGHT", "PRESS", "TEMP", "TOTAM", "FRAC", "DELH", "BASET", "LAYSF"))}
+        o = 8 * nl
+        out["AMOUNT"] = buf[o:o + nl * NV].view(n, NL, NV); o += nl * NV
+        out["PP"] = buf[o:o + nl * NV].view(n, NL, NV); o += nl * NV
+        out["CONT"] = buf[o:o + nl * ND].view(n, NL, ND)
+        return out
+
     def map2pro(self, dSPECIN, NWAVE, NVMR, NDUST, NPRO, NPATH, NLAYIN, LAYINC, DTE, DAM, DCO, INCPAR=(-1,), to_host=True):
         """ForwardModel_0.map2pro (:5319), same arguments -> dSPECOUT (NWAVE, NVMR+2+NDUST, NPRO, NPATH).
         When dSPECIN is the very array the last cirsradg_ck_thermal call returned, its device copy is used
@@ -719,11 +746,29 @@ class AnsfmEngine:
     def calc_tau_rayleigh_batch_dev(self, IRAY, ISPACE, TOTAM, out, ID=None, ISO=None, VMR=None, variant=None):
         """calc_tau_rayleigh (:4869) for the n states of a batch on the uploaded table's wavenumber grid, left in HBM:
         TOTAM (n, NLAY) host, VMR (n, NLAY, NVMR) host for IRAY 4, out = torch device tensor (n, NWAVE, NLAY) float64."""
-        TOTAM = _np(TOTAM)
-        n, L = TOTAM.shape
         mode = 12 if variant == "v" else int(IRAY)
         if mode not in (1, 2, 4, 12):
             raise ValueError("error in CIRSrad :: IRAY = " + str(IRAY) + " type has not been implemented yet")
+        if not isinstance(TOTAM, np.ndarray) and hasattr(TOTAM, "data_ptr"):      # torch device tensors (layer_average_dev)
+            import torch
+            n, L = TOTAM.shape
+            f4 = None
+            if mode == 4:
+                f4 = torch.zeros((n, L, 4), dtype=torch.float64, device=TOTAM.device)
+                ID = np.asarray(ID); ISO = np.asarray(ISO)
+                for j in range(ID.size):
+                    if ISO[j] in (0, 1):
+                        col = {39: 0, 40: 1, 6: 2, 11: 3}.get(int(ID[j]))
+                        if col is not None:
+                            f4[:, :, col] = VMR[:, :, j]
+            if tuple(out.shape)[0] != n or tuple(out.shape)[2] != L or not out.is_contiguous() or not TOTAM.is_contiguous():
+                raise ValueError("out must be a contiguous (n, NWAVE, NLAY) float64 device tensor")
+            rc = self._lib.ansfm_calc_tau_rayleigh_batch_dev_in(self._ctx, mode, int(ISPACE), n, L, _ptr(TOTAM), _ptr(f4), _ptr(out))
+            self._check(rc, "calc_tau_rayleigh_batch_dev")
+            self._keep = (TOTAM, f4)          # alive until the next call: the kernel may still be queued
+            return out
+        TOTAM = _np(TOTAM)
+        n, L = TOTAM.shape
         f4 = None
         if mode == 4:
             ID = np.asarray(ID); ISO = np.asarray(ISO); VMR = _np(VMR).reshape(n, L, -1)

@@ -133,15 +133,68 @@ class BatchedCKThermalModel:
         lay["VMRLAY"] = lay["PP"] / lay["PRESS"][:, :, None]          # Layer_0: PP / PRESS is the layer's mixing ratio
         return lay
 
+    # ---- the same with the layers left in HBM ----------------------------------------------------------------------
+    device_layers = True      # False: `layers` (host arrays) feeds spectra_batch, as in rounds 1-2; same numbers bit for bit
+
+    def layers_dev(self, X, dev, order=lambda: None, drain=lambda: None):
+        """`layers` without the round trip over PCIe: the profiles of the n states are put together on the device (the
+        elements of the state vector are the only thing uploaded: exp() of a log-VMR block is taken on the host, as
+        `profiles` takes it), k_layer_average leaves the layers in HBM, the arrays CIRSrad and the Rayleigh kernel want are
+        views / gathers of them.  The ray geometry depends on the layer grid only and stays on the host.  -> dict of device
+        tensors (PRESS, TEMP, TOTAM, amount, VMRLAY, EMTEMP) and "path".  order / drain: called before / after the engine's
+        kernel when torch and the engine do not share a stream."""
+        import torch
+        st, la, ge = self.state, self.lay, self.geo
+        X = np.atleast_2d(np.asarray(X, float))
+        n = X.shape[0]
+        td = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        key = (n, str(dev))
+        c = getattr(self, "_dev_consts", None)
+        if c is None or c["key"] != key:
+            rep = lambda a: td(a)[None].expand((n,) + np.shape(a)).contiguous()
+            DELH0 = np.append(self.BASEH[1:] - self.BASEH[:-1], st.H[-1] - self.BASEH[-1])      # k_layer_average's DELH
+            path = layering.calc_path(self.RADIUS, self.BASEH, DELH0, np.zeros(self.BASEH.size), float(st.H[-1]),
+                                      pointing=ge["pointing"], BOTLAY=ge["BOTLAY"], ANGLE=ge["ANGLE"],
+                                      EMISS_ANG=ge["EMISS_ANG"], IPZEN=ge["IPZEN"])
+            LIMAX = path.LAYINC.shape[0]
+            inside = np.arange(LIMAX)[:, None] < path.NLAYIN[None, :]
+            c = dict(key=key, H=rep(st.H), P=rep(st.P), T0=rep(st.T), VMR0=td(st.VMR), BASEH=rep(self.BASEH), path=path,
+                     LAYINC=td(path.LAYINC, torch.int64), inside=td(inside, torch.bool), igas=td(self.igas_map, torch.int64),
+                     NLAYIN32=td(path.NLAYIN, torch.int32), LAYINC32=td(path.LAYINC, torch.int32),
+                     SCALE=rep(path.SCALE), TSURF=td(np.full(n, self.TSURF)))
+            self._dev_consts = c
+        T, VMR = c["T0"], None
+        for b, (kind, j) in enumerate(st.blocks):
+            xb = X[:, b * st.NPRO:(b + 1) * st.NPRO]
+            if kind == "T":
+                T = td(xb)
+            else:
+                if VMR is None:
+                    VMR = c["VMR0"][None].repeat(n, 1, 1)
+                VMR[:, :, j] = td(np.exp(xb))
+        if VMR is None:
+            VMR = c["VMR0"][None].repeat(n, 1, 1)
+        order()
+        lay = self.eng.layer_average_dev(self.RADIUS, c["H"], c["P"], T, VMR, None, None, c["BASEH"], LAYANG=la["LAYANG"],
+                                         LAYINT=la["LAYINT"], LAYHT=la["LAYHT"], NINT=la["NINT"])
+        drain()
+        out = dict(PRESS=lay["PRESS"], TEMP=lay["TEMP"], TOTAM=lay["TOTAM"], path=c["path"], consts=c)
+        out["amount"] = (lay["AMOUNT"][:, :, c["igas"]].transpose(1, 2) * SQ_CM_TO_SQ_METER).contiguous()
+        out["VMRLAY"] = lay["PP"] / lay["PRESS"][:, :, None]
+        out["EMTEMP"] = torch.where(c["inside"][None], lay["TEMP"][:, c["LAYINC"]], torch.zeros((), dtype=torch.float64, device=dev))
+        return out
+
     # ---- device part ------------------------------------------------------------------------------------------
     def spectra_batch(self, X, device=None):
         """Spectra of the n states X (n, NX): torch tensor (n, NY), NY = NWAVE * NPATH (path fastest like SPECOUT),
         resident on the engine's device."""
         import torch
         eng = self.eng
+        dev = torch.device("cuda", eng.device) if device is None else device
+        if self.device_layers and self.DUST is None and self.PARAH2 is None:
+            return self._spectra_batch_dev(X, dev)
         lay = self.layers(X)
         n, L = lay["PRESS"].shape
-        dev = torch.device("cuda", eng.device) if device is None else device
         td = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
         path = lay["path"]
         P_, LIMAX = path.NPATH, path.LAYINC.shape[0]
@@ -173,6 +226,38 @@ class BatchedCKThermalModel:
         self.last_rows = eng.last_layer_rows()
         if not shared:
             eng.synchronize()
+        return out.reshape(n, self.W * P_)
+
+    def _spectra_batch_dev(self, X, dev):
+        import torch
+        eng = self.eng
+        cur = torch.cuda.current_stream(dev)
+        shared = cur.cuda_stream != 0 and eng.stream_ptr == cur.cuda_stream
+        order = (lambda: None) if shared else cur.synchronize      # see spectra_batch
+        drain = (lambda: None) if shared else eng.synchronize
+        lay = self.layers_dev(X, dev, order, drain)
+        c, path = lay["consts"], lay["path"]
+        n, L = lay["PRESS"].shape
+        P_, LIMAX = path.NPATH, path.LAYINC.shape[0]
+        cont = None
+        if self.IRAY != 0 or self.extra is not None:
+            if self.IRAY != 0:
+                cont = torch.empty((n, self.W, L), dtype=torch.float64, device=dev)
+                totam, vmrlay = lay["TOTAM"].contiguous(), lay["VMRLAY"]
+                order()
+                eng.calc_tau_rayleigh_batch_dev(self.IRAY, self.ISPACE, totam, cont, ID=self.ID, ISO=self.ISO, VMR=vmrlay)
+                drain()
+            else:
+                cont = torch.zeros((n, self.W, L), dtype=torch.float64, device=dev)
+            if self.extra is not None:
+                cont += torch.as_tensor(self.extra, dtype=torch.float64, device=dev)[None]
+        out = torch.empty((n, self.W, P_), dtype=torch.float64, device=dev)
+        args = (lay["PRESS"].contiguous(), lay["TEMP"].contiguous(), lay["amount"], cont, P_, LIMAX, c["NLAYIN32"], c["LAYINC32"],
+                c["SCALE"], lay["EMTEMP"].contiguous(), c["TSURF"])
+        order()
+        eng.cirsrad_ck_thermal_dev(self.ISPACE, n, L, *args, None, None, None, None, None, None, out)
+        self.last_rows = eng.last_layer_rows()
+        drain()
         return out.reshape(n, self.W * P_)
 
     # ---- analytic route: nemesisfmg for the same configuration ----------------------------------------------------

@@ -364,6 +364,18 @@ int ansfm_layer_average(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, c
                         double *AMOUNT, double *PP, double *CONT, double *FRAC, double *DELH,
                         double *BASET, double *LAYSF);
 
+/* The same with every array argument resident on the DEVICE (DUST_UNITS stays a host array) and the results left there:
+ * out_dev = HEIGHT,PRESS,TEMP,TOTAM,FRAC,DELH,BASET,LAYSF [n][NLAY] one after the other, then AMOUNT [n][NLAY][NVMR],
+ * PP [n][NLAY][NVMR], CONT [n][NLAY][NDUST] -- n * NLAY * (8 + 2 NVMR + NDUST) doubles.  Asynchronous on the context's
+ * stream: the states of a numerical Jacobian go from profiles to layers to CIRSrad without crossing PCIe.  With more than
+ * one state, a layer whose sub-points read only levels at which a state holds state 0's numbers takes state 0's result
+ * (bit-identical; also in ansfm_layer_average; ANSFM_LAYER_SHARE=0 integrates every layer). */
+int ansfm_layer_average_dev(ansfm_ctx *ctx, int n_models, double RADIUS, int NPRO, const double *H,
+                            const double *P, const double *T, int NVMR, const double *VMR, int NDUST,
+                            const double *DUST, const double *PARAH2, int NLAY, const double *BASEH,
+                            double LAYANG, int LAYINT, double LAYHT, int NINT, const int32_t *DUST_UNITS,
+                            const double *XMOLWT, double *out_dev);
+
 /* Layer_0.layer_averageg (Layer_0.py:1032-1398): the same plus DTE, DAM, DCO, DPH [n][NLAY][NPRO], the matrices
  * relating layer temperature / gas amounts / dust amounts / para-H2 fraction to the profile levels (consumed by
  * map2pro).  T, PARAH2, VMR and DUST go through the reference's own `interpg` bracket (:716-751) here, so the layer
@@ -467,6 +479,9 @@ int ansfm_calc_tau_rayleigh(ansfm_ctx *ctx, int mode, int ISPACE, int W, const d
  * the layout ansfm_cirsrad_ck_thermal_dev takes as taucont (8 MB per state at C2 that never cross PCIe). */
 int ansfm_calc_tau_rayleigh_batch_dev(ansfm_ctx *ctx, int mode, int ISPACE, int n_models, int L, const double *TOTAM,
                                       const double *f4, double *TAURAY_dev);
+/* ... and with TOTAM / f4 resident on the device too (what ansfm_layer_average_dev left there); asynchronous. */
+int ansfm_calc_tau_rayleigh_batch_dev_in(ansfm_ctx *ctx, int mode, int ISPACE, int n_models, int L,
+                                         const double *TOTAM_dev, const double *f4_dev, double *TAURAY_dev);
 
 /* ForwardModel_0.calc_tau_dust (ForwardModel_0.py:4790): KEXT / KSCA[NWS][NDUST] tabulated on SWAVE[NWS] (Scatter.WAVE,
  * strictly ascending) interpolated to WAVEC[W] like scipy interp1d(kind='cubic') (not-a-knot spline; linear when

@@ -656,6 +656,42 @@ def test_layer_average_golden(eng, golden_dir, case):
     assert np.all(rb[2][1] > rb[2][0])          # TEMP of the warmed state
 
 
+@pytest.mark.parametrize("case", ["cg_nadir", "cg_slant", "mid_slant", "cg_dustunits"])
+def test_layer_average_batch_shares_unchanged_layers_bit_for_bit(eng, golden_dir, case):
+    """A Jacobian's states differ from state 0 at one level: the batched call takes state 0's layers where a layer reads only
+    unchanged levels -- every state equals its own single-state call bit for bit, whatever was perturbed (T, P, H, a gas,
+    the dust, para-H2, the molecular weight, the layer bases)."""
+    from test_layer_oracle import CASES
+    z = _load(golden_dir, "layer_average")
+    kw = dict(CASES[case]); du = kw.pop("dust_units", False)
+    NPRO = z["H"].size
+    base = dict(H=z["H"], P=z["P"], T=z["T"], VMR=z["VMR"], DUST=z["DUST"], PARAH2=z["PARAH2"], XMOLWT=z["XMOLWT"],
+                BASEH=z["split1_BASEH"])
+    states = [dict(base)]
+    def bump(key, lev, col=None):
+        a = np.array(base[key], dtype=float)
+        if col is None: a[lev] *= 1.05
+        else: a[lev, col] *= 1.05
+        states.append(dict(base, **{key: a}))
+    bump("T", 0); bump("T", NPRO // 2); bump("T", NPRO - 1); bump("P", 3); bump("VMR", NPRO // 3, 1); bump("DUST", 5, 0)
+    bump("PARAH2", 7); bump("XMOLWT", NPRO // 2); bump("BASEH", 4)
+    hs = np.array(base["H"], dtype=float); hs[NPRO - 1] += 10.0; states.append(dict(base, H=hs))     # the top level enters SMAX
+    states.append(dict(base))                                                                          # an unperturbed copy
+    st = lambda k: np.stack([np.asarray(s_[k], dtype=float) for s_ in states])
+    args = dict(LAYHT=-6.0e4, NINT=101, DUST_UNITS=np.array([-1, 0]) if du else None, **kw)
+    rb = eng.layer_average(float(z["RADIUS"]), st("H"), st("P"), st("T"), None, st("VMR"), st("DUST"), st("PARAH2"), st("BASEH"),
+                           None, XMOLWT=st("XMOLWT") if du else None, **args)
+    nchanged = []
+    for i, s_ in enumerate(states):
+        r1 = eng.layer_average(float(z["RADIUS"]), s_["H"], s_["P"], s_["T"], None, s_["VMR"], s_["DUST"], s_["PARAH2"], s_["BASEH"],
+                               None, XMOLWT=s_["XMOLWT"] if du else None, **args)
+        for vb, v1 in zip(rb, r1):
+            assert np.array_equal(vb[i], v1), (case, i)
+        nchanged.append(int(np.sum(np.any(rb[4][i] != rb[4][0], axis=-1) | (rb[2][i] != rb[2][0]) | (rb[8][i] != rb[8][0]))))
+    assert nchanged[0] == 0 and nchanged[-1] == 0
+    assert 1 <= nchanged[2] <= 8, nchanged            # one temperature level reaches a few layers only
+
+
 def test_gradient_maps_golden(eng, golden_dir):
     """ForwardModel_0.map2pro / map2xvec (matrix-core GEMM) vs the reference (golden): default and explicit INCPAR
     (para-H2 slot = previous parameter's product), host-pointer and device-chained inputs."""

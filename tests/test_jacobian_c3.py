@@ -191,6 +191,16 @@ def test_c3_numerical_jacobian_vs_oracle(oracle, pointing, f32):
                                       layering_args=dict(NLAY=NLAY, LAYINT=1, NINT=101), geometry=geo, IRAY=4)
         YN, KK = jacobian_nemesis_batched(model)
         rows, total = model.last_rows
+        # the layers left in HBM (layer_average_dev; default) and the layers through host arrays: the same bits
+        model.device_layers = False
+        YN_h, KK_h = jacobian_nemesis_batched(model)
+        assert np.array_equal(YN, YN_h) and np.array_equal(KK, KK_h) and model.last_rows == (rows, total)
+        import torch
+        model.device_layers = True
+        side = torch.cuda.Stream(device=model.torch_device())          # torch on a stream of its own, the engine on another
+        with torch.cuda.stream(side):
+            YN_s, KK_s = jacobian_nemesis_batched(model)
+        assert np.array_equal(YN, YN_s) and np.array_equal(KK, KK_s)
     finally:
         eng.close()
     assert total == (st.NX + 1) * NLAY and NLAY < rows < total // 3        # a level touches a few layers, not all
