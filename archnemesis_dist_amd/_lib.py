@@ -28,7 +28,7 @@ EXPORTS = [
     "ansfm_ktable_file_header", "ansfm_upload_ktable_files", "ansfm_ktable_grids", "ansfm_lbltable_file_header",
     "ansfm_upload_lbltable_files", "ansfm_kdist_bins", "ansfm_calc_tau_cia", "ansfm_set_merge_keys", "ansfm_merge_redo_count", "ansfm_calc_tau_rayleigh_batch_dev", "ansfm_cirsrad_ck_scatter", "ansfm_thermal_emission_g", "ansfm_cirsrad_ck_transmission", "ansfm_cirsradg_ck_transmission", "ansfm_set_gradient_gases", "ansfm_set_shared_gas_gradient", "ansfm_singlescatt_plane_spectrum",
     "ansfm_cirsrad_ck_singlescatt", "ansfm_cirsrad_ck_scatter_batch", "ansfm_last_scatter_cache",
-    "ansfm_layer_average_dev", "ansfm_calc_tau_rayleigh_batch_dev_in",
+    "ansfm_layer_average_dev", "ansfm_calc_tau_rayleigh_batch_dev_in", "ansfm_last_rt_shared",
 ]
 
 _lib = None
@@ -168,6 +168,7 @@ def load():
     lib.ansfm_calc_tau_rayleigh.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp]
     lib.ansfm_calc_tau_rayleigh_batch_dev.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
     lib.ansfm_calc_tau_rayleigh_batch_dev_in.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
+    lib.ansfm_last_rt_shared.argtypes = [vp, vp]
     lib.ansfm_calc_tau_dust.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp]
     lib.ansfm_integrate_filter.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp]
     lib.ansfm_conv_fil.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp]

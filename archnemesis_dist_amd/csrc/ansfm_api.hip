@@ -72,6 +72,8 @@ struct ansfm_ctx {
     DevBuf li, tau, scratch, cont_t, tmp_in, tmp_out, misc;
     DevBuf dspec_ref, map_out, map_b, map_batch;
     DevBuf dd_slot, dd_work, dd_in;      // layer de-duplication: row map [n][L], work list, packed inputs
+    DevBuf rt_prefix, rt_same;           // thermal RT of a batch: state 0's records along every path; same flags [n][L] + jstart [n][P]
+    int last_rt_shared = 0;
     int dedup = 1;                       // ansfm_set_layer_dedup
     int last_rows = 0, last_dedup = 0;   // opacity rows computed by the last cirsrad call / whether tau_slot applies
     int dspec_dims[4] = {0, 0, 0, 0};   // W, NPAR, LIMAX, P of dspec_ref (single-model cirsradg result)
@@ -600,11 +602,37 @@ static void launch_w_to_last(hipStream_t st, unsigned n_batch, const double *src
                        dst_stride);
 }
 
-static int launch_rt(ansfm_ctx *ctx, const RtParams &p, int n_models)
+static int launch_rt(ansfm_ctx *ctx, const RtParams &p_in, int n_models)
 {
+    RtParams p = p_in;
     dim3 grid((unsigned)n_models, (unsigned)p.P, (unsigned)(p.Wpad / kWave));
     if (p.Wpad / kWave > 65535) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: more than 65535 wavenumber tiles (4.19e6 wavenumbers)");
     if (p.LIMAX > 1500) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: at most 1500 layers along a path");
+    ctx->last_rt_shared = 0;
+    // a de-duplicated batch (the states of a numerical Jacobian) in thermal emission: every state starts each path from the
+    // record state 0 left after the last layer the two have in common
+    static const bool prefix_off = [] { const char *e = getenv("ANSFM_RT_PREFIX"); return e && e[0] == '0'; }();
+    const size_t rec = (size_t)p.P * p.LIMAX * 3 * p.G * p.Wpad * sizeof(double);
+    if (!prefix_off && n_models >= 4 && p.tau_slot && p.mode == 0 && !p.emi && !p.per_g && rec <= ((size_t)4 << 30)) {
+        HIPCHK(ctx->rt_prefix.reserve(rec));
+        const size_t nl = (size_t)n_models * p.L, np = (size_t)n_models * p.P;
+        const size_t off_j = (nl + 15) & ~(size_t)15;
+        HIPCHK(ctx->rt_same.reserve(off_j + np * sizeof(int32_t)));
+        unsigned char *same = ctx->rt_same.as<unsigned char>();
+        int32_t *jstart = reinterpret_cast<int32_t *>(same + off_j);
+        hipLaunchKernelGGL(k_rt_same, dim3((unsigned)p.L, (unsigned)(n_models - 1)), dim3(256), 0, ctx->stream, p.L, p.Wpad, p.tau_slot,
+                           p.cont, same);
+        hipLaunchKernelGGL(k_rt_jstart, dim3(nblk(np, 128)), dim3(128), 0, ctx->stream, n_models, p.L, p.P, p.LIMAX, p.nlayin, p.layinc,
+                           p.scale, p.emtemp, same, jstart);
+        p.prefix = ctx->rt_prefix.as<double>(); p.jstart = jstart; p.m0 = 0;
+        const size_t lds = (size_t)4 * p.LIMAX * sizeof(double);
+        hipLaunchKernelGGL((k_thermal_rt<false, 1>), dim3(1u, grid.y, grid.z), dim3(kWave, kGY), lds, ctx->stream, p);
+        p.m0 = 1;
+        hipLaunchKernelGGL((k_thermal_rt<true, 2>), dim3((unsigned)(n_models - 1), grid.y, grid.z), dim3(kWave, kGY), lds, ctx->stream, p);
+        HIPCHK(hipGetLastError());
+        ctx->last_rt_shared = 1;
+        return ANSFM_OK;
+    }
     if (n_models >= 4)
         hipLaunchKernelGGL(k_thermal_rt<true>, grid, dim3(kWave, kGY), (size_t)4 * p.LIMAX * sizeof(double), ctx->stream, p);
     else
@@ -765,6 +793,13 @@ int ansfm_last_layer_rows(const ansfm_ctx *ctx, int *rows_computed, int *rows_to
     if (!ctx) return ANSFM_ERR_INVALID;
     if (rows_computed) *rows_computed = ctx->last_rows;
     if (rows_total) *rows_total = ctx->last_n * ctx->last_L;
+    return ANSFM_OK;
+}
+
+int ansfm_last_rt_shared(const ansfm_ctx *ctx, int *shared)
+{
+    if (!ctx || !shared) return ANSFM_ERR_INVALID;
+    *shared = ctx->last_rt_shared;
     return ANSFM_OK;
 }
 

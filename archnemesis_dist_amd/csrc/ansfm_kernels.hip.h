@@ -1328,7 +1328,51 @@ struct RtParams {
     const double *sca;      // [L][Wpad] TAURAY + TAUSCAT of the layers, or nullptr
     const double *phase;    // [P][L][Wpad] (by layer; the array-level seam passes L = Li, identity LAYINC)
     const double *brdf;     // [W][P] or nullptr
+    // The states of a numerical Jacobian share the top of every path with state 0 (k_thermal_rt<.., PREFIX>): state 0's
+    // launch (PREFIX 1, m0 = 0) leaves (taud, trold, spec) after every layer of the path in `prefix`
+    // [P][LIMAX][3][G][Wpad]; the launch of the states m0 .. (PREFIX 2) starts state m's path ip at layer jstart[m][ip] --
+    // the first one whose opacity row, continuum, SCALE or EMTEMP is not state 0's -- from that record.  Same bits.
+    double *prefix;
+    const int32_t *jstart;  // [n][P]
+    int m0;
 };
+
+// same[m][lay] = the opacity row of (m, lay) is state 0's row and (cont != nullptr) so is its continuum, bit for bit.
+// grid (L, n - 1), block 256
+__global__ void k_rt_same(int L, int Wpad, const int32_t *__restrict__ slot, const double *__restrict__ cont, unsigned char *same)
+{
+    const int lay = blockIdx.x, m = blockIdx.y + 1;
+    int differs = slot[(size_t)m * L + lay] != slot[lay];
+    if (!differs && cont) {
+        const long long *a = reinterpret_cast<const long long *>(cont + ((size_t)m * L + lay) * Wpad);
+        const long long *b = reinterpret_cast<const long long *>(cont + (size_t)lay * Wpad);
+        for (int i = threadIdx.x; i < Wpad; i += blockDim.x) differs |= (a[i] != b[i]);
+    }
+    differs = __syncthreads_or(differs);
+    if (threadIdx.x == 0) same[(size_t)m * L + lay] = differs ? 0 : 1;
+}
+
+// jstart[m][ip] = number of leading layers of path ip that state m shares with state 0 (one thread per (m, ip); m = 0: 0)
+__global__ void k_rt_jstart(int n, int L, int P, int LIMAX, const int32_t *__restrict__ nlayin, const int32_t *__restrict__ layinc,
+                            const double *__restrict__ scale, const double *__restrict__ emtemp,
+                            const unsigned char *__restrict__ same, int32_t *jstart)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * P) return;
+    const int m = idx / P, ip = idx % P;
+    int j = 0;
+    if (m > 0) {
+        const int nl = nlayin[ip];
+        const size_t pm = (size_t)m * LIMAX * P + ip, p0 = ip;
+        for (; j < nl; ++j) {
+            const int lay = layinc[(size_t)j * P + ip];
+            if (!same[(size_t)m * L + lay]) break;
+            if (__double_as_longlong(scale[pm + (size_t)j * P]) != __double_as_longlong(scale[p0 + (size_t)j * P])) break;
+            if (__double_as_longlong(emtemp[pm + (size_t)j * P]) != __double_as_longlong(emtemp[p0 + (size_t)j * P])) break;
+        }
+    }
+    jstart[idx] = j;
+}
 
 __device__ __forceinline__ double planck_bb(double a, double c2y, double T)
 {
@@ -1339,7 +1383,7 @@ __device__ __forceinline__ double planck_bb(double a, double c2y, double T)
 // kernel's natural 142 registers a second block does not fit on the CU, and a batch has the blocks to fill it: capped at 128
 // (14 spilled) the 201 states of a C3 Jacobian take 9.2 instead of 11.4 ms.  A single model has 157 blocks for 256 CUs and
 // only pays for the spills (0.093 -> 0.107 ms): it keeps the uncapped build.
-template <bool BATCH>
+template <bool BATCH, int PREFIX = 0>
 __global__ __launch_bounds__(kWave *kGY) __attribute__((amdgpu_waves_per_eu(BATCH ? 4 : 1, BATCH ? 4 : 8))) void k_thermal_rt(RtParams p)
 {
     __shared__ double red[kGY][kWave];
@@ -1348,7 +1392,7 @@ __global__ __launch_bounds__(kWave *kGY) __attribute__((amdgpu_waves_per_eu(BATC
     // states) run next to each other on a wavenumber tile, so the rows are re-read out of L2 instead of HBM
     const int nu = blockIdx.z * kWave + lane;
     const int nuc = nu < p.W ? nu : p.W - 1;
-    const int ip = blockIdx.y, m = blockIdx.x;
+    const int ip = blockIdx.y, m = blockIdx.x + (PREFIX != 0 ? p.m0 : 0);
     const int nl = p.nlayin[ip];
     const int G = p.G;
     const double c1 = 1.1911e-12, c2 = 1.439;  // ForwardModel_0.py:6214-6215
@@ -1430,15 +1474,44 @@ __global__ __launch_bounds__(kWave *kGY) __attribute__((amdgpu_waves_per_eu(BATC
             }
         }
     };
-    if (nl > 0) fetch(0, tvA, tcA, emA);
+    // the record after layer jd of the path: [ip][jd][3][G][Wpad]
+    auto record = [&](int jd) -> double * { return p.prefix + (((size_t)ip * p.LIMAX + jd) * 3) * (size_t)G * p.Wpad + nu; };
+    auto leave = [&](int jd) {
+        if constexpr (PREFIX == 1) {
+            double *r = record(jd);
+#pragma unroll
+            for (int k = 0; k < kGPer; ++k) {
+                const int g = gy + k * kGY;
+                if (g < G) {
+                    r[(size_t)g * p.Wpad] = taud[k]; r[((size_t)G + g) * p.Wpad] = trold[k]; r[((size_t)2 * G + g) * p.Wpad] = spec[k];
+                }
+            }
+        }
+    };
     int j = 0;
+    if constexpr (PREFIX == 2) {
+        j = p.jstart[(size_t)m * p.P + ip];              // block-uniform
+        if (j > 0) {
+            const double *r = record(j - 1);
+#pragma unroll
+            for (int k = 0; k < kGPer; ++k) {
+                const int g = gy + k * kGY;
+                if (g < G) {
+                    taud[k] = r[(size_t)g * p.Wpad]; trold[k] = r[((size_t)G + g) * p.Wpad]; spec[k] = r[((size_t)2 * G + g) * p.Wpad];
+                }
+            }
+        }
+    }
+    if (j < nl) fetch(j, tvA, tcA, emA);
     for (; j + 1 < nl; j += 2) {                         // ping-pong buffers: no register rotation
         fetch(j + 1, tvB, tcB, emB);
         integrate(j, tvA, tcA, emA);
+        leave(j);
         if (j + 2 < nl) fetch(j + 2, tvA, tcA, emA);
         integrate(j + 1, tvB, tcB, emB);
+        leave(j + 1);
     }
-    if (j < nl) integrate(j, tvA, tcA, emA);
+    if (j < nl) { integrate(j, tvA, tcA, emA); leave(j); }
     // surface / bottom-of-atmosphere term  (:6354-6365)
     int i1 = (int)(nl / 2.0) - 1;
     if (i1 < 0) i1 += nl;

@@ -16,6 +16,7 @@
 namespace ansfm {
 
 constexpr int kLayMaxNint = 256;
+constexpr int kLayPairTerms = 2048;   // Simpson terms (quantity x pair of intervals) a workgroup forms side by side in LDS
 
 struct LayerAvgParams {
     const double *H, *P, *T;        // [n][NPRO]
@@ -71,6 +72,8 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
     __shared__ int idx[kLayMaxNint], jg[kLayMaxNint];
     __shared__ double FF[kLayMaxNint];
     __shared__ double res[160];
+    __shared__ double cA[kLayMaxNint / 2], cB0[kLayMaxNint / 2], cB1[kLayMaxNint / 2], cB2[kLayMaxNint / 2];
+    __shared__ double IN[kLayPairTerms];
     __shared__ int lv_lo, lv_hi;
     const bool GR = p.with_grad != 0;
     const double k_B = 1.38065e-23, AVOGAD = 6.02214076e23, PI = 3.141592653589793;
@@ -151,8 +154,7 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
     }
     // ---- phase 2: one thread per integrated quantity ----------------------------------------------------
     const int NQ = 5 + 2 * V + D;
-    for (int q = tid; q < NQ; q += blockDim.x) {
-        auto yval = [&](int k) -> double {
+    auto yval_q = [&](int q, int k) -> double {
             const double h = hh[k];
             const int ix = idx[k];
             if (q == 0) return duds[k];
@@ -177,7 +179,32 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
             const int J = q - 5 - 2 * V;
             const double dd = lay_interp(H, DUST + J, D, ix, h);
             return (p.dust_units && p.dust_units[J] == -1) ? dd * duds[k] * mw[k] / AVOGAD : dd;
-        };
+    };
+    // scipy _basic_simpson, unequal-spacing form: the weights of a pair of intervals once per workgroup, the bracket of every
+    // (quantity, pair) side by side (the profile reads are a microsecond each from a cold cache: one thread walking the 50
+    // pairs of a quantity took 0.2 ms per layer), then one thread per quantity adds its terms in order
+    const int nodd_ = (npts & 1) ? npts : npts - 1;
+    const int npairs = (p.LAYINT != 0 && npts > 2) ? (nodd_ - 1) / 2 : 0;
+    const bool side_by_side = npairs > 0 && NQ * npairs <= kLayPairTerms;
+    if (side_by_side) {
+        for (int e = tid; e < npairs; e += blockDim.x) {
+            const int i = 2 * e;
+            const double h0 = S[i + 1] - S[i], h1 = S[i + 2] - S[i + 1];
+            const double hsum = h0 + h1, hprod = h0 * h1;
+            const double h0divh1 = (h1 != 0) ? h0 / h1 : 0.0;
+            const double inv = (h0divh1 != 0) ? 1.0 / h0divh1 : 0.0;
+            const double hq = (hprod != 0) ? hsum / hprod : 0.0;
+            cA[e] = hsum / 6.0; cB0[e] = 2.0 - inv; cB1[e] = hsum * hq; cB2[e] = 2.0 - h0divh1;
+        }
+        __syncthreads();
+        for (int e = tid; e < NQ * npairs; e += blockDim.x) {
+            const int q = e / npairs, ip = e - q * npairs, i = 2 * ip;
+            IN[e] = yval_q(q, i) * cB0[ip] + yval_q(q, i + 1) * cB1[ip] + yval_q(q, i + 2) * cB2[ip];
+        }
+        __syncthreads();
+    }
+    for (int q = tid; q < NQ; q += blockDim.x) {
+        auto yval = [&](int k) -> double { return yval_q(q, k); };
         double r = 0.0;
         if (p.LAYINT == 0) {
             r = yval(0);   // point value; combined below
@@ -185,7 +212,10 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
             r = 0.5 * (S[1] - S[0]) * (yval(1) + yval(0));     // scipy simpson with two points
         } else {
             const int nodd = (npts & 1) ? npts : npts - 1;
-            for (int i = 0; i + 2 < nodd; i += 2) {   // scipy _basic_simpson, unequal-spacing form
+            if (side_by_side)
+                for (int ip = 0; ip < npairs; ++ip) r += cA[ip] * IN[q * npairs + ip];
+            else
+            for (int i = 0; i + 2 < nodd; i += 2) {   // (more terms than the LDS array holds: one thread per quantity all the way)
                 const double h0 = S[i + 1] - S[i], h1 = S[i + 2] - S[i + 1];
                 const double hsum = h0 + h1, hprod = h0 * h1;
                 const double h0divh1 = (h1 != 0) ? h0 / h1 : 0.0;

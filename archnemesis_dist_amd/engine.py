@@ -925,6 +925,12 @@ class AnsfmEngine:
         self._check(self._lib.ansfm_merge_redo_count(self._ctx, C.byref(n)), "merge_redo_count")
         return int(n.value)
 
+    def last_rt_shared(self):
+        """True when the last thermal-emission batch started its states' paths from state 0's records (ansfm_last_rt_shared)."""
+        v = C.c_int(0)
+        self._check(self._lib.ansfm_last_rt_shared(self._ctx, C.byref(v)), "last_rt_shared")
+        return bool(v.value)
+
     def last_layer_rows(self):
         """(layer opacities computed, n_models * L) of the last cirsrad_ck_thermal call."""
         a = C.c_int(); b = C.c_int()

@@ -502,6 +502,11 @@ int ansfm_calc_tau_dust(ansfm_ctx *ctx, int W, const double *WAVEC, int NWS, con
 int ansfm_set_layer_dedup(ansfm_ctx *ctx, int enable);
 int ansfm_last_layer_rows(const ansfm_ctx *ctx, int *rows_computed, int *rows_total);
 
+/* *shared = 1 when the last thermal-emission batch started the paths of its states from the records state 0 left behind
+ * (a de-duplicated batch of at least 4 states: every state shares the top of each path with state 0 up to the first layer
+ * whose opacity row, continuum, SCALE or EMTEMP differs; bit-identical; ANSFM_RT_PREFIX=0 switches it off). */
+int ansfm_last_rt_shared(const ansfm_ctx *ctx, int *shared);
+
 /* Row-head list of the forward random-overlap merge (k_overlap / rank, ForwardModel_0.py:6029-6173): bits = 64 (default)
  * orders the heads on double keys (k_ck_overlap: values closer than 2^-41 count as ties); bits = 32 on float32 keys
  * (k_ck_overlap32: heads whose float32 values coincide are settled by their exact double sums, every merge carries a

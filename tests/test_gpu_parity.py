@@ -943,6 +943,64 @@ def test_batch_layer_dedup_is_bit_identical(eng):
     assert not np.array_equal(a[0], a[3])
 
 
+@pytest.mark.parametrize("geometry", ["nadir", "limb_paths"])
+def test_batch_thermal_rt_starts_from_state0_records_bit_for_bit(eng, geometry):
+    """The states of a batch start every path from what state 0 left after the last layer they share with it: a change of a
+    layer's gas opacity, of its continuum only, of SCALE only, of EMTEMP only, of TSURF, and no change at all -- against
+    the same call with de-duplication (and with it the sharing) off."""
+    from archnemesis_dist_amd import synthetic as syn
+    W, G, S, L, NP, NT = 200, 12, 3, 24, 8, 6
+    _, delg = syn.gauss_legendre_01(G, True)
+    PRESS, TEMP, K = syn.synth_ktable(W, G, NP, NT, S, seed=33)
+    eng.upload_ktable(K, PRESS, TEMP, 150.0 + np.arange(W), delg)
+    base = syn.synth_atmosphere(L, S)
+    n = 9
+    lp = np.repeat(base["lay_press_pa"], n, 0); lt = np.repeat(base["lay_temp"], n, 0); am = np.repeat(base["amount"], n, 0)
+    if geometry == "nadir":
+        NLAYIN, LAYINC, SCALE = syn.nadir_path(L)
+    else:       # three tangent paths: down to layer b and up again (AtmCalc_0's limb order), ragged NLAYIN
+        bots = [2, 9, 17]
+        LIMAX = 2 * (L - min(bots))
+        NLAYIN = np.array([2 * (L - b) for b in bots], dtype=np.int32)
+        LAYINC = np.zeros((LIMAX, len(bots)), dtype=np.int32); SCALE = np.zeros((LIMAX, len(bots)))
+        for ip, b in enumerate(bots):
+            down = np.arange(L - 1, b - 1, -1)
+            order = np.concatenate([down, down[::-1]])
+            LAYINC[:order.size, ip] = order
+            SCALE[:order.size, ip] = 1.0 + 3.0 / (1.0 + np.abs(order - b))
+    P_ = LAYINC.shape[1]
+    inside = np.arange(LAYINC.shape[0])[:, None] < NLAYIN[None, :]
+    SC = np.repeat(SCALE[None], n, 0)
+    cont = np.repeat(syn.synth_continuum(W, L), n, 0)
+    tsurf = np.full(n, -1.0)
+    lt[1, 20] *= 1.02                        # near the top of the atmosphere: nearly nothing shared on the way down
+    am[2, 1, 3] *= 1.05                      # near the bottom: most of a nadir path shared
+    cont[3, :, 11] *= 1.01                   # the continuum alone
+    cont[4, 7, 15] *= 1.0000001              # ... at a single wavenumber
+    SC[5, 5, 0] *= 1.01                      # SCALE alone
+    lt[7, 0] *= 1.0                          # state 7: nothing changed
+    tsurf[8] = 180.0                         # the ground term only (applied after the loop)
+    EMTEMP = np.where(inside[None], lt[:, LAYINC], 0.0)
+    EMTEMP[6, 8, P_ - 1] += 0.5              # EMTEMP alone
+    emis = np.full(W, 0.9)
+    args = (0, lp, lt, am, cont, NLAYIN, LAYINC, SC, EMTEMP, tsurf)
+    eng.set_layer_dedup(True)
+    a = eng.cirsrad_ck_thermal(*args, EMISSIVITY=emis)
+    assert eng.last_rt_shared()
+    eng.set_layer_dedup(False)
+    try:
+        b = eng.cirsrad_ck_thermal(*args, EMISSIVITY=emis)
+        assert not eng.last_rt_shared()
+    finally:
+        eng.set_layer_dedup(True)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[7], a[0])
+    for m in (1, 2, 3, 4, 5, 6):
+        assert not np.array_equal(a[m], a[0]), m
+    if geometry == "nadir":
+        assert not np.array_equal(a[8], a[0])
+
+
 @pytest.mark.parametrize("W,G,S,L", [(1, 1, 1, 1), (3, 1, 3, 2), (63, 2, 2, 3), (65, 3, 4, 2), (130, 32, 3, 2), (5, 31, 2, 1),
                                        (64, 17, 5, 1)])
 def test_k_overlap_edge_sizes_vs_oracle(eng, oracle, W, G, S, L):
