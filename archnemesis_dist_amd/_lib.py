@@ -29,6 +29,7 @@ EXPORTS = [
     "ansfm_upload_lbltable_files", "ansfm_kdist_bins", "ansfm_calc_tau_cia", "ansfm_set_merge_keys", "ansfm_merge_redo_count", "ansfm_calc_tau_rayleigh_batch_dev", "ansfm_cirsrad_ck_scatter", "ansfm_thermal_emission_g", "ansfm_cirsrad_ck_transmission", "ansfm_cirsradg_ck_transmission", "ansfm_set_gradient_gases", "ansfm_set_shared_gas_gradient", "ansfm_singlescatt_plane_spectrum",
     "ansfm_cirsrad_ck_singlescatt", "ansfm_cirsrad_ck_scatter_batch", "ansfm_last_scatter_cache",
     "ansfm_layer_average_dev", "ansfm_calc_tau_rayleigh_batch_dev_in", "ansfm_last_rt_shared",
+    "ansfm_cirsrad_ck_thermal_ray_dev",
 ]
 
 _lib = None
@@ -128,6 +129,7 @@ def load():
     cirs = [vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ansfm_cirsrad_ck_thermal.argtypes = cirs
     lib.ansfm_cirsrad_ck_thermal_dev.argtypes = cirs
+    lib.ansfm_cirsrad_ck_thermal_ray_dev.argtypes = [vp, ci, ci, ci, vp, vp, vp, ci, vp, vp, ci, ci] + [vp] * 12
     lib.ansfm_cirsrad_ck_transmission.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp]
     lib.ansfm_set_gradient_gases.argtypes = [vp, C.c_uint]
     lib.ansfm_set_shared_gas_gradient.argtypes = [vp, ci, vp]

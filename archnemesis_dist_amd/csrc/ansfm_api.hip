@@ -621,7 +621,7 @@ static int launch_rt(ansfm_ctx *ctx, const RtParams &p_in, int n_models)
         unsigned char *same = ctx->rt_same.as<unsigned char>();
         int32_t *jstart = reinterpret_cast<int32_t *>(same + off_j);
         hipLaunchKernelGGL(k_rt_same, dim3((unsigned)p.L, (unsigned)(n_models - 1)), dim3(256), 0, ctx->stream, p.L, p.Wpad, p.tau_slot,
-                           p.cont, same);
+                           p.cont_by_row ? nullptr : p.cont, same);      // a continuum stored by row is the row's
         hipLaunchKernelGGL(k_rt_jstart, dim3(nblk(np, 128)), dim3(128), 0, ctx->stream, n_models, p.L, p.P, p.LIMAX, p.nlayin, p.layinc,
                            p.scale, p.emtemp, same, jstart);
         p.prefix = ctx->rt_prefix.as<double>(); p.jstart = jstart; p.m0 = 0;
@@ -664,6 +664,15 @@ static int check_unsorted(ansfm_ctx *ctx)
 /* ------------------------------------------------------------------------------------------ */
 /* fused CIRSrad (device pointers)                                                             */
 /* ------------------------------------------------------------------------------------------ */
+static int cirsrad_ck_thermal_dev_impl(ansfm_ctx *ctx, int ISPACE, int n_models, int L,
+                                 const double *lay_press_pa, const double *lay_temp,
+                                 const double *amount, const double *taucont, int P, int LIMAX,
+                                 const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE,
+                                 const double *EMTEMP, const double *TSURF, const double *EMISSIVITY,
+                                 const double *SOLFLUX, const double *REFLECTANCE, const double *SOL_ANG,
+                                 const double *EMISS_ANG, const double *xfac, double *SPECOUT,
+                                 int ray_mode, const double *ray_totam, const double *ray_f4);
+
 int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L,
                                  const double *lay_press_pa, const double *lay_temp,
                                  const double *amount, const double *taucont, int P, int LIMAX,
@@ -671,6 +680,35 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
                                  const double *EMTEMP, const double *TSURF, const double *EMISSIVITY,
                                  const double *SOLFLUX, const double *REFLECTANCE, const double *SOL_ANG,
                                  const double *EMISS_ANG, const double *xfac, double *SPECOUT)
+{
+    return cirsrad_ck_thermal_dev_impl(ctx, ISPACE, n_models, L, lay_press_pa, lay_temp, amount, taucont, P, LIMAX, NLAYIN, LAYINC,
+                                       SCALE, EMTEMP, TSURF, EMISSIVITY, SOLFLUX, REFLECTANCE, SOL_ANG, EMISS_ANG, xfac, SPECOUT, 0,
+                                       nullptr, nullptr);
+}
+
+int ansfm_cirsrad_ck_thermal_ray_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L, const double *lay_press_pa,
+                                     const double *lay_temp, const double *amount, int ray_mode, const double *TOTAM,
+                                     const double *f4, int P, int LIMAX, const int32_t *NLAYIN, const int32_t *LAYINC,
+                                     const double *SCALE, const double *EMTEMP, const double *TSURF, const double *EMISSIVITY,
+                                     const double *SOLFLUX, const double *REFLECTANCE, const double *SOL_ANG,
+                                     const double *EMISS_ANG, const double *xfac, double *SPECOUT)
+{
+    CHECK_CTX(ctx);
+    if ((ray_mode != 1 && ray_mode != 2 && ray_mode != 4 && ray_mode != 12) || !TOTAM || (ray_mode == 4 && !f4))
+        FAIL(ANSFM_ERR_INVALID, "cirsrad_ck_thermal_ray_dev: bad argument (ray_mode = IRAY 1, 2, 4 or 12 for calc_tau_rayleighv)");
+    return cirsrad_ck_thermal_dev_impl(ctx, ISPACE, n_models, L, lay_press_pa, lay_temp, amount, nullptr, P, LIMAX, NLAYIN, LAYINC,
+                                       SCALE, EMTEMP, TSURF, EMISSIVITY, SOLFLUX, REFLECTANCE, SOL_ANG, EMISS_ANG, xfac, SPECOUT,
+                                       ray_mode, TOTAM, ray_mode == 4 ? f4 : nullptr);
+}
+
+static int cirsrad_ck_thermal_dev_impl(ansfm_ctx *ctx, int ISPACE, int n_models, int L,
+                                 const double *lay_press_pa, const double *lay_temp,
+                                 const double *amount, const double *taucont, int P, int LIMAX,
+                                 const int32_t *NLAYIN, const int32_t *LAYINC, const double *SCALE,
+                                 const double *EMTEMP, const double *TSURF, const double *EMISSIVITY,
+                                 const double *SOLFLUX, const double *REFLECTANCE, const double *SOL_ANG,
+                                 const double *EMISS_ANG, const double *xfac, double *SPECOUT,
+                                 int ray_mode, const double *ray_totam, const double *ray_f4)
 {
     CHECK_CTX(ctx);
     if (!ctx->have_table) FAIL(ANSFM_ERR_NOTABLE, "cirsrad: upload a k-table first");
@@ -692,7 +730,8 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
         int *counter = ctx->d_flag.as<int>() + 12;
         HIPCHK(hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
         hipLaunchKernelGGL(k_dedup_mark, dim3(nblk(nl, 128)), dim3(128), 0, ctx->stream, n_models, L, S, lay_press_pa,
-                           lay_temp, amount, ctx->dd_slot.as<int32_t>(), ctx->dd_work.as<int32_t>(), counter);
+                           lay_temp, amount, ctx->dd_slot.as<int32_t>(), ctx->dd_work.as<int32_t>(), counter,
+                           ray_mode ? ray_totam : nullptr, ray_mode ? ray_f4 : nullptr);
         HIPCHK(hipGetLastError());
         int extra = 0;
         HIPCHK(hipMemcpyAsync(&extra, counter, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -714,7 +753,16 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
                        ctx->d_temp.as<double>(), 101325.0, ctx->grid_f32, ctx->li.as<LayerInterp>());
     HIPCHK(hipGetLastError());
     const double *cont_t = nullptr;
-    if (taucont) {
+    if (ray_mode) {
+        // the Rayleigh continuum of the rows that are computed (the distinct layers of the batch), straight in the layout the RT
+        // reads: the 201 states of a C3 Jacobian have 696 of them, not 20 100
+        HIPCHK(ctx->cont_t.reserve((size_t)rows * Wpad * sizeof(double)));
+        hipLaunchKernelGGL(k_tau_rayleigh_rows, dim3(nblk((size_t)rows * Wpad, 256)), dim3(256), 0, ctx->stream, rows, W, Wpad, ray_mode,
+                           ISPACE, ctx->d_wave.as<double>(), tau_slot ? ctx->dd_work.as<int32_t>() : (const int32_t *)nullptr,
+                           ray_totam, ray_f4, ctx->cont_t.as<double>());
+        HIPCHK(hipGetLastError());
+        cont_t = ctx->cont_t.as<double>();
+    } else if (taucont) {
         HIPCHK(ctx->cont_t.reserve((size_t)n_models * L * Wpad * sizeof(double)));
         launch_w_to_last(ctx->stream, (unsigned)n_models, taucont, ctx->cont_t.as<double>(), W, Wpad, 1, L, 0, 0.0, (size_t)W * L, (size_t)L * Wpad);
         HIPCHK(hipGetLastError());
@@ -739,6 +787,7 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
     r.tau = ctx->tau.as<double>();
     r.tau_slot = tau_slot;
     r.cont = cont_t;
+    r.cont_by_row = (ray_mode && tau_slot) ? 1 : 0;
     r.emi = nullptr;
     r.wave = ctx->d_wave.as<double>();
     r.delg = ctx->d_delg.as<double>();

@@ -108,23 +108,16 @@ struct RayParams {
     int Lm;                     // layers per state of a batch, 0 = one state
 };
 
-__global__ __launch_bounds__(128) void k_tau_rayleigh(RayParams p)
+// k(wavenumber[, composition of the layer]) of the four parametrisations: TAURAY = k * TOTAM
+__device__ __forceinline__ double rayleigh_k(int mode, int ispace, double v, const double *f4row)
 {
 #pragma clang fp contract(off)      // n*n - 1 with n = 1 + 4e-4 cancels: a fused multiply-add would differ from NumPy by 1e-13
-    // one thread per output element in storage order (layer fastest): the [W][L] / [n][W][Lm] arrays are written in whole
-    // cache lines (a thread per wavenumber and a block row per layer wrote 8 bytes every L * 8: 3.1 ms for the 201 states
-    // of a C3 Jacobian)
-    const size_t flat = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int Lm = p.Lm ? p.Lm : p.L;
-    if (flat >= (size_t)p.W * p.L) return;
-    const int lm = (int)(flat % Lm), w = (int)((flat / Lm) % p.W), l = (int)(flat / ((size_t)Lm * p.W)) * Lm + lm;
     const double PI = 3.141592653589793;
-    const double v = p.wavec[w];
     double k = 0.0;
-    if (p.mode == 1) {                                           // :5543-5577
+    if (mode == 1) {                                           // :5543-5577
         const double AH2 = 13.58E-5, BH2 = 7.52E-3, AHe = 3.48E-5, BHe = 2.30E-3, fH2 = 0.864;
         const double kb = 1.37971e-23, P0 = 1.01325e5, T0 = 273.15;
-        const double LAMBDA = (p.ispace == 0) ? 1. / v * 1.0e-2 : v * 1.0e-6;
+        const double LAMBDA = (ispace == 0) ? 1. / v * 1.0e-2 : v * 1.0e-6;
         double x = 1.0 / (LAMBDA * 1.0e6);
         const double nH2 = AH2 * (1.0 + BH2 * x * x);
         const double nHe = AHe * (1.0 + BHe * x * x);
@@ -134,12 +127,12 @@ __global__ __launch_bounds__(128) void k_tau_rayleigh(RayParams p)
         x = N0 * LAMBDA * LAMBDA;
         const double faniso = (6.0 + 3.0 * 0.0) / (6.0 - 7.0 * 0.0);
         k = temp * faniso / (3. * (x * x));
-    } else if (p.mode == 12) {                                   // :5620-5632
-        const double LAMBDA = (p.ispace == 0) ? 1. / v * 1.0e4 : v;
+    } else if (mode == 12) {                                   // :5620-5632
+        const double LAMBDA = (ispace == 0) ? 1. / v * 1.0e4 : v;
         const double l2 = LAMBDA * LAMBDA;
         k = 8.8e-28 / (l2 * l2) * 1.0e-4;
-    } else if (p.mode == 2) {                                    // :5670-5695
-        const double LAMBDA = (p.ispace == 0) ? 1. / v * 1.0e4 : v;
+    } else if (mode == 2) {                                    // :5670-5695
+        const double LAMBDA = (ispace == 0) ? 1. / v * 1.0e4 : v;
         const double dens = 2.5475605e+19;
         const double lam = LAMBDA * 1.0e-4;
         const double f_king = 1.14 + (25.3e-12) / (lam * lam);
@@ -153,7 +146,7 @@ __global__ __launch_bounds__(128) void k_tau_rayleigh(RayParams p)
         k = (24. * (PI * PI * PI) / (l2 * l2) / (dens * dens)) * factor1 * f_king;
         k = k * 1.0e-4;
     } else {                                                     // mode 4, :5745-5824
-        const double *f = p.f4 + (size_t)l * 4;
+        const double *f = f4row;
         const double fh2 = f[0], fhe = f[1], fch4 = f[2], fnh3 = f[3];
         double fheh2 = 0.0, fch4h2 = 0.0;
         if (fh2 > 0.0) { fheh2 = fhe / fh2; fch4h2 = fch4 / fh2; }
@@ -163,7 +156,7 @@ __global__ __launch_bounds__(128) void k_tau_rayleigh(RayParams p)
         comp[2] = fch4h2 * comp[0];
         comp[3] = fnh3;
         const double losch = 2.687e19 * 1.0E+12;                 // loschpm3 as the reference forms it (:5786)
-        const double wl = (p.ispace == 0) ? 1. / v * 1.0e4 : v;
+        const double wl = (ispace == 0) ? 1. / v * 1.0e4 : v;
         const double A[4] = {13.58e-5, 3.48e-5, 37.0e-5, 37.0e-5};
         const double B[4] = {7.52e-3, 2.3e-3, 12.0e-3, 12.0e-3};
         const double D[4] = {0.0221, 0.025, .0922, .0922};
@@ -179,8 +172,38 @@ __global__ __launch_bounds__(128) void k_tau_rayleigh(RayParams p)
         const double fact = 8.0 * (PI * PI * PI) / (3.0 * (wl2 * wl2) * (losch * losch));
         k = fact * xc1 * 1.0E-8 / sumwt * 1.0e-4;
     }
+    return k;
+}
+
+__global__ __launch_bounds__(128) void k_tau_rayleigh(RayParams p)
+{
+#pragma clang fp contract(off)
+    // one thread per output element in storage order (layer fastest): the [W][L] / [n][W][Lm] arrays are written in whole
+    // cache lines (a thread per wavenumber and a block row per layer wrote 8 bytes every L * 8: 3.1 ms for the 201 states
+    // of a C3 Jacobian)
+    const size_t flat = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Lm = p.Lm ? p.Lm : p.L;
+    if (flat >= (size_t)p.W * p.L) return;
+    const int lm = (int)(flat % Lm), w = (int)((flat / Lm) % p.W), l = (int)(flat / ((size_t)Lm * p.W)) * Lm + lm;
+    const double k = rayleigh_k(p.mode, p.ispace, p.wavec[w], p.mode == 4 ? p.f4 + (size_t)l * 4 : nullptr);
     p.tau[flat] = k * p.totam[l];
     if (p.dtau) p.dtau[flat] = k;
+}
+
+// The same for the distinct layers of a batch, in the layout the thermal RT reads ([row][Wpad], zero beyond W): row r is
+// layer work[r] (flattened (state, layer); nullptr: r itself) of totam [n * L] / f4 [n * L][4].  One thread per (row, wavenumber).
+__global__ __launch_bounds__(256) void k_tau_rayleigh_rows(int rows, int W, int Wpad, int mode, int ispace, const double *__restrict__ wavec,
+                                                           const int32_t *__restrict__ work, const double *__restrict__ totam,
+                                                           const double *__restrict__ f4, double *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    const size_t flat = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (flat >= (size_t)rows * Wpad) return;
+    const int w = (int)(flat % Wpad), r = (int)(flat / Wpad);
+    if (w >= W) { out[flat] = 0.0; return; }
+    const int l = work ? work[r] : r;
+    const double k = rayleigh_k(mode, ispace, wavec[w], mode == 4 ? f4 + (size_t)l * 4 : nullptr);
+    out[flat] = k * totam[l];
 }
 
 // ------------------------------------------------------------------------------------------------------------------

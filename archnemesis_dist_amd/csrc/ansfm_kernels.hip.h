@@ -1111,9 +1111,12 @@ __global__ void k_kta_relayout(const float *__restrict__ kf, double *__restrict_
 // so that the merge kernel sees them as the layers of one pseudo-model; k_thermal_rt follows tau_slot.
 // Nothing is approximated: a layer is shared only when all of its S+2 inputs are equal to the last bit.
 // ------------------------------------------------------------------------------------------------
+// x1 [n][L], x4 [n][L][4] (or nullptr): further per-layer inputs that are part of a row's identity (the column and the
+// composition the Rayleigh continuum of a row is formed from, ansfm_cirsrad_ck_thermal_ray_dev).
 __global__ void k_dedup_mark(int n_models, int L, int S, const double *__restrict__ press,
                              const double *__restrict__ temp, const double *__restrict__ amount,
-                             int32_t *__restrict__ slot, int32_t *__restrict__ work, int *__restrict__ counter)
+                             int32_t *__restrict__ slot, int32_t *__restrict__ work, int *__restrict__ counter,
+                             const double *__restrict__ x1 = nullptr, const double *__restrict__ x4 = nullptr)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_models * L) return;
@@ -1121,6 +1124,9 @@ __global__ void k_dedup_mark(int n_models, int L, int S, const double *__restric
     if (m == 0) { slot[i] = l; work[l] = i; return; }
     auto bits = [](double x) { return __double_as_longlong(x); };
     bool same = bits(press[i]) == bits(press[l]) && bits(temp[i]) == bits(temp[l]);
+    if (same && x1) same = bits(x1[i]) == bits(x1[l]);
+    if (same && x4)
+        for (int c = 0; c < 4 && same; ++c) same = bits(x4[(size_t)i * 4 + c]) == bits(x4[(size_t)l * 4 + c]);
     for (int s = 0; s < S && same; ++s)
         same = bits(amount[((size_t)m * S + s) * L + l]) == bits(amount[(size_t)s * L + l]);
     if (same) { slot[i] = l; return; }
@@ -1306,7 +1312,7 @@ constexpr int kGPer = kMaxG / kGY;  // 4
 struct RtParams {
     const double *tau;      // [n][L][G][Wpad], or [unique layers][G][Wpad] addressed through tau_slot
     const int32_t *tau_slot;// [n][L] row of tau holding layer (m, l), or nullptr (identity)
-    const double *cont;     // [n][L][Wpad] or nullptr
+    const double *cont;     // [n][L][Wpad] or nullptr; cont_by_row: [rows][Wpad] addressed like tau
     const double *emi;      // [Li][Wpad] or nullptr  (array-level seam only)
     const double *wave;     // [W]
     const double *delg;     // [G]
@@ -1335,6 +1341,7 @@ struct RtParams {
     double *prefix;
     const int32_t *jstart;  // [n][P]
     int m0;
+    int cont_by_row;
 };
 
 // same[m][lay] = the opacity row of (m, lay) is state 0's row and (cont != nullptr) so is its continuum, bit for bit.
@@ -1426,7 +1433,7 @@ __global__ __launch_bounds__(kWave *kGY) __attribute__((amdgpu_waves_per_eu(BATC
         const size_t ri = (size_t)m_row[j];
         const int lay = (int)m_lay[j];
         const double *trow = p.tau + (ri * G) * p.Wpad + nu;
-        tc = p.cont ? p.cont[((size_t)m * p.L + lay) * p.Wpad + nu] : 0.0;
+        tc = p.cont ? p.cont[(p.cont_by_row ? ri : (size_t)m * p.L + lay) * p.Wpad + nu] : 0.0;
         em = p.emi ? p.emi[(size_t)j * p.Wpad + nu] : 0.0;
 #pragma unroll
         for (int k = 0; k < kGPer; ++k) {

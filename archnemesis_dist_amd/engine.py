@@ -417,6 +417,35 @@ class AnsfmEngine:
             _ptr(SPECOUT))
         self._check(rc, "cirsrad_ck_thermal_dev")
 
+    def cirsrad_ck_thermal_ray_dev(self, ISPACE, n_models, L, lay_press_pa, lay_temp, amount, IRAY, TOTAM, f4, P, LIMAX,
+                                   NLAYIN, LAYINC, SCALE, EMTEMP, TSURF, EMISSIVITY, SOLFLUX, REFLECTANCE, SOL_ANG,
+                                   EMISS_ANG, xfac, SPECOUT, variant=None):
+        """cirsrad_ck_thermal_dev for a batch whose continuum is Rayleigh scattering alone: TOTAM (n, L) and, IRAY 4,
+        f4 (n, L, 4) (see rayleigh_f4) are device tensors; the continuum is formed per distinct layer inside the call."""
+        mode = 12 if variant == "v" else int(IRAY)
+        rc = self._lib.ansfm_cirsrad_ck_thermal_ray_dev(
+            self._ctx, int(ISPACE), int(n_models), int(L), _ptr(lay_press_pa), _ptr(lay_temp), _ptr(amount), mode, _ptr(TOTAM),
+            _ptr(f4), int(P), int(LIMAX), _ptr(NLAYIN), _ptr(LAYINC), _ptr(SCALE), _ptr(EMTEMP), _ptr(TSURF), _ptr(EMISSIVITY),
+            _ptr(SOLFLUX), _ptr(REFLECTANCE), _ptr(SOL_ANG), _ptr(EMISS_ANG), _ptr(xfac), _ptr(SPECOUT))
+        self._check(rc, "cirsrad_ck_thermal_ray_dev")
+
+    @staticmethod
+    def rayleigh_f4(ID, ISO, VMR):
+        """calc_tau_rayleighls' composition (:5748-5767): VMR (..., NVMR) numpy array or torch tensor -> (..., 4) mixing
+        ratios of H2, He, CH4, NH3, zero where the gas is absent; the last matching gas wins."""
+        ID = np.asarray(ID); ISO = np.asarray(ISO)
+        if isinstance(VMR, np.ndarray):
+            f4 = np.zeros(VMR.shape[:-1] + (4,))
+        else:
+            import torch
+            f4 = torch.zeros(tuple(VMR.shape[:-1]) + (4,), dtype=VMR.dtype, device=VMR.device)
+        for j in range(ID.size):
+            if ISO[j] in (0, 1):
+                col = {39: 0, 40: 1, 6: 2, 11: 3}.get(int(ID[j]))
+                if col is not None:
+                    f4[..., col] = VMR[..., j]
+        return f4
+
     def scloud11wave_core(self, phasarr, radg, sol_angs, emiss_angs, solar, aphis, lowbc, brdf_matrix, mu1, wt1, nf,
                           vwaves, bnu, taus, tauray, omegas_s, nphi, iray, imie, lfrac):
         """Multiple_Scattering_Core.scloud11wave_core (same arguments) -> rad (NPATH, NG, NWAVE)."""
@@ -752,15 +781,7 @@ class AnsfmEngine:
         if not isinstance(TOTAM, np.ndarray) and hasattr(TOTAM, "data_ptr"):      # torch device tensors (layer_average_dev)
             import torch
             n, L = TOTAM.shape
-            f4 = None
-            if mode == 4:
-                f4 = torch.zeros((n, L, 4), dtype=torch.float64, device=TOTAM.device)
-                ID = np.asarray(ID); ISO = np.asarray(ISO)
-                for j in range(ID.size):
-                    if ISO[j] in (0, 1):
-                        col = {39: 0, 40: 1, 6: 2, 11: 3}.get(int(ID[j]))
-                        if col is not None:
-                            f4[:, :, col] = VMR[:, :, j]
+            f4 = self.rayleigh_f4(ID, ISO, VMR) if mode == 4 else None
             if tuple(out.shape)[0] != n or tuple(out.shape)[2] != L or not out.is_contiguous() or not TOTAM.is_contiguous():
                 raise ValueError("out must be a contiguous (n, NWAVE, NLAY) float64 device tensor")
             rc = self._lib.ansfm_calc_tau_rayleigh_batch_dev_in(self._ctx, mode, int(ISPACE), n, L, _ptr(TOTAM), _ptr(f4), _ptr(out))

@@ -135,6 +135,7 @@ class BatchedCKThermalModel:
 
     # ---- the same with the layers left in HBM ----------------------------------------------------------------------
     device_layers = True      # False: `layers` (host arrays) feeds spectra_batch, as in rounds 1-2; same numbers bit for bit
+    fused_rayleigh = True     # False: the Rayleigh continuum of all n * NLAY layers as an array of its own (same bits)
 
     def layers_dev(self, X, dev, order=lambda: None, drain=lambda: None):
         """`layers` without the round trip over PCIe: the profiles of the n states are put together on the device (the
@@ -239,6 +240,17 @@ class BatchedCKThermalModel:
         c, path = lay["consts"], lay["path"]
         n, L = lay["PRESS"].shape
         P_, LIMAX = path.NPATH, path.LAYINC.shape[0]
+        out = torch.empty((n, self.W, P_), dtype=torch.float64, device=dev)
+        if self.IRAY != 0 and self.extra is None and self.fused_rayleigh:
+            # the Rayleigh continuum is formed inside the call, once per distinct layer of the batch
+            f4 = eng.rayleigh_f4(self.ID, self.ISO, lay["VMRLAY"]) if self.IRAY == 4 else None
+            args = (lay["PRESS"].contiguous(), lay["TEMP"].contiguous(), lay["amount"], self.IRAY, lay["TOTAM"].contiguous(), f4, P_,
+                    LIMAX, c["NLAYIN32"], c["LAYINC32"], c["SCALE"], lay["EMTEMP"].contiguous(), c["TSURF"])
+            order()
+            eng.cirsrad_ck_thermal_ray_dev(self.ISPACE, n, L, *args, None, None, None, None, None, None, out)
+            self.last_rows = eng.last_layer_rows()
+            drain()
+            return out.reshape(n, self.W * P_)
         cont = None
         if self.IRAY != 0 or self.extra is not None:
             if self.IRAY != 0:
@@ -251,7 +263,6 @@ class BatchedCKThermalModel:
                 cont = torch.zeros((n, self.W, L), dtype=torch.float64, device=dev)
             if self.extra is not None:
                 cont += torch.as_tensor(self.extra, dtype=torch.float64, device=dev)[None]
-        out = torch.empty((n, self.W, P_), dtype=torch.float64, device=dev)
         args = (lay["PRESS"].contiguous(), lay["TEMP"].contiguous(), lay["amount"], cont, P_, LIMAX, c["NLAYIN32"], c["LAYINC32"],
                 c["SCALE"], lay["EMTEMP"].contiguous(), c["TSURF"])
         order()

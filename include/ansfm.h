@@ -212,6 +212,19 @@ int ansfm_cirsrad_ck_thermal_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L
                                  const double *REFLECTANCE, const double *SOL_ANG,
                                  const double *EMISS_ANG, const double *xfac, double *SPECOUT);
 
+/* The same for a batch whose only continuum is Rayleigh scattering (calc_tau_rayleigh, ForwardModel_0.py:4869; ray_mode =
+ * IRAY 1, 2, 4, or 12 for calc_tau_rayleighv): TAURAY = k(wavenumber[, composition]) * TOTAM is formed inside the call from
+ * the DEVICE arrays TOTAM[n][L] (m-2) and, ray_mode 4, f4[n][L][4] (mixing ratios of H2, He, CH4, NH3) -- once per DISTINCT
+ * layer of the batch (TOTAM and f4 are part of a layer's identity next to pressure, temperature and amounts) and straight in
+ * the layout the RT kernel reads.  The n * NWAVE * L array ansfm_calc_tau_rayleigh_batch_dev would fill (1.6 GB for the 201
+ * states of BASELINE configs[2]) is neither written, transposed nor compared.  Same bits as the two-call route. */
+int ansfm_cirsrad_ck_thermal_ray_dev(ansfm_ctx *ctx, int ISPACE, int n_models, int L, const double *lay_press_pa,
+                                     const double *lay_temp, const double *amount, int ray_mode, const double *TOTAM,
+                                     const double *f4, int P, int LIMAX, const int32_t *NLAYIN, const int32_t *LAYINC,
+                                     const double *SCALE, const double *EMTEMP, const double *TSURF, const double *EMISSIVITY,
+                                     const double *SOLFLUX, const double *REFLECTANCE, const double *SOL_ANG,
+                                     const double *EMISS_ANG, const double *xfac, double *SPECOUT);
+
 /* CIRSrad, pure-transmission branch (IMOD without ABSORBTION / THERMAL_EMISSION / scattering flags; ForwardModel_0.py:
  * 4478-4481 -> calculate_transmission_spectrum :4110-4131): SPECOUT[n][W][P] = xfac[W] * sum_g DELG[g] exp(-sum_layers
  * TAUTOT_LAYINC) -- the same opacity assembly as the thermal branch, the RT kernel's epilogue switched.  xfac = the

@@ -195,8 +195,12 @@ def test_c3_numerical_jacobian_vs_oracle(oracle, pointing, f32):
         model.device_layers = False
         YN_h, KK_h = jacobian_nemesis_batched(model)
         assert np.array_equal(YN, YN_h) and np.array_equal(KK, KK_h) and model.last_rows == (rows, total)
-        import torch
         model.device_layers = True
+        model.fused_rayleigh = False                                    # the continuum as an (n, NWAVE, NLAY) array of its own
+        YN_c, KK_c = jacobian_nemesis_batched(model)
+        assert np.array_equal(YN, YN_c) and np.array_equal(KK, KK_c) and model.last_rows == (rows, total)
+        model.fused_rayleigh = True
+        import torch
         side = torch.cuda.Stream(device=model.torch_device())          # torch on a stream of its own, the engine on another
         with torch.cuda.stream(side):
             YN_s, KK_s = jacobian_nemesis_batched(model)
