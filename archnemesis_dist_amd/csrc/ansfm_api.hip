@@ -622,7 +622,7 @@ static int launch_rt(ansfm_ctx *ctx, const RtParams &p_in, int n_models)
         int32_t *jstart = reinterpret_cast<int32_t *>(same + off_j);
         hipLaunchKernelGGL(k_rt_same, dim3((unsigned)p.L, (unsigned)(n_models - 1)), dim3(256), 0, ctx->stream, p.L, p.Wpad, p.tau_slot,
                            p.cont_by_row ? nullptr : p.cont, same);      // a continuum stored by row is the row's
-        hipLaunchKernelGGL(k_rt_jstart, dim3(nblk(np, 128)), dim3(128), 0, ctx->stream, n_models, p.L, p.P, p.LIMAX, p.nlayin, p.layinc,
+        hipLaunchKernelGGL(k_rt_jstart, dim3((unsigned)np), dim3(64), 0, ctx->stream, n_models, p.L, p.P, p.LIMAX, p.nlayin, p.layinc,
                            p.scale, p.emtemp, same, jstart);
         p.prefix = ctx->rt_prefix.as<double>(); p.jstart = jstart; p.m0 = 0;
         const size_t lds = (size_t)4 * p.LIMAX * sizeof(double);
@@ -2942,7 +2942,10 @@ static int layer_average_impl(ansfm_ctx *ctx, int n_models, double RADIUS, int N
     static const bool share_off = [] { const char *e = getenv("ANSFM_LAYER_SHARE"); return e && e[0] == '0'; }();
     if (n_models > 1 && !with_grad && !share_off) {
         hipLaunchKernelGGL(k_layer_average, dim3((unsigned)NLAY, 1u), dim3(128), 0, ctx->stream, p);
-        p.m0 = 1; p.share = 1;
+        HIPCHK(ctx->rt_same.reserve(nl));                 // (not in use at this point of a call sequence)
+        unsigned char *flag = ctx->rt_same.as<unsigned char>();
+        hipLaunchKernelGGL(k_layer_share, dim3(nblk(nl - NLAY, 128)), dim3(128), 0, ctx->stream, p, flag);
+        p.m0 = 1; p.share = flag;
         hipLaunchKernelGGL(k_layer_average, dim3((unsigned)NLAY, (unsigned)(n_models - 1)), dim3(128), 0, ctx->stream, p);
     } else
         hipLaunchKernelGGL(k_layer_average, dim3((unsigned)NLAY, (unsigned)n_models), dim3(128), 0, ctx->stream, p);

@@ -1359,26 +1359,33 @@ __global__ void k_rt_same(int L, int Wpad, const int32_t *__restrict__ slot, con
     if (threadIdx.x == 0) same[(size_t)m * L + lay] = differs ? 0 : 1;
 }
 
-// jstart[m][ip] = number of leading layers of path ip that state m shares with state 0 (one thread per (m, ip); m = 0: 0)
-__global__ void k_rt_jstart(int n, int L, int P, int LIMAX, const int32_t *__restrict__ nlayin, const int32_t *__restrict__ layinc,
-                            const double *__restrict__ scale, const double *__restrict__ emtemp,
-                            const unsigned char *__restrict__ same, int32_t *jstart)
+// jstart[m][ip] = number of leading layers of path ip that state m shares with state 0 (one wave per (m, ip); m = 0: 0)
+__global__ __launch_bounds__(64) void k_rt_jstart(int n, int L, int P, int LIMAX, const int32_t *__restrict__ nlayin,
+                                                  const int32_t *__restrict__ layinc, const double *__restrict__ scale,
+                                                  const double *__restrict__ emtemp, const unsigned char *__restrict__ same,
+                                                  int32_t *jstart)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * P) return;
+    const int idx = blockIdx.x, lane = threadIdx.x;
     const int m = idx / P, ip = idx % P;
-    int j = 0;
+    int first = 0;
     if (m > 0) {
         const int nl = nlayin[ip];
         const size_t pm = (size_t)m * LIMAX * P + ip, p0 = ip;
-        for (; j < nl; ++j) {
-            const int lay = layinc[(size_t)j * P + ip];
-            if (!same[(size_t)m * L + lay]) break;
-            if (__double_as_longlong(scale[pm + (size_t)j * P]) != __double_as_longlong(scale[p0 + (size_t)j * P])) break;
-            if (__double_as_longlong(emtemp[pm + (size_t)j * P]) != __double_as_longlong(emtemp[p0 + (size_t)j * P])) break;
+        first = nl;
+        for (int j0 = 0; j0 < nl; j0 += 64) {
+            const int j = j0 + lane;
+            bool bad = false;
+            if (j < nl) {
+                const int lay = layinc[(size_t)j * P + ip];
+                bad = !same[(size_t)m * L + lay] ||
+                      __double_as_longlong(scale[pm + (size_t)j * P]) != __double_as_longlong(scale[p0 + (size_t)j * P]) ||
+                      __double_as_longlong(emtemp[pm + (size_t)j * P]) != __double_as_longlong(emtemp[p0 + (size_t)j * P]);
+            }
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(bad);
+            if (hit != 0) { first = j0 + __builtin_ctzll(hit); break; }
         }
     }
-    jstart[idx] = j;
+    if (lane == 0) jstart[idx] = first;
 }
 
 __device__ __forceinline__ double planck_bb(double a, double c2y, double T)

@@ -35,11 +35,59 @@ struct LayerAvgParams {
     // matrices DTE, DAM, DCO, DPH [n][NLAY][NPRO] (zeroed by the caller)
     int with_grad, any_dust_units;
     double *DTE, *DAM, *DCO, *DPH;
-    // A numerical Jacobian's states differ from state 0 at one profile level or two: m0 = first state of this launch; share != 0
-    // (launched after state 0's own launch, without gradients): a layer whose sub-points read only levels at which the state
-    // holds state 0's very numbers takes state 0's results instead of integrating again -- same bits either way
-    int m0, share;
+    // A numerical Jacobian's states differ from state 0 at one profile level or two: m0 = first state of this launch; a layer
+    // whose sub-points read only levels at which the state holds state 0's very numbers takes state 0's results instead of
+    // integrating again (k_layer_share, after state 0's own launch, without gradients) -- same bits either way
+    int m0;
+    const unsigned char *share;   // [n][NLAY] or nullptr: 1 = k_layer_share copied state 0's layer, nothing to do
 };
+
+__device__ __forceinline__ int lay_bracket(const double *x, int n, double xn);
+
+// One thread per (state m >= 1, layer): the sub-points of a layer lie between its two ends along the ray, and their heights --
+// the same expressions as k_layer_average's phase 1, every operation monotone in s -- between the heights of those ends: the
+// layer reads the levels bracket(h(S0)) - 1 .. bracket(h(S1)), those of its base (BASET), and the top level (SMAX).  If the
+// state holds state 0's numbers there (bit for bit: H, P, T, para-H2, every gas, the dust, the molecular weight; the layer's
+// bases), its results are state 0's: copy them and flag the layer.
+__global__ void k_layer_share(LayerAvgParams p, unsigned char *flag)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int NL = p.NLAY, NPRO = p.NPRO, V = p.NVMR, D = p.NDUST;
+    if (idx >= (p.n_models - 1) * NL) return;
+    const int m = 1 + idx / NL, I = idx % NL;
+    const double PI = 3.141592653589793;
+    const double *H = p.H + (size_t)m * NPRO, *BASEH = p.BASEH + (size_t)m * NL;
+    auto ne = [](double a, double b) { return __double_as_longlong(a) != __double_as_longlong(b); };
+    bool differs = ne(H[NPRO - 1], p.H[NPRO - 1]) || ne(BASEH[I], p.BASEH[I]) || (I < NL - 1 && ne(BASEH[I + 1], p.BASEH[I + 1]));
+    if (!differs) {
+        const double sn = sin(p.LAYANG * PI / 180), cs = cos(p.LAYANG * PI / 180);
+        const double z0 = p.RADIUS + p.LAYHT, zmax = p.RADIUS + H[NPRO - 1];
+        const double SMAX = sqrt(zmax * zmax - (z0 * sn) * (z0 * sn)) - z0 * cs;
+        auto bases = [&](int i) { const double r = p.RADIUS + BASEH[i]; return sqrt(r * r - (z0 * sn) * (z0 * sn)) - z0 * cs; };
+        const double S0 = bases(I), S1 = (I < NL - 1) ? bases(I + 1) : SMAX;
+        double sa = S0, sb = S1;
+        if (p.LAYINT == 0) sa = sb = (I < NL - 1) ? (bases(I + 1) + S0) / 2 : (SMAX + S0) / 2;
+        const double ha = sqrt(sa * sa + z0 * z0 + 2 * sa * z0 * cs) - p.RADIUS, hb = sqrt(sb * sb + z0 * z0 + 2 * sb * z0 * cs) - p.RADIUS;
+        const int ia = lay_bracket(H, NPRO, ha), ib = lay_bracket(H, NPRO, hb), ic = lay_bracket(H, NPRO, BASEH[I]);
+        const int lo = min(min(ia, ib), ic) - 1, hi = max(max(ia, ib), ic);
+        const bool xm = p.dust_units && p.XMOLWT;
+        for (int lev = lo; lev <= hi && !differs; ++lev) {
+            const size_t a = (size_t)m * NPRO + lev;
+            differs = ne(p.H[a], p.H[lev]) || ne(p.P[a], p.P[lev]) || ne(p.T[a], p.T[lev]);
+            if (p.PARAH2) differs = differs || ne(p.PARAH2[a], p.PARAH2[lev]);
+            if (xm) differs = differs || ne(p.XMOLWT[a], p.XMOLWT[lev]);
+            for (int j = 0; j < V && !differs; ++j) differs = ne(p.VMR[a * V + j], p.VMR[(size_t)lev * V + j]);
+            for (int j = 0; j < D && !differs; ++j) differs = ne(p.DUST[a * D + j], p.DUST[(size_t)lev * D + j]);
+        }
+    }
+    const size_t o = (size_t)m * NL + I, b = I;
+    flag[o] = differs ? 0 : 1;
+    if (differs) return;
+    p.HEIGHT[o] = p.HEIGHT[b]; p.PRESS[o] = p.PRESS[b]; p.TEMP[o] = p.TEMP[b]; p.TOTAM[o] = p.TOTAM[b];
+    p.FRAC[o] = p.FRAC[b]; p.DELH[o] = p.DELH[b]; p.BASET[o] = p.BASET[b]; p.LAYSF[o] = p.LAYSF[b];
+    for (int J = 0; J < V; ++J) { p.AMOUNT[o * V + J] = p.AMOUNT[b * V + J]; p.PP[o * V + J] = p.PP[b * V + J]; }
+    for (int J = 0; J < D; ++J) p.CONT[o * D + J] = p.CONT[b * D + J];
+}
 
 // Layer_0.interpg (:716-751): j = clip(#{x <= X}, 1, n-1)
 __device__ __forceinline__ int lay_bracket_g(const double *x, int n, double xn)
@@ -74,7 +122,6 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
     __shared__ double res[160];
     __shared__ double cA[kLayMaxNint / 2], cB0[kLayMaxNint / 2], cB1[kLayMaxNint / 2], cB2[kLayMaxNint / 2];
     __shared__ double IN[kLayPairTerms];
-    __shared__ int lv_lo, lv_hi;
     const bool GR = p.with_grad != 0;
     const double k_B = 1.38065e-23, AVOGAD = 6.02214076e23, PI = 3.141592653589793;
     const int I = blockIdx.x, m = blockIdx.y + p.m0, tid = threadIdx.x;
@@ -94,9 +141,7 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
     const double DELH = (I < NL - 1) ? BASEH[I + 1] - BASEH[I] : H[NPRO - 1] - BASEH[NL - 1];
     const double LAYSF = DELS / DELH;
     const int npts = (p.LAYINT == 0) ? 1 : p.NINT;
-    const bool sharing = p.share != 0 && m > 0 && !GR;
-    if (sharing && tid == 0) { lv_lo = NPRO; lv_hi = 0; }
-    if (sharing) __syncthreads();
+    if (p.share != nullptr && p.share[(size_t)m * NL + I]) return;     // k_layer_share took state 0's results for this layer
     // ---- phase 1: sub-points -------------------------------------------------------------------------
     for (int k = tid; k < npts; k += blockDim.x) {
         double s;
@@ -115,43 +160,8 @@ __global__ __launch_bounds__(256) void k_layer_average(LayerAvgParams p)
         S[k] = s; hh[k] = h; idx[k] = ix; pp[k] = pk;
         duds[k] = pk / (k_B * tk);
         mw[k] = XM ? lay_interp(H, XM, 1, ix, h) * 1000. : 0.0;       // XMOLWT *= 1000 :877
-        if (sharing) { atomicMin(&lv_lo, ix - 1); atomicMax(&lv_hi, ix); }
     }
     __syncthreads();
-    if (sharing) {
-        // the levels this layer reads: the brackets of its sub-points and of its base (BASET); the top level enters SMAX
-        const int ib = lay_bracket(H, NPRO, BASEH[I]);
-        const int lo = min(lv_lo, ib - 1), hi = max(lv_hi, ib);
-        const int nlev = hi - lo + 1, per = 4 + V + D + (XM ? 1 : 0);
-        int differs = 0;
-        auto ne = [](double a, double b) { return __double_as_longlong(a) != __double_as_longlong(b); };
-        for (int e = tid; e < nlev * per; e += blockDim.x) {
-            const int lev = lo + e / per, f = e % per;
-            bool d;
-            if (f == 0) d = ne(H[lev], p.H[lev]);
-            else if (f == 1) d = ne(P[lev], p.P[lev]);
-            else if (f == 2) d = ne(T[lev], p.T[lev]);
-            else if (f == 3) d = PH2 ? ne(PH2[lev], p.PARAH2[lev]) : false;
-            else if (f < 4 + V) d = ne(VMR[(size_t)lev * V + (f - 4)], p.VMR[(size_t)lev * V + (f - 4)]);
-            else if (f < 4 + V + D) d = ne(DUST[(size_t)lev * D + (f - 4 - V)], p.DUST[(size_t)lev * D + (f - 4 - V)]);
-            else d = ne(XM[lev], p.XMOLWT[lev]);
-            differs |= d ? 1 : 0;
-        }
-        if (tid == 0) {
-            differs |= ne(H[NPRO - 1], p.H[NPRO - 1]) || ne(BASEH[I], p.BASEH[I]) ||
-                       (I < NL - 1 && ne(BASEH[I + 1], p.BASEH[I + 1]));
-        }
-        if (!__syncthreads_or(differs)) {
-            const size_t o = (size_t)m * NL + I, b = I;
-            if (tid == 0) {
-                p.HEIGHT[o] = p.HEIGHT[b]; p.PRESS[o] = p.PRESS[b]; p.TEMP[o] = p.TEMP[b]; p.TOTAM[o] = p.TOTAM[b];
-                p.FRAC[o] = p.FRAC[b]; p.DELH[o] = p.DELH[b]; p.BASET[o] = p.BASET[b]; p.LAYSF[o] = p.LAYSF[b];
-            }
-            for (int J = tid; J < V; J += blockDim.x) { p.AMOUNT[o * V + J] = p.AMOUNT[b * V + J]; p.PP[o * V + J] = p.PP[b * V + J]; }
-            for (int J = tid; J < D; J += blockDim.x) p.CONT[o * D + J] = p.CONT[b * D + J];
-            return;
-        }
-    }
     // ---- phase 2: one thread per integrated quantity ----------------------------------------------------
     const int NQ = 5 + 2 * V + D;
     auto yval_q = [&](int q, int k) -> double {

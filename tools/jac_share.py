@@ -1,6 +1,8 @@
+"""Wall time of the batched C3 Jacobian (201 states) on a table of W wavenumbers -- W = 1250: one rank's share of an 8-GPU run
+sharded over the spectral axis.    python tools/jac_share.py [W]      (rocprofv3 --kernel-trace --stats -- python3 tools/jac_share.py 1250)"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import archnemesis_dist_amd as pkg
 from archnemesis_dist_amd import synthetic as syn
@@ -8,7 +10,7 @@ from archnemesis_dist_amd import jacobian as jac
 from archnemesis_dist_amd.profile_state import ContinuousProfileState, BatchedCKThermalModel
 from bench import torch_ktable
 dev = torch.device("cuda", 0)
-W = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 1250
 G, S, L, NP, NT = 20, 8, 100, 20, 15
 stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
 eng = pkg.AnsfmEngine(0); eng.set_stream(stream.cuda_stream)
@@ -20,14 +22,9 @@ pr = syn.synth_profiles(100, S + 2, seed=11)
 st = ContinuousProfileState(pr["H"], pr["P"], pr["T"], pr["VMR"], ["T", ("VMR", 2)])
 model = BatchedCKThermalModel(eng, st, pr["RADIUS"], pr["ID"], pr["ISO"], list(range(2, S + 2)),
                               layering_args=dict(NLAY=L, LAYINT=1, NINT=101), IRAY=4)
-X = jac.perturbed_states(st.XN, 0.05 * st.XN).T
-def t(f, *a):
-    torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(*a); torch.cuda.synchronize(); return (time.perf_counter() - t0) * 1e3, r
-print("W", W)
-for i in range(3):
-    print("layers alone %.2f ms" % t(model.layers, X)[0])
-for i in range(3):
-    ms, _ = t(model.spectra_batch, X)
-    print("spectra_batch %.2f ms" % ms, end="; ")
-    print("layers right after %.2f ms" % t(model.layers, X)[0], end="; ")
-    print("again %.2f ms" % t(model.layers, X)[0])
+ts = []
+for i in range(12):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    YN, KK = jac.jacobian_nemesis_batched(model)
+    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+print("W", W, "jacobian ms:", " ".join("%.2f" % t for t in ts))
