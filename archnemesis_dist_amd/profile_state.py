@@ -149,7 +149,11 @@ class BatchedCKThermalModel:
         X = np.atleast_2d(np.asarray(X, float))
         n = X.shape[0]
         td = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
-        key = (n, str(dev))
+        # what the cached device constants were made from: the state's arrays (by identity and a checksum -- they are not
+        # meant to be edited in place), the layering, the geometry, the surface temperature
+        key = (n, str(dev), id(st), float(st.H.sum()), float(st.P.sum()), float(st.T.sum()), float(st.VMR.sum()), self.TSURF,
+               tuple(sorted((k, float(v)) for k, v in la.items())), tuple(sorted((k, float(v)) for k, v in ge.items())),
+               float(self.BASEH.sum()), tuple(int(i) for i in self.igas_map))
         c = getattr(self, "_dev_consts", None)
         if c is None or c["key"] != key:
             rep = lambda a: td(a)[None].expand((n,) + np.shape(a)).contiguous()
