@@ -46,12 +46,10 @@ def main():
             return r
         return g
     from archnemesis_dist_amd import layering
-    model.layers = timed("layers (profiles + layer_average + path)", model.layers)
-    eng.layer_average = timed("  of which eng.layer_average", eng.layer_average)
-    layering.calc_path = timed("  of which layering.calc_path", layering.calc_path)
-    st.profiles = timed("  of which state.profiles", st.profiles)
-    eng.calc_tau_rayleigh_batch_dev = timed("rayleigh", eng.calc_tau_rayleigh_batch_dev)
-    eng.cirsrad_ck_thermal_dev = timed("cirsrad (merge + rt)", eng.cirsrad_ck_thermal_dev)
+    # (every wrapper synchronises before and after: the phases add up to more than the untimed call, tools/jac_share.py)
+    model.layers_dev = timed("layers in HBM (profiles up, layer_average_dev, gathers)", model.layers_dev)
+    eng.layer_average_dev = timed("  of which eng.layer_average_dev", eng.layer_average_dev)
+    eng.cirsrad_ck_thermal_ray_dev = timed("cirsrad (rows' Rayleigh continuum + merge + rt)", eng.cirsrad_ck_thermal_ray_dev)
     jac.finite_difference_jacobian_dev = timed("KK quotient + copy", jac.finite_difference_jacobian_dev)
     for it in range(4):
         ph.clear()
