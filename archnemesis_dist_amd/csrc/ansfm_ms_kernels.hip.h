@@ -69,6 +69,7 @@ struct MsParams {
 };
 constexpr int kMsCacheEntry = 528;   // doubles per cached layer: r (256) and t (256) in the MFMA accumulator layout, j (16)
 constexpr int kMsPrefixStep = 4;     // the stack below is kept after sweep layers 3, 7, 11, ...
+constexpr int kMsHansenDepth = 8;    // steps the Hansen walk fetches its matrices ahead (k_ms_hansen_seq)
 
 __device__ __forceinline__ double ms_interp(double x, const double *xp, const double *fp, int n)
 {   // np.interp
@@ -224,7 +225,7 @@ __device__ __forceinline__ double ms_wave_max(double x)
 template <int NMU>   // NMU = 16: compile-time size (unrolled sums, all LDS reads in flight); 0: any nmu <= kMsMaxMu
 __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
 {
-    __shared__ double ppl_s[2][kMsMaxMu * kMsMaxMu], pmi_s[2][kMsMaxMu * kMsMaxMu], fc[kMsMaxMu * kMsMaxMu];
+    __shared__ double ppl_s[kMsMaxMu * kMsMaxMu], pmi_s[kMsMaxMu * kMsMaxMu], fc[kMsMaxMu * kMsMaxMu];
     __shared__ double rsum[kMsMaxMu], tsum[kMsMaxMu], xs[kMsMaxMu];
     // two waves on the whole chip walk while thousands of chain waves compute: the walk gates the chains of the next
     // g-ordinate, so its waves issue first wherever they share a SIMD
@@ -233,23 +234,29 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
     const int n = NMU ? NMU : p.nmu, nn = n * n, tid = threadIdx.x;
     const double x1 = 2.0 * 3.141592653589793;
     constexpr int NE = NMU ? (NMU * NMU + 63) / 64 : (kMsMaxMu * kMsMaxMu + 63) / 64;   // matrix elements per lane
-    double nppl[NE], npmi[NE];
-    // The walk is latency-bound: matrices are fetched two iterations ahead (registers), staged into the
-    // other LDS buffer one iteration ahead.
-    auto fetch = [&](int widx) {
+    // The walk is a chain of short steps (a converged start needs one pass over a 16 x 16 matrix) and every step needs two
+    // matrices from HBM / L2: a microsecond away.  They are fetched kMsHansenDepth steps ahead into a ring of registers (the
+    // loop is unrolled over the ring so that every slot is a fixed set of registers and the wait before a slot is used counts
+    // the younger loads and stores still in flight instead of draining them); fetched ONE step ahead, as until round 3, the
+    // step took the memory latency: 2.0-2.5 us, 20-25 ms per g-ordinate at 1e4 wavenumbers, which was the wall time of a C4
+    // forward model (the chain kernels of g-ordinate ig wait for the factors of ig).
+    constexpr int D = NMU ? kMsHansenDepth : 2;
+    constexpr bool FULL = NMU != 0 && (NMU * NMU) % 64 == 0;     // every lane holds NE elements: no bounds tests on the accesses
+    double ring[D][2 * NE];
+    auto fetch = [&](int d, int widx) {
         const double *gppl = p.ppl + (((size_t)widx * (p.nf + 1) + 0) * p.ncomp + comp) * nn;
         const double *gpmi = p.pmi + (((size_t)widx * (p.nf + 1) + 0) * p.ncomp + comp) * nn;
 #pragma unroll
         for (int r = 0; r < NE; ++r) {
             const int e = tid + 64 * r;
-            if (e < nn) { nppl[r] = gppl[e]; npmi[r] = gpmi[e]; }
+            if (FULL || e < nn) { ring[d][r] = gppl[e]; ring[d][NE + r] = gpmi[e]; }
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int d) {
 #pragma unroll
         for (int r = 0; r < NE; ++r) {
             const int e = tid + 64 * r;
-            if (e < nn) { ppl_s[buf][e] = nppl[r]; pmi_s[buf][e] = npmi[r]; }
+            if (FULL || e < nn) { ppl_s[e] = ring[d][r]; pmi_s[e] = ring[d][NE + r]; }
         }
     };
     // the walk of this launch: g-ordinates [ig0, ig0 + ng_launch), continuing from the factors the previous launch left
@@ -260,15 +267,21 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
         for (int e = tid; e < nn; e += 64) fc[e] = pfc[e];
     }
     const long total = (long)p.ng_launch * p.nwave;
-    fetch(0);
-    stage(0);
-    if (total > 1) fetch(1 % p.nwave);
+    int wf = 0;                                                  // wavenumber of the next fetch (wraps around: see below)
+#pragma unroll
+    for (int d = 0; d < D; ++d) { fetch(d, wf); if (++wf == p.nwave) wf = 0; }
     int ig = p.ig0, widx = 0;
-    for (long iter = 0; iter < total; ++iter) {
-        const int buf = (int)(iter & 1);
-        const double *ppl = ppl_s[buf], *pmi = pmi_s[buf];
-        if (iter + 1 < total) stage(buf ^ 1);                   // data of iter+1 (its readers are two syncs away)
-        if (iter + 2 < total) fetch((int)((iter + 2) % p.nwave));
+    for (long iter0 = 0; iter0 < total; iter0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const long iter = iter0 + d;
+        if (iter >= total) break;
+        const double *ppl = ppl_s, *pmi = pmi_s;
+        stage(d);                                               // the previous step's readers are behind this wave's fence
+        // always issued (beyond the end of the walk it re-reads a matrix that is there): a fetch under a condition leaves the
+        // number of loads in flight unknown to the compiler, which then waits for all of them
+        fetch(d, wf);
+        if (++wf == p.nwave) wf = 0;
         MS_WAVE_SYNC();
         double rs = 0.0;
         if (tid < n) {
@@ -305,9 +318,14 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
             MS_WAVE_SYNC();
         }
         double *ofc = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp + comp) * nn;
-        for (int e = tid; e < nn; e += 64) ofc[e] = fc[e];
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {           // a fixed number of stores per step (the waits before the ring's slots count them)
+            const int e = tid + 64 * r;
+            if (FULL || e < nn) ofc[e] = fc[e];
+        }
         if (++widx == p.nwave) { widx = 0; ++ig; }
         MS_WAVE_SYNC();
+    }
     }
 }
 
@@ -647,6 +665,18 @@ struct Ms16 {
         for (int kb = 0; kb < 4; ++kb) s += a[kb] * x[q + 4 * kb];
         return ms_xor32_sum(ms_xor16_sum(s));
     }
+    // |v|_F^2, and the smallest doubles whose (correctly rounded) square root exceeds 0.1 / 0.01: `frob(v) > 0.1` is
+    // `sumsq(v) >= kFrobSq01` without the square root in the chain
+    static constexpr double kFrobSq01 = 0x1.47ae147ae147dp-7, kFrobSq001 = 0x1.a36e2eb1c432fp-14;
+    __device__ __forceinline__ static double sumsq(ms_v4f64 v)
+    {
+        double s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        s += ms_dpp_f64<0x128>(s);
+        s += ms_dpp_f64<0x124>(s);
+        s += ms_dpp_f64<0x122>(s);
+        s += ms_dpp_f64<0x121>(s);
+        return ms_xor32_sum(ms_xor16_sum(s));
+    }
     __device__ __forceinline__ static double frob(ms_v4f64 v)
     {
         double s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
@@ -965,12 +995,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             if (q == 0) j1[c] = jv;
             MS16_FENCE();
             for (int it = 0; it < nd; ++it) {   // add :275-297
-                double aR[4], aT[4], aC[4], aS[4];
+                double aR[4], aT[4], aC[4];
                 L.load_a(r1, aR);
                 L.load_a(t1, aT);                                             // before r1 / t1 serve as scratch
                 const ms_v4f64 bcom = Ms16::mm(aR, bR);                       // r1 r1
+                // rans t1 = (ccom r1) t1 is formed as ccom (r1 t1): r1 t1 needs nothing of the inverse and keeps the matrix
+                // cores busy while it is worked out, and ccom is the only intermediate that has to change layout (one LDS
+                // round trip instead of two).  Same products, other association: the last bits differ from the reference's order.
+                const ms_v4f64 r1t1 = Ms16::mm(aR, bT);                       // r1 t1
                 ms_v4f64 acom;
-                if (Ms16::frob(bR) > 0.1) {                                   // inv(e - bcom)
+                if (Ms16::sumsq(bR) >= Ms16::kFrobSq01) {                     // |r1|_F > 0.1: inv(e - bcom)
                     if (!ms_inv16_series(L, bcom, mA, mB, acom)) {
                         L.store_d(mA, L.eye_plus(bcom, -1.0));
                         MS16_FENCE();
@@ -988,13 +1022,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 }
                 MS16_FENCE();
                 L.load_a(mB, aC);
-                const ms_v4f64 rans = Ms16::mm(aC, bR);                       // ccom r1
-                L.store_d(mA, rans);
                 const ms_v4f64 tans = Ms16::mm(aC, bT);                       // ccom t1
-                MS16_FENCE();
+                const ms_v4f64 acc = Ms16::mm(aC, r1t1);                      // ccom (r1 t1) = rans t1
                 if (ic == 0) jv = L.mv(aC, v0) + jv;                          // ccom jcom + j1
-                L.load_a(mA, aS);
-                const ms_v4f64 acc = Ms16::mm(aS, bT);                        // rans t1
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bR[r] = bR[r] + acc[r];
                 bT = tans;
@@ -1017,14 +1047,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             if (lane < n) jc[lane] = j1[lane];
             MS16_FENCE();
         } else if (iscl == 1) {   // addp, scattering layer :486-511 (rsub,tsub,jsub) = (rc,tc,jc)
-            double aRc[4], aT[4], aC[4], aS[4];
-            const ms_v4f64 bR1 = L.load_d(r1), bT1 = L.load_d(t1), bRc = L.load_d(rc), bTc = L.load_d(tc);
+            double aRc[4], aT[4], aC[4];
+            const ms_v4f64 bR1 = L.load_d(r1), bT1 = L.load_d(t1), bTc = L.load_d(tc);
             const double j1v = j1[c];
             L.load_a(rc, aRc);
             L.load_a(t1, aT);                                                 // before r1 / t1 serve as scratch
             const ms_v4f64 rsq = Ms16::mm(aRc, bR1);                          // rsub r1
+            const ms_v4f64 rst1 = Ms16::mm(aRc, bT1);                         // rsub t1: rans t1 = ccom (rsub t1), as in the doubling
             ms_v4f64 acom;
-            if (Ms16::frob(rsq) > 0.01) {
+            if (Ms16::sumsq(rsq) >= Ms16::kFrobSq001) {                       // |rsq|_F > 0.01
                 if (!ms_inv16_series(L, rsq, mA, mB, acom)) {
                     L.store_d(mA, L.eye_plus(rsq, -1.0));
                     MS16_FENCE();
@@ -1039,13 +1070,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             if (q == 0) v0[c] = jcom;
             MS16_FENCE();
             L.load_a(mB, aC);
-            const ms_v4f64 rans = Ms16::mm(aC, bRc);                          // ccom rsub
-            L.store_d(mA, rans);
             const ms_v4f64 tans = Ms16::mm(aC, bTc);                          // ccom tsub
-            MS16_FENCE();
+            const ms_v4f64 bcomm = Ms16::mm(aC, rst1);                        // ccom (rsub t1) = rans t1
             const double jans = L.mv(aC, v0) + j1v;                           // ccom jcom + j1
-            L.load_a(mA, aS);
-            const ms_v4f64 bcomm = Ms16::mm(aS, bT1);                         // rans t1
             ms_v4f64 rnew;
 #pragma unroll
             for (int r = 0; r < 4; ++r) rnew[r] = bR1[r] + bcomm[r];

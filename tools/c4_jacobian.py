@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--nx", type=int, default=20)
     ap.add_argument("--waves", type=int, default=10000)
     ap.add_argument("--check", action="store_true", help="compare every state with a call of its own (slow)")
+    ap.add_argument("--forward", type=int, default=0, help="only time this many calls of ONE forward model (C4 size)")
     args = ap.parse_args()
     import torch
     import archnemesis_dist_amd as pkg
@@ -57,6 +58,15 @@ def main():
     radg = np.stack([np.repeat((c1 * WAVE ** 3 / (np.exp(c2 * WAVE / lay["TEMP"][m, 0]) - 1.0))[:, None], NMU, 1) for m in range(n)])
     a = (0, lay["PRESS"], lay["TEMP"], lay["amount"], None, rep(TAUDUST), rep(TAURAY), rep(TAUSCAT), ph, rep(np.ones((W, 1, L))), radg,
          [30.0], [20.0], [45.0], np.full(W, 1e-8), 0, np.zeros((W, NMU, NMU, NF + 1)), MU, WT, NF, 101, 1, 1)
+    if args.forward:
+        ts = []
+        for it in range(args.forward):
+            t0 = time.perf_counter()
+            one = eng.cirsrad_ck_scatter(0, lay["PRESS"][0], lay["TEMP"][0], lay["amount"][0], None, TAUDUST, TAURAY, TAUSCAT, ph,
+                                         np.ones((W, 1, L)), radg[0], *a[11:])
+            ts.append(time.perf_counter() - t0)
+        print("one forward model, %d calls: min %.4f median %.4f s   checksum %.17g" % (len(ts), min(ts), float(np.median(ts)), float(one.sum())))
+        return
     for it in range(2):
         t0 = time.perf_counter()
         spec = eng.cirsrad_ck_scatter_batch(*a)
