@@ -608,12 +608,13 @@ static int launch_rt(ansfm_ctx *ctx, const RtParams &p_in, int n_models)
     dim3 grid((unsigned)n_models, (unsigned)p.P, (unsigned)(p.Wpad / kWave));
     if (p.Wpad / kWave > 65535) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: more than 65535 wavenumber tiles (4.19e6 wavenumbers)");
     if (p.LIMAX > 1500) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: at most 1500 layers along a path");
+    if (p.P > 65535) FAIL(ANSFM_ERR_UNSUPPORTED, "thermal RT: at most 65535 paths per call");
     ctx->last_rt_shared = 0;
     // a de-duplicated batch (the states of a numerical Jacobian) in thermal emission: every state starts each path from the
     // record state 0 left after the last layer the two have in common
     static const bool prefix_off = [] { const char *e = getenv("ANSFM_RT_PREFIX"); return e && e[0] == '0'; }();
     const size_t rec = (size_t)p.P * p.LIMAX * 3 * p.G * p.Wpad * sizeof(double);
-    if (!prefix_off && n_models >= 4 && p.tau_slot && p.mode == 0 && !p.emi && !p.per_g && rec <= ((size_t)4 << 30)) {
+    if (!prefix_off && n_models >= 4 && n_models <= 65536 && p.tau_slot && p.mode == 0 && !p.emi && !p.per_g && rec <= ((size_t)4 << 30)) {
         HIPCHK(ctx->rt_prefix.reserve(rec));
         const size_t nl = (size_t)n_models * p.L, np = (size_t)n_models * p.P;
         const size_t off_j = (nl + 15) & ~(size_t)15;
@@ -2904,6 +2905,7 @@ static int layer_average_impl(ansfm_ctx *ctx, int n_models, double RADIUS, int N
     if (LAYINT == 1 && (NINT < 2 || NINT > kLayMaxNint))
         FAIL(ANSFM_ERR_UNSUPPORTED, "layer_average: NINT must be in [2,256]");
     if (5 + 2 * NVMR + NDUST > 160) FAIL(ANSFM_ERR_UNSUPPORTED, "layer_average: 5 + 2*NVMR + NDUST <= 160");
+    if (n_models > 65535) FAIL(ANSFM_ERR_UNSUPPORTED, "layer_average: at most 65535 states per call");
     if (DUST_UNITS && !XMOLWT)
         for (int j = 0; j < NDUST; ++j)
             if (DUST_UNITS[j] == -1) FAIL(ANSFM_ERR_INVALID, "if DUST_UNITS=-1 (particles per gram of atm), the XMOLWT must be defined");
