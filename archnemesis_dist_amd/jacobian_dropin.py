@@ -19,7 +19,9 @@ override keeps the method's signature, state-vector arithmetic (:2234-2242), NUM
              to the GPU as ONE batched call (layers bit-identical to the unperturbed state's are not recomputed,
              DESIGN.md 4.1d); the second half of nemesisfm (FOV weights, convolution, subspecret, :531-587) then runs
              per state.  read_tables runs once per geometry instead of once per forward model.
-  "loop"     everything else (nemesisSO / L / C / disc / PT variants, line-by-line runtime, Telluric, a CIRSrad branch
+             With nemesisL = True the same is done for nemesisLfm (:1254-1368: all tangent paths of a state in one CIRSrad
+             call, then the interpolation to the measurement's tangent heights and the convolution over all geometries).
+  "loop"     everything else (nemesisSO / C / disc / PT variants, line-by-line runtime, Telluric, a CIRSrad branch
              that has no batch axis): the reference's `execute_fm` (:2121) per column, in this process, one after the
              other -- never joblib workers on one GPU.  NCores > 1 is noted once (RuntimeWarning) and not used.
 
@@ -99,6 +101,9 @@ class JacobianGPU:
             routes.append(("profile", self._ansfm_profile_route))
         if plain and want in ("auto", "staged"):
             routes.append(("staged", self._ansfm_staged_route))
+        limb_only = bool(flags["nemesisL"]) and not any(v for k, v in flags.items() if k != "nemesisL")
+        if limb_only and want in ("auto", "staged"):
+            routes.append(("staged", self._ansfm_staged_limb_route))
         if want not in ("auto", "loop") and not routes:
             raise ValueError("jacobian_nemesis: route %r is not available for these flags" % (want,))
         for name, fn in routes:
@@ -237,6 +242,103 @@ class JacobianGPU:
             V.XN = xnx[:, col]
             dS = np.zeros((int(M.NCONV.max()), int(M.NGEOM), int(V.NX)))
             SP, _ = self.subspecret(SPECONV[k], dS)                                 # :585-587
+            ik = 0
+            for ig in range(M.NGEOM):                                               # execute_fm :2171-2174
+                nc = int(M.NCONV[ig])
+                Y[ik:ik + nc, ifm] = SP[0:nc, ig]
+                ik += nc
+        info["rows"] = (int(rows_c), int(rows_t))
+        if world > 1:
+            Y = self._ansfm_gather(Y, s, e, nfm, rank, world, group)
+        return Y
+
+    # ---- "staged" for nemesisL: nemesisLfm's host code per state, ONE batched CIRSrad for all states ------------------------
+    @staticmethod
+    def _ansfm_limb_to_tangent_heights(SPECOUT, BASEH_TANHE, TANHE):
+        """nemesisLfm :1322-1344: the spectra of the NPATH tangent paths (one per layer base, km) brought to the tangent
+        heights of the measurement by linear weights between the two neighbouring paths.  The reference's arithmetic is kept as
+        it stands: the nearest base is divided by 1e3 a second time before it is compared with the tangent height (:1328), the
+        weights are (1 - fhl) and (1 - fhh), a lower neighbour of -1 wraps to the last path as a Python index does, and above
+        the top path the lower neighbour's spectrum is taken."""
+        NPATH = BASEH_TANHE.size
+        out = np.zeros((SPECOUT.shape[0], len(TANHE)))
+        for i in range(len(TANHE)):
+            t = TANHE[i]
+            near = int(np.argmin(np.abs(BASEH_TANHE - t)))
+            lo, hi = (near, near + 1) if BASEH_TANHE[near] / 1.0e3 <= t else (near - 1, near)
+            if hi > NPATH - 1:
+                out[:, i] = SPECOUT[:, lo]
+            else:
+                span = BASEH_TANHE[hi] - BASEH_TANHE[lo]
+                fhl, fhh = (t - BASEH_TANHE[lo]) / span, (BASEH_TANHE[hi] - t) / span
+                out[:, i] = SPECOUT[:, lo] * (1. - fhl) + SPECOUT[:, hi] * (1. - fhh)
+        return out
+
+    def _ansfm_staged_limb_route(self, xnx, ixrun, info):
+        """jacobian_nemesis(nemesisL=True): every forward model is nemesisLfm (:1254-1368) -- all tangent paths of a state in one
+        CIRSrad call.  Its host code runs per state as the reference wrote it (deep copies, subprofretg with the hydrostatic
+        re-adjustment off, calc_path_L), the CIRSrad calls of all states become one batched engine call (NPATH paths each), then
+        the interpolation to the measurement's tangent heights, the convolution over all geometries and subspecret per state."""
+        if not self._ansfm_staged_supported(info):
+            return None
+        M, V = self.Measurement, self.Variables
+        nfm = len(ixrun)
+        rank, world, group = self.ansfm_jacobian_group or (0, 1, None)
+        s, e = chunk_range(nfm, world, rank)
+        owners = list(range(s, e))
+        if not owners:
+            return self._ansfm_gather(np.zeros((int(M.NY), nfm)), s, e, nfm, rank, world, group) if world > 1 else np.zeros((int(M.NY), nfm))
+        cols = [int(ixrun[i]) for i in owners]
+        if cols[0] != 0:                           # the unperturbed state leads the batch (see _ansfm_staged_route)
+            cols, owners = [0] + cols, [None] + owners
+        eng = _fm.get_engine(self.ansfm_device)
+        self.check_gas_spec_atm()                                                   # :1294-1295
+        self.check_wave_range_consistency()
+        M.build_ils(IGEOM=0)                                                        # :1298-1303, once: no state changes them
+        wmin, wmax = M.calc_wave_range(apply_doppler=True, IGEOM=None)
+        self.SpectroscopyX = deepcopy(self.Spectroscopy)
+        if self.SpectroscopyX.NGAS > 0:
+            self.SpectroscopyX.read_tables(wavemin=wmin, wavemax=wmax)
+        W = int(self.SpectroscopyX.NWAVE)
+        recs, kept = [], []
+        for col in cols:
+            V.XN = xnx[:, col]                                                      # execute_fm :2154
+            self.Variables1 = deepcopy(self.Variables)                              # :1283-1291
+            for name in ("Measurement", "Atmosphere", "Scatter", "Stellar", "Surface", "Layer", "CIA"):
+                setattr(self, name + "X", deepcopy(getattr(self, name)))
+            self.adjust_hydrostat = False                                           # :1306
+            self.subprofretg()
+            self.LayerX.DUST_UNITS_FLAG = self.AtmosphereX.DUST_UNITS_FLAG
+            self.calc_path_L()
+            P, L = self.PathX, self.LayerX
+            NPATH = int(P.NPATH)
+            base_km = np.array([L.BASEH[P.LAYINC[int(P.NLAYIN[i] / 2), i]] / 1.0e3 for i in range(NPATH)])    # :1314-1316
+            rec = self._ansfm_thermal_inputs()
+            if rec is None:
+                rec = self._ansfm_scatter_inputs()
+            if rec is None:
+                rec = dict(alone=self.CIRSrad())
+            recs.append(rec)
+            kept.append((self.MeasurementX, base_km))
+        spectra, rows_c, rows_t = self._ansfm_run_batches(eng, recs, W)
+        Y = np.zeros((int(M.NY), nfm))
+        S = self.SpectroscopyX
+        for k, (col, ifm) in enumerate(zip(cols, owners)):
+            if ifm is None:
+                continue
+            MX, base_km = kept[k]
+            self.MeasurementX = MX
+            V.XN = xnx[:, col]
+            SPECMOD = self._ansfm_limb_to_tangent_heights(np.asarray(spectra[k]).reshape(W, -1), base_km,
+                                                          [MX.TANHE[i] for i in range(int(MX.NGEOM))])
+            if int(MX.IFORM) == IFORM_INTEGRATED_RADIANCE:                          # :1348-1361
+                SPECONV = MX.integrate_filter(S.WAVE, SPECMOD, IGEOM='All')
+            elif int(S.ILBL) == _fm.ILBL_K_TABLES:
+                SPECONV = MX.conv(S.WAVE, SPECMOD, IGEOM='All')
+            else:
+                SPECONV = MX.lblconv(S.WAVE, SPECMOD, IGEOM='All')
+            dS = np.zeros((int(MX.NCONV.max()), int(MX.NGEOM), int(V.NX)))
+            SP, _ = self.subspecret(SPECONV, dS)                                    # :1366
             ik = 0
             for ig in range(M.NGEOM):                                               # execute_fm :2171-2174
                 nc = int(M.NCONV[ig])

@@ -337,6 +337,72 @@ def test_routes_agree_on_a_limb_geometry(c1_cut):
 
 @pytest.mark.needs_reference
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_limb_forward_model_jacobian_staged_equals_the_reference_loop(c1_cut):
+    """jacobian_nemesis(nemesisL=True): every forward model is the reference's nemesisLfm (all tangent paths of a state in one
+    CIRSrad call, interpolation to the three tangent heights of the measurement, convolution over all geometries).  The
+    staged route -- nemesisLfm's host code per state, ONE batched engine call with NPATH paths per state -- against the loop
+    route, which IS the reference's execute_fm / nemesisLfm per column: the same YN and KK to the last bit."""
+    ans, gj, fmod, double = c1_cut
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    free = (20, 45, 70)
+    res = {}
+    for route in ("auto", "loop"):
+        fm = gj.cut_case(ans, cls=FMGPU, nkeep=10, free=free)
+        M = fm.Measurement
+        n0, ng = 10, 3
+        rep = lambda a: np.repeat(np.asarray(a)[:n0, 0:1], ng, axis=1)
+        M.NGEOM = ng
+        M.NCONV = np.array([n0] * ng, dtype="int32")
+        M.NAV = np.ones(ng, dtype="int32")
+        M.VCONV = rep(M.VCONV); M.MEAS = rep(M.MEAS); M.ERRMEAS = rep(M.ERRMEAS)
+        z = np.zeros((ng, 1))
+        M.FLAT, M.FLON, M.AZI_ANG = z.copy(), z.copy(), z.copy()
+        M.SOL_ANG = np.full((ng, 1), 60.0)
+        M.EMISS_ANG = np.full((ng, 1), -1.0)
+        M.TANHE = np.array([[40.0], [80.0], [130.0]])
+        M.WGEOM = np.ones((ng, 1))
+        M.NY = n0 * ng
+        fm.ansfm_jacobian_route = route
+        double.batch_sizes = []
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            YN, KK = fm.jacobian_nemesis(NCores=1, nemesisL=True, analytical_gradient=False)
+        info = fm.ansfm_last_jacobian
+        assert info["route"] == ("staged" if route == "auto" else "loop") and info["nfm"] == 4
+        res[route] = (YN, KK, list(double.batch_sizes))
+    assert np.array_equal(res["auto"][0], res["loop"][0]) and np.array_equal(res["auto"][1], res["loop"][1])
+    assert res["auto"][2] == [4] and res["loop"][2] == []                        # one batched call of four states / none
+    for ix in free:
+        assert np.abs(res["auto"][1][:, ix]).max() > 0
+    assert not np.array_equal(res["auto"][0][:10], res["auto"][0][10:20])         # the tangent heights see different spectra
+
+
+def test_limb_spectra_are_brought_to_the_tangent_heights_as_the_reference_does():
+    """nemesisLfm :1322-1344 restated (JacobianGPU._ansfm_limb_to_tangent_heights): weights between the neighbouring tangent
+    paths, the nearest base compared after a second division by 1e3, the lower neighbour -1 wrapping to the last path, the
+    lower neighbour's spectrum above the top path."""
+    from archnemesis_dist_amd.jacobian_dropin import JacobianGPU
+    f = JacobianGPU._ansfm_limb_to_tangent_heights
+    base = np.array([0.0, 10.0, 25.0, 45.0])                       # km, one tangent path per layer base
+    S = np.arange(12, dtype=float).reshape(3, 4) + 1.0
+    out = f(S, base, [np.array([12.0]), np.array([60.0]), np.array([10.0])])
+    # 12 km: nearest base 10 km; 10 / 1e3 <= 12 -> between paths 1 and 2
+    fhl, fhh = (12.0 - 10.0) / 15.0, (25.0 - 12.0) / 15.0
+    np.testing.assert_array_equal(out[:, 0], S[:, 1] * (1 - fhl) + S[:, 2] * (1 - fhh))
+    # 60 km: nearest base is the top path, its upper neighbour does not exist -> the top path's spectrum
+    np.testing.assert_array_equal(out[:, 1], S[:, 3])
+    # exactly on a base
+    np.testing.assert_array_equal(out[:, 2], S[:, 1] * 1.0 + S[:, 2] * 0.0)
+    # a tangent height below every base: nearest is path 0, 0 / 1e3 <= -5 fails -> neighbours (-1, 0): path -1 is the LAST path
+    out = f(S, base, [np.array([-5.0])])
+    span = base[0] - base[-1]
+    fhl, fhh = (-5.0 - base[-1]) / span, (base[0] + 5.0) / span
+    np.testing.assert_array_equal(out[:, 0], S[:, -1] * (1 - fhl) + S[:, 0] * (1 - fhh))
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
 def test_routes_agree_with_a_gas_profile_carried_as_logarithm(c1_cut):
     """A second model-0 variable, the NH3 mixing-ratio profile: read_apr carries it as ln(vmr) (LX = 1; model_0.py
     from_apr_to_state_vector), subprofretg un-logs it.  State vector of 162 elements, two temperature levels and two ln(vmr)
