@@ -20,8 +20,9 @@ override keeps the method's signature, state-vector arithmetic (:2234-2242), NUM
              DESIGN.md 4.1d); the second half of nemesisfm (FOV weights, convolution, subspecret, :531-587) then runs
              per state.  read_tables runs once per geometry instead of once per forward model.
              With nemesisL = True the same is done for nemesisLfm (:1254-1368: all tangent paths of a state in one CIRSrad
-             call, then the interpolation to the measurement's tangent heights and the convolution over all geometries).
-  "loop"     everything else (nemesisSO / C / disc / PT variants, line-by-line runtime, Telluric, a CIRSrad branch
+             call, then the interpolation to the measurement's tangent heights and the convolution over all geometries), with
+             nemesisSO = True for nemesisSOfm's plain branch (:909-978: calc_path_SO, CIRSrad's transmission branch).
+  "loop"     everything else (nemesisC / disc / PT variants, AOTF orders in nemesisSOfm, line-by-line runtime, Telluric, a CIRSrad branch
              that has no batch axis): the reference's `execute_fm` (:2121) per column, in this process, one after the
              other -- never joblib workers on one GPU.  NCores > 1 is noted once (RuntimeWarning) and not used.
 
@@ -101,9 +102,9 @@ class JacobianGPU:
             routes.append(("profile", self._ansfm_profile_route))
         if plain and want in ("auto", "staged"):
             routes.append(("staged", self._ansfm_staged_route))
-        limb_only = bool(flags["nemesisL"]) and not any(v for k, v in flags.items() if k != "nemesisL")
-        if limb_only and want in ("auto", "staged"):
-            routes.append(("staged", self._ansfm_staged_limb_route))
+        for flag, kind in (("nemesisL", "L"), ("nemesisSO", "SO")):
+            if bool(flags[flag]) and not any(v for k, v in flags.items() if k != flag) and want in ("auto", "staged"):
+                routes.append(("staged", lambda xnx, ixrun, info, kind=kind: self._ansfm_staged_limb_route(xnx, ixrun, info, kind)))
         if want not in ("auto", "loop") and not routes:
             raise ValueError("jacobian_nemesis: route %r is not available for these flags" % (want,))
         for name, fn in routes:
@@ -274,12 +275,17 @@ class JacobianGPU:
                 out[:, i] = SPECOUT[:, lo] * (1. - fhl) + SPECOUT[:, hi] * (1. - fhh)
         return out
 
-    def _ansfm_staged_limb_route(self, xnx, ixrun, info):
+    def _ansfm_staged_limb_route(self, xnx, ixrun, info, kind="L"):
         """jacobian_nemesis(nemesisL=True): every forward model is nemesisLfm (:1254-1368) -- all tangent paths of a state in one
         CIRSrad call.  Its host code runs per state as the reference wrote it (deep copies, subprofretg with the hydrostatic
         re-adjustment off, calc_path_L), the CIRSrad calls of all states become one batched engine call (NPATH paths each), then
-        the interpolation to the measurement's tangent heights, the convolution over all geometries and subspecret per state."""
+        the interpolation to the measurement's tangent heights, the convolution over all geometries and subspecret per state.
+        kind = "SO" (nemesisSO=True): nemesisSOfm's plain branch (:909-978) has the same shape with calc_path_SO and CIRSrad's
+        transmission branch; its AOTF branch (a forward model per diffraction order, :824-907) stays with the loop route."""
         if not self._ansfm_staged_supported(info):
+            return None
+        if kind == "SO" and getattr(self.Measurement, "NORDERS_AOTF", None) is not None:
+            info["why_not_staged"] = "AOTF diffraction orders"
             return None
         M, V = self.Measurement, self.Variables
         nfm = len(ixrun)
@@ -309,11 +315,16 @@ class JacobianGPU:
             self.adjust_hydrostat = False                                           # :1306
             self.subprofretg()
             self.LayerX.DUST_UNITS_FLAG = self.AtmosphereX.DUST_UNITS_FLAG
-            self.calc_path_L()
+            if kind == "SO":
+                self.calc_path_SO()
+            else:
+                self.calc_path_L()
             P, L = self.PathX, self.LayerX
             NPATH = int(P.NPATH)
             base_km = np.array([L.BASEH[P.LAYINC[int(P.NLAYIN[i] / 2), i]] / 1.0e3 for i in range(NPATH)])    # :1314-1316
-            rec = self._ansfm_thermal_inputs()
+            rec = self._ansfm_transmission_inputs()
+            if rec is None:
+                rec = self._ansfm_thermal_inputs()
             if rec is None:
                 rec = self._ansfm_scatter_inputs()
             if rec is None:
@@ -331,7 +342,7 @@ class JacobianGPU:
             V.XN = xnx[:, col]
             SPECMOD = self._ansfm_limb_to_tangent_heights(np.asarray(spectra[k]).reshape(W, -1), base_km,
                                                           [MX.TANHE[i] for i in range(int(MX.NGEOM))])
-            if int(MX.IFORM) == IFORM_INTEGRATED_RADIANCE:                          # :1348-1361
+            if kind == "L" and int(MX.IFORM) == IFORM_INTEGRATED_RADIANCE:          # :1348-1361 (nemesisSOfm has no filter branch)
                 SPECONV = MX.integrate_filter(S.WAVE, SPECMOD, IGEOM='All')
             elif int(S.ILBL) == _fm.ILBL_K_TABLES:
                 SPECONV = MX.conv(S.WAVE, SPECMOD, IGEOM='All')
@@ -387,6 +398,32 @@ class JacobianGPU:
             TSURF=float(self.SurfaceX.TSURF), emissivity=emissivity, xfac=xfac,
             SOL_ANG=np.asarray(P.SOL_ANG, dtype=np.float64).reshape(NPATH), EMISS_ANG=np.asarray(P.EMISS_ANG, dtype=np.float64).reshape(NPATH))
 
+    def _ansfm_transmission_inputs(self):
+        """What CIRSrad's pure-transmission branch (:4478-4483, calculate_transmission_spectrum :4110) hands to the engine, kept
+        instead of run; None when the staged state takes another branch."""
+        if not self._ansfm_supported(False):
+            return None
+        P, L, S = self.PathX, self.LayerX, self.SpectroscopyX
+        imod = int(np.unique(np.asarray(P.IMOD).astype(int))[0])
+        if not self._ansfm_transmission_branch(imod):
+            return None
+        TAUCIA, TAUDUST, TAURAY, _ = self._ansfm_continuum(False)
+        xf = None
+        if int(self.MeasurementX.IFORM) == _fm.IFORM_ATMOSPHERIC_TRANSMISSION:     # :4119-4127: times the solar flux
+            import scipy.interpolate
+            self.StellarX.calc_solar_flux()
+            xf = scipy.interpolate.interp1d(self.StellarX.WAVE, self.StellarX.SOLFLUX)(S.WAVE)
+        NPATH = np.asarray(P.LAYINC).shape[1]
+        return dict(transmission=True, lp=np.array(L.PRESS, dtype=np.float64), lt=np.array(L.TEMP, dtype=np.float64),
+                    f_gas=self._ansfm_layer_inputs(), taucont=TAUCIA + TAUDUST + TAURAY,
+                    NLAYIN=np.asarray(P.NLAYIN, dtype=np.int32).reshape(NPATH), LAYINC=np.asarray(P.LAYINC, dtype=np.int32).reshape(-1, NPATH),
+                    SCALE=np.asarray(P.SCALE, dtype=np.float64).reshape(-1, NPATH), xfac=xf)
+
+    @staticmethod
+    def _ansfm_transmission_key(r):
+        opt = lambda a: b"-" if a is None else np.ascontiguousarray(a, dtype=np.float64).tobytes()
+        return ("transmission", r["lp"].shape, r["LAYINC"].shape, r["NLAYIN"].tobytes(), r["LAYINC"].tobytes(), opt(r["xfac"]))
+
     def _ansfm_scatter_inputs(self):
         """What CIRSrad's multiple-scattering branch hands to the engine (CIRSradGPU._ansfm_cirsrad_scatter), kept instead of
         run; None when the staged state is not on that branch."""
@@ -424,6 +461,8 @@ class JacobianGPU:
                 out[k] = np.asarray(r["alone"]).reshape(W, -1)
             elif r.get("scatter"):
                 groups.setdefault(self._ansfm_scatter_key(r), []).append(k)
+            elif r.get("transmission"):
+                groups.setdefault(self._ansfm_transmission_key(r), []).append(k)
             else:
                 groups.setdefault(self._ansfm_batch_key(r), []).append(k)
         self._ansfm_upload_table(eng)
@@ -442,6 +481,16 @@ class JacobianGPU:
                     a, b = eng.last_scatter_cache()           # layers of models 1.. taken from model 0's doublings / all of them
                     nlay = int(r0["lp"].shape[0])
                     rc += (b - a) + nlay; rt += b + nlay
+                for j, k in enumerate(ks):
+                    out[k] = spec[j]
+                continue
+            if key[0] == "transmission":
+                spec = eng.cirsrad_ck_transmission(st("lp"), st("lt"), st("f_gas"), st("taucont"), r0["NLAYIN"], r0["LAYINC"],
+                                                   st("SCALE"), xfac=r0["xfac"])
+                spec = np.asarray(spec).reshape(len(ks), W, -1)
+                if hasattr(eng, "last_layer_rows"):
+                    a, b = eng.last_layer_rows()
+                    rc += a; rt += b
                 for j, k in enumerate(ks):
                     out[k] = spec[j]
                 continue

@@ -126,6 +126,12 @@ class OracleEngineDouble:
         return sg, dk, np.asarray(D, dtype=float)
 
     def cirsrad_ck_transmission(self, lp, lt, am, taucont, NLAYIN, LAYINC, SCALE, xfac=None):
+        if np.ndim(lp) == 2:                         # leading model axis (the engine's batched call): one model at a time
+            n = np.shape(lp)[0]
+            self.batch_sizes = getattr(self, "batch_sizes", []) + [n]
+            sc = np.asarray(SCALE)
+            return np.stack([self.cirsrad_ck_transmission(lp[i], lt[i], am[i], None if taucont is None else np.asarray(taucont)[i],
+                                                          NLAYIN, LAYINC, sc[i] if sc.ndim == 3 else sc, xfac=xfac) for i in range(n)])
         self.tr_calls = getattr(self, "tr_calls", 0) + 1
         sg, _, D = self._transmission(lp, lt, am, taucont, NLAYIN, LAYINC, SCALE, xfac)
         return np.tensordot(sg, D, axes=([1], [0]))

@@ -337,11 +337,13 @@ def test_routes_agree_on_a_limb_geometry(c1_cut):
 
 @pytest.mark.needs_reference
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
-def test_limb_forward_model_jacobian_staged_equals_the_reference_loop(c1_cut):
+@pytest.mark.parametrize("flag", ["nemesisL", "nemesisSO"])
+def test_limb_forward_model_jacobian_staged_equals_the_reference_loop(c1_cut, flag):
     """jacobian_nemesis(nemesisL=True): every forward model is the reference's nemesisLfm (all tangent paths of a state in one
     CIRSrad call, interpolation to the three tangent heights of the measurement, convolution over all geometries).  The
     staged route -- nemesisLfm's host code per state, ONE batched engine call with NPATH paths per state -- against the loop
-    route, which IS the reference's execute_fm / nemesisLfm per column: the same YN and KK to the last bit."""
+    route, which IS the reference's execute_fm / nemesisLfm per column: the same YN and KK to the last bit.  nemesisSO=True:
+    the same for nemesisSOfm (solar occultation: calc_path_SO, CIRSrad's transmission branch)."""
     ans, gj, fmod, double = c1_cut
     FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
     free = (20, 45, 70)
@@ -367,7 +369,7 @@ def test_limb_forward_model_jacobian_staged_equals_the_reference_loop(c1_cut):
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            YN, KK = fm.jacobian_nemesis(NCores=1, nemesisL=True, analytical_gradient=False)
+            YN, KK = fm.jacobian_nemesis(NCores=1, analytical_gradient=False, **{flag: True})
         info = fm.ansfm_last_jacobian
         assert info["route"] == ("staged" if route == "auto" else "loop") and info["nfm"] == 4
         res[route] = (YN, KK, list(double.batch_sizes))
