@@ -1573,6 +1573,19 @@ def test_cirsrad_transmission_vs_oracle(eng, oracle):
         path = np.sum(tautot[:, :, LAYINC] * SCALE, axis=2)                         # TAUTOT_PATH (:4006-4009)
         ref = np.tensordot(np.exp(-path) * solflux[:, None, None], delg, axes=([1], [0]))
         np.testing.assert_allclose(got[m], ref, rtol=1e-11)
+    # the states of a solar-occultation Jacobian (jacobian_nemesis(nemesisSO=True), staged route): six states, four of them one
+    # layer away from the first -- the batch build of the RT kernel, shared opacity rows; every state equals its own call
+    n = 6
+    lp6 = np.repeat(lp[:1], n, 0); lt6 = np.repeat(lt[:1], n, 0); am6 = np.repeat(am[:1], n, 0); cont6 = np.repeat(cont[:1], n, 0)
+    lt6[1, 3] *= 1.02; am6[2, 1, 7] *= 1.05; cont6[3, :, 5] *= 1.01; lp6[4, 9] *= 1.001
+    SC6 = np.repeat(SCALE[None], n, 0); SC6[5, 2, 0] *= 1.01
+    batch = eng.cirsrad_ck_transmission(lp6, lt6, am6, cont6, NLAYIN, LAYINC, SC6, xfac=solflux)
+    rows, total = eng.last_layer_rows()
+    assert total == n * L and rows < total
+    for m in range(n):
+        one = eng.cirsrad_ck_transmission(lp6[m], lt6[m], am6[m], cont6[m], NLAYIN, LAYINC, SC6[m], xfac=solflux)
+        assert np.array_equal(batch[m], one), m
+    assert not any(np.array_equal(batch[m], batch[0]) for m in range(1, n))
 
 
 def test_cirsradg_transmission_vs_oracle(eng, oracle):
