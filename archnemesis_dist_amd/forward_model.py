@@ -27,6 +27,7 @@ IMOD_DOWNWARD_FLUX = 16
 IMOD_SINGLE_SCATTERING_PLANE_PARALLEL = 1024
 IMOD_ABSORBTION = 4096
 IFORM_FLUXRATIO = 1                    # SpectraUnitEnum.FluxRatio
+IFORM_TRANSIT_DEPTH = 2                # SpectraUnitEnum.TransitDepth
 IFORM_ATMOSPHERIC_TRANSMISSION = 4     # SpectraUnitEnum.Atmospheric_transmission
 ATM_TO_PASCAL = 101325.0               # ForwardModel_0.py:61
 SQ_CM_TO_SQ_METER = 1.0e-4             # ForwardModel_0.py:66

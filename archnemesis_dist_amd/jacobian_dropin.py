@@ -22,7 +22,10 @@ override keeps the method's signature, state-vector arithmetic (:2234-2242), NUM
              With nemesisL = True the same is done for nemesisLfm (:1254-1368: all tangent paths of a state in one CIRSrad
              call, then the interpolation to the measurement's tangent heights and the convolution over all geometries), with
              nemesisSO = True for nemesisSOfm's plain branch (:909-978: calc_path_SO, CIRSrad's transmission branch).
-  "loop"     everything else (nemesisC / disc / PT variants, AOTF orders in nemesisSOfm, line-by-line runtime, Telluric, a CIRSrad branch
+             nemesisdisc = True: nemesisdiscfm (:1609-1716) is nemesisfm with process_IAV per averaging point: same route.
+             nemesisC = True: nemesisCfm (:1526-1604; several viewing angles in one multiple-scattering call per state).
+             nemesisPT = True: nemesisPTfm (:1838-1995; the transit depth from the transmission of the tangent paths).
+  "loop"     everything else (AOTF orders in nemesisSOfm, line-by-line runtime, Telluric, a CIRSrad branch
              that has no batch axis): the reference's `execute_fm` (:2121) per column, in this process, one after the
              other -- never joblib workers on one GPU.  NCores > 1 is noted once (RuntimeWarning) and not used.
 
@@ -102,7 +105,9 @@ class JacobianGPU:
             routes.append(("profile", self._ansfm_profile_route))
         if plain and want in ("auto", "staged"):
             routes.append(("staged", self._ansfm_staged_route))
-        for flag, kind in (("nemesisL", "L"), ("nemesisSO", "SO")):
+        if bool(flags["nemesisdisc"]) and not any(v for k, v in flags.items() if k != "nemesisdisc") and want in ("auto", "staged"):
+            routes.append(("staged", lambda xnx, ixrun, info: self._ansfm_staged_route(xnx, ixrun, info, disc=True)))
+        for flag, kind in (("nemesisL", "L"), ("nemesisSO", "SO"), ("nemesisC", "C"), ("nemesisPT", "PT")):
             if bool(flags[flag]) and not any(v for k, v in flags.items() if k != flag) and want in ("auto", "staged"):
                 routes.append(("staged", lambda xnx, ixrun, info, kind=kind: self._ansfm_staged_limb_route(xnx, ixrun, info, kind)))
         if want not in ("auto", "loop") and not routes:
@@ -183,7 +188,11 @@ class JacobianGPU:
         self.LayerX.DUST_UNITS_FLAG = self.AtmosphereX.DUST_UNITS_FLAG
         self.calc_path()
 
-    def _ansfm_staged_route(self, xnx, ixrun, info):
+    def _ansfm_staged_route(self, xnx, ixrun, info, disc=False):
+        """nemesisfm per state up to CIRSrad, one batched call per (geometry, averaging point), the rest per state.  disc = True
+        (jacobian_nemesis(nemesisdisc=True)): nemesisdiscfm (:1609-1716) is the same forward model with the averaging points
+        of a geometry run through process_IAV (:1998: the very stage nemesisfm has inline; joblib workers over the points in
+        the reference, one batched call here), their weighted sum taken at once, and no filter-integral branch."""
         if not self._ansfm_staged_supported(info):
             return None
         M, V = self.Measurement, self.Variables
@@ -235,7 +244,7 @@ class JacobianGPU:
                 for k, sp in enumerate(spectra):                                    # :531 (NAV >= 1 inside this loop)
                     SPEC[k] += M.WGEOM[IGEOM, IAV] * sp[:, 0]
             for k in range(len(states)):
-                SPECONV[k, 0:int(M.NCONV[IGEOM]), IGEOM] = self._ansfm_convolve(SPEC[k], IGEOM)
+                SPECONV[k, 0:int(M.NCONV[IGEOM]), IGEOM] = self._ansfm_convolve(SPEC[k], IGEOM, disc)
         Y = np.zeros((int(M.NY), nfm))
         for k, (col, ifm) in enumerate(zip(states, owners)):
             if ifm is None:
@@ -275,17 +284,40 @@ class JacobianGPU:
                 out[:, i] = SPECOUT[:, lo] * (1. - fhl) + SPECOUT[:, hi] * (1. - fhh)
         return out
 
+    @staticmethod
+    def _ansfm_transit_depth(SPECOUT, base_km, r_star_km, r_planet_m, ngeom):
+        """nemesisPTfm :1931-1950 (gradients = False): SPECOUT (NWAVE, NPATH) the transmission of the tangent paths, base_km
+        their tangent heights.  Absorbing annuli (1 - T) 2 pi (h + R) integrated over height by trapezoids, path after path
+        in the reference's order, plus the disc below the lowest tangent height, over the stellar disc, in per cent."""
+        area_star = np.pi * ((r_star_km * 1.0e3) ** 2)
+        area_disc = np.pi * ((r_planet_m + base_km[0] * 1.0e3) ** 2)
+        out = np.zeros((SPECOUT.shape[0], ngeom))
+        for i in range(len(base_km) - 1):
+            lower = (1. - SPECOUT[:, i]) * 2. * np.pi * (base_km[i] * 1.0e3 + r_planet_m)
+            upper = (1. - SPECOUT[:, i + 1]) * 2. * np.pi * (base_km[i + 1] * 1.0e3 + r_planet_m)
+            out[:, 0] += 0.5 * (lower + upper) * ((base_km[i + 1] - base_km[i]) * 1.0e3)
+        return (out + area_disc) / area_star * 100.
+
     def _ansfm_staged_limb_route(self, xnx, ixrun, info, kind="L"):
         """jacobian_nemesis(nemesisL=True): every forward model is nemesisLfm (:1254-1368) -- all tangent paths of a state in one
         CIRSrad call.  Its host code runs per state as the reference wrote it (deep copies, subprofretg with the hydrostatic
         re-adjustment off, calc_path_L), the CIRSrad calls of all states become one batched engine call (NPATH paths each), then
         the interpolation to the measurement's tangent heights, the convolution over all geometries and subspecret per state.
         kind = "SO" (nemesisSO=True): nemesisSOfm's plain branch (:909-978) has the same shape with calc_path_SO and CIRSrad's
-        transmission branch; its AOTF branch (a forward model per diffraction order, :824-907) stays with the loop route."""
+        transmission branch; its AOTF branch (a forward model per diffraction order, :824-907) stays with the loop route.
+        kind = "C" (nemesisC=True): nemesisCfm (:1526-1604) -- an instrument looking up or down at several viewing angles, one
+        path per geometry in ONE multiple-scattering CIRSrad call per state: hydrostatic re-adjustment on, calc_path_C, then
+        subspecret on the unconvolved spectra and convg / lblconv over all geometries.
+        kind = "PT" (nemesisPT=True): nemesisPTfm (:1838-1995, gradients = False) -- a primary transit: calc_path_PT, the
+        transmission of every tangent path in one CIRSrad call per state, then the absorbing area integrated over the tangent
+        heights (trapezoids of (1 - T) 2 pi r), the planet's disc added, over the star's area, in per cent."""
         if not self._ansfm_staged_supported(info):
             return None
         if kind == "SO" and getattr(self.Measurement, "NORDERS_AOTF", None) is not None:
             info["why_not_staged"] = "AOTF diffraction orders"
+            return None
+        if kind == "PT" and (int(self.Measurement.IFORM) != _fm.IFORM_TRANSIT_DEPTH or int(self.Measurement.NGEOM) != 1):
+            info["why_not_staged"] = "nemesisPTfm refuses this measurement"         # :1876-1880: let its own code say so
             return None
         M, V = self.Measurement, self.Variables
         nfm = len(ixrun)
@@ -312,16 +344,23 @@ class JacobianGPU:
             self.Variables1 = deepcopy(self.Variables)                              # :1283-1291
             for name in ("Measurement", "Atmosphere", "Scatter", "Stellar", "Surface", "Layer", "CIA"):
                 setattr(self, name + "X", deepcopy(getattr(self, name)))
-            self.adjust_hydrostat = False                                           # :1306
+            self.adjust_hydrostat = kind in ("C", "PT")                             # :1306 / :1576 / :1893
             self.subprofretg()
-            self.LayerX.DUST_UNITS_FLAG = self.AtmosphereX.DUST_UNITS_FLAG
-            if kind == "SO":
-                self.calc_path_SO()
+            base_km = None
+            if kind == "C":
+                MX, SX = self.MeasurementX, self.ScatterX                           # :1582-1587
+                SX.SOL_ANG, SX.EMISS_ANG, SX.AZI_ANG = MX.SOL_ANG[0, 0], MX.EMISS_ANG[0, 0], MX.AZI_ANG[0, 0]
+                self.calc_path_C()
             else:
-                self.calc_path_L()
-            P, L = self.PathX, self.LayerX
-            NPATH = int(P.NPATH)
-            base_km = np.array([L.BASEH[P.LAYINC[int(P.NLAYIN[i] / 2), i]] / 1.0e3 for i in range(NPATH)])    # :1314-1316
+                self.LayerX.DUST_UNITS_FLAG = self.AtmosphereX.DUST_UNITS_FLAG
+                if kind == "SO":
+                    self.calc_path_SO()
+                elif kind == "PT":
+                    self.calc_path_PT()
+                else:
+                    self.calc_path_L()
+                P, L = self.PathX, self.LayerX
+                base_km = np.array([L.BASEH[P.LAYINC[int(P.NLAYIN[i] / 2), i]] / 1.0e3 for i in range(int(P.NPATH))])    # :1314-1316
             rec = self._ansfm_transmission_inputs()
             if rec is None:
                 rec = self._ansfm_thermal_inputs()
@@ -330,6 +369,8 @@ class JacobianGPU:
             if rec is None:
                 rec = dict(alone=self.CIRSrad())
             recs.append(rec)
+            if kind == "PT":                       # the radii the transit depth is formed with are the state's (:1931-1932)
+                base_km = (base_km, float(self.StellarX.RADIUS), float(self.AtmosphereX.RADIUS))
             kept.append((self.MeasurementX, base_km))
         spectra, rows_c, rows_t = self._ansfm_run_batches(eng, recs, W)
         Y = np.zeros((int(M.NY), nfm))
@@ -340,8 +381,25 @@ class JacobianGPU:
             MX, base_km = kept[k]
             self.MeasurementX = MX
             V.XN = xnx[:, col]
-            SPECMOD = self._ansfm_limb_to_tangent_heights(np.asarray(spectra[k]).reshape(W, -1), base_km,
-                                                          [MX.TANHE[i] for i in range(int(MX.NGEOM))])
+            if kind == "C":                                                         # :1592-1602
+                SPECOUT = np.asarray(spectra[k]).reshape(W, -1)
+                dS = np.zeros((W, int(MX.NGEOM), int(V.NX)))
+                SPECOUT, dS = self.subspecret(SPECOUT, dS)
+                if int(S.ILBL) == _fm.ILBL_K_TABLES:
+                    SP, _ = MX.convg(S.WAVE, SPECOUT, dS, IGEOM='All')
+                else:
+                    SP = MX.lblconv(S.WAVE, SPECOUT, IGEOM='All')
+                ik = 0
+                for ig in range(M.NGEOM):                                           # execute_fm :2171-2174
+                    nc = int(M.NCONV[ig])
+                    Y[ik:ik + nc, ifm] = SP[0:nc, ig]
+                    ik += nc
+                continue
+            if kind == "PT":
+                SPECMOD = self._ansfm_transit_depth(np.asarray(spectra[k]).reshape(W, -1), *base_km, int(MX.NGEOM))
+            else:
+                SPECMOD = self._ansfm_limb_to_tangent_heights(np.asarray(spectra[k]).reshape(W, -1), base_km,
+                                                              [MX.TANHE[i] for i in range(int(MX.NGEOM))])
             if kind == "L" and int(MX.IFORM) == IFORM_INTEGRATED_RADIANCE:          # :1348-1361 (nemesisSOfm has no filter branch)
                 SPECONV = MX.integrate_filter(S.WAVE, SPECMOD, IGEOM='All')
             elif int(S.ILBL) == _fm.ILBL_K_TABLES:
@@ -360,12 +418,13 @@ class JacobianGPU:
             Y = self._ansfm_gather(Y, s, e, nfm, rank, world, group)
         return Y
 
-    def _ansfm_convolve(self, SPEC, IGEOM):
-        """nemesisfm :556-581 for one geometry: filter integral, ILS convolution by table kind, normalisation."""
+    def _ansfm_convolve(self, SPEC, IGEOM, disc=False):
+        """nemesisfm :556-581 for one geometry: filter integral, ILS convolution by table kind, normalisation.  disc: as
+        nemesisdiscfm does it (:1692-1708: no filter-integral branch)."""
         import os
         M, S = self.Measurement, self.SpectroscopyX
         nc = int(M.NCONV[IGEOM])
-        if int(M.IFORM) == IFORM_INTEGRATED_RADIANCE:
+        if not disc and int(M.IFORM) == IFORM_INTEGRATED_RADIANCE:
             return np.asarray(M.integrate_filter(S.WAVE, SPEC, IGEOM=IGEOM))[0:nc]
         if int(S.ILBL) == _fm.ILBL_K_TABLES:
             fw = self.runname if os.path.exists(self.runname + ".fwh") else ""

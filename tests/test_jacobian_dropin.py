@@ -380,6 +380,121 @@ def test_limb_forward_model_jacobian_staged_equals_the_reference_loop(c1_cut, fl
     assert not np.array_equal(res["auto"][0][:10], res["auto"][0][10:20])         # the tangent heights see different spectra
 
 
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_disc_forward_model_jacobian_staged_equals_the_reference_loop(c1_cut):
+    """jacobian_nemesis(nemesisdisc=True): nemesisdiscfm is nemesisfm with the averaging points of a geometry run through
+    process_IAV and summed at once.  Two geometries, the second a field-of-view average of three emission angles: the staged
+    route (one batched call per averaging point) equals the loop route (the reference's nemesisdiscfm per column) bit for bit."""
+    ans, gj, fmod, double = c1_cut
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    free = (5, 30, 60)
+    res = {}
+    for route in ("auto", "loop"):
+        fm = gj.cut_case(ans, cls=FMGPU, nkeep=12, free=free)
+        M = fm.Measurement
+        n0, n1 = 12, 9
+        two = lambda a, b: np.stack([a, b], axis=1)
+        pad = lambda v: np.concatenate([v[:n1], np.zeros(n0 - n1)])
+        M.NGEOM = 2
+        M.NCONV = np.array([n0, n1], dtype="int32")
+        M.NAV = np.array([1, 3], dtype="int32")
+        M.VCONV = two(M.VCONV[:n0, 0], pad(M.VCONV[:n0, 0] + 1.0))
+        M.MEAS = two(M.MEAS[:n0, 0], pad(M.MEAS[:n0, 0])); M.ERRMEAS = two(M.ERRMEAS[:n0, 0], pad(M.ERRMEAS[:n0, 0]))
+        z3 = np.zeros((2, 3))
+        M.FLAT, M.FLON, M.SOL_ANG, M.AZI_ANG = z3.copy(), z3.copy(), z3.copy(), z3.copy()
+        M.EMISS_ANG = np.array([[0.0, 0.0, 0.0], [15.0, 35.0, 55.0]])
+        M.WGEOM = np.array([[1.0, 0.0, 0.0], [0.2, 0.5, 0.3]])
+        M.NY = n0 + n1
+        fm.ansfm_jacobian_route = route
+        double.batch_sizes = []
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            YN, KK = fm.jacobian_nemesis(NCores=1, nemesisdisc=True, analytical_gradient=False)
+        assert fm.ansfm_last_jacobian["route"] == ("staged" if route == "auto" else "loop")
+        res[route] = (YN, KK, list(double.batch_sizes))
+    assert np.array_equal(res["auto"][0], res["loop"][0]) and np.array_equal(res["auto"][1], res["loop"][1])
+    assert res["auto"][2] == [4, 4, 4, 4] and res["loop"][2] == []        # one batched call per (geometry, averaging point)
+    for ix in free:
+        assert np.abs(res["auto"][1][:, ix]).max() > 0
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_several_viewing_angles_jacobian_staged_equals_the_reference_loop(c1_cut):
+    """jacobian_nemesis(nemesisC=True) on the scattering case: nemesisCfm puts the three viewing geometries into ONE
+    multiple-scattering CIRSrad call per state (calc_path_C, hydrostatic re-adjustment on), applies subspecret to the
+    unconvolved spectra and convolves all geometries at once.  Staged (one batched scattering call for the six states) against
+    the loop (the reference's nemesisCfm per column): the same YN and KK to the last bit."""
+    ans, gj, fmod, double = c1_cut
+    from oracle import gen_golden_jacobian_ms as gm
+    gj.setup_c1(ans, os.getcwd(), seed=4, case=gm.CASE)
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    res = {}
+    for route in ("auto", "loop"):
+        fm = gj.cut_case(ans, cls=FMGPU, nkeep=gm.NKEEP, free=gm.FREE)
+        M = fm.Measurement
+        n0, ng = int(M.NCONV[0]), 3
+        rep = lambda a: np.repeat(np.asarray(a)[:n0, 0:1], ng, axis=1)
+        M.NGEOM = ng
+        M.NCONV = np.array([n0] * ng, dtype="int32")
+        M.NAV = np.ones(ng, dtype="int32")
+        M.VCONV = rep(M.VCONV); M.MEAS = rep(M.MEAS); M.ERRMEAS = rep(M.ERRMEAS)
+        z = np.zeros((ng, 1))
+        M.FLAT, M.FLON, M.TANHE = z.copy(), z.copy(), z.copy()
+        M.AZI_ANG = np.array([[0.0], [40.0], [90.0]])
+        M.SOL_ANG = np.full((ng, 1), 30.0)
+        M.EMISS_ANG = np.array([[10.0], [30.0], [50.0]])
+        M.WGEOM = np.ones((ng, 1))
+        M.NY = n0 * ng
+        fm.ansfm_jacobian_route = route
+        double.scatter_batches = []
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            YN, KK = fm.jacobian_nemesis(NCores=1, nemesisC=True, analytical_gradient=False)
+        info = fm.ansfm_last_jacobian
+        assert info["route"] == ("staged" if route == "auto" else "loop") and info["nfm"] == 6
+        res[route] = (YN, KK, list(double.scatter_batches))
+    assert np.array_equal(res["auto"][0], res["loop"][0]) and np.array_equal(res["auto"][1], res["loop"][1])
+    assert res["auto"][2] == [6] and res["loop"][2] == []
+    n0 = res["auto"][0].size // 3
+    assert not np.array_equal(res["auto"][0][:n0], res["auto"][0][n0:2 * n0]) and np.abs(res["auto"][1]).max() > 0
+
+
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+def test_primary_transit_jacobian_staged_equals_the_reference_loop(c1_cut):
+    """jacobian_nemesis(nemesisPT=True), IFORM = TransitDepth: nemesisPTfm takes the transmission of every tangent path in one
+    CIRSrad call and integrates the absorbing area over the tangent heights.  Staged (one batched transmission call for the
+    four states, the reference's integration restated) against the loop (the reference's nemesisPTfm per column): same bits.
+    With another measurement unit the staged route declines and the reference's own code raises its error."""
+    ans, gj, fmod, double = c1_cut
+    FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+    free = (20, 45, 70)
+    res = {}
+    for route in ("auto", "loop"):
+        fm = gj.cut_case(ans, cls=FMGPU, nkeep=10, free=free)
+        fm.Measurement.IFORM = 2
+        fm.ansfm_jacobian_route = route
+        double.batch_sizes = []
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            YN, KK = fm.jacobian_nemesis(NCores=1, nemesisPT=True, analytical_gradient=False)
+        assert fm.ansfm_last_jacobian["route"] == ("staged" if route == "auto" else "loop")
+        res[route] = (YN, KK, list(double.batch_sizes))
+    assert np.array_equal(res["auto"][0], res["loop"][0]) and np.array_equal(res["auto"][1], res["loop"][1])
+    assert res["auto"][2] == [4] and res["loop"][2] == []
+    assert np.all(res["auto"][0] > 0.5) and np.all(res["auto"][0] < 5.0)          # a transit depth in per cent
+    for ix in free:
+        assert np.abs(res["auto"][1][:, ix]).max() > 0
+    fm = gj.cut_case(ans, cls=FMGPU, nkeep=10, free=free)                          # radiance units: the reference refuses
+    with pytest.raises(ValueError, match="TransitDepth"):
+        fm.jacobian_nemesis(NCores=1, nemesisPT=True, analytical_gradient=False)
+
+
 def test_limb_spectra_are_brought_to_the_tangent_heights_as_the_reference_does():
     """nemesisLfm :1322-1344 restated (JacobianGPU._ansfm_limb_to_tangent_heights): weights between the neighbouring tangent
     paths, the nearest base compared after a second division by 1e3, the lower neighbour -1 wrapping to the last path, the
