@@ -2245,11 +2245,71 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
         HIPCHK(hipGetLastError());
     }
     p.hansen_comp0 = 0;
+    // the walk's kernel by quadrature size: 16 (the matrix-core chain's), 5 (the reference's default, Scatter_0.py:59), 8; any
+    // other size takes the run-time build
+    auto launch_hansen = [&](hipStream_t st, const MsParams &pp) {
+        const dim3 hg((unsigned)ncomp_run), hb(64);
+        switch (nmu) {
+        case 16: hipLaunchKernelGGL(k_ms_hansen_seq<16>, hg, hb, 0, st, pp); break;
+        case 5: hipLaunchKernelGGL(k_ms_hansen_seq<5>, hg, hb, 0, st, pp); break;
+        case 8: hipLaunchKernelGGL(k_ms_hansen_seq<8>, hg, hb, 0, st, pp); break;
+        default: hipLaunchKernelGGL(k_ms_hansen_seq<0>, hg, hb, 0, st, pp); break;
+        }
+    };
+    // The Hansen walk is sequential over (g, wave) -- two waves on the whole chip -- so it is cut into one launch per
+    // g-ordinate on a second stream and the chains of g start as soon as its factors exist: the walk of g + 1 hides behind
+    // them.  chain_of(g, stream, params of that g-ordinate) launches the chains of one g-ordinate.
+    auto per_g_ordinate = [&](auto chain_of) -> int {
+        if (!ctx->ms_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->ms_stream, hipStreamNonBlocking));
+        if (!ctx->ms_stream2) HIPCHK(hipStreamCreateWithFlags(&ctx->ms_stream2, hipStreamNonBlocking));
+        while ((int)ctx->ms_ev.size() < ng + 3) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->ms_ev.push_back(e);
+        }
+        HIPCHK(hipEventRecord(ctx->ms_ev[ng], ctx->stream));                    // phase matrices (and every input) ready
+        HIPCHK(hipStreamWaitEvent(ctx->ms_stream, ctx->ms_ev[ng], 0));
+        HIPCHK(hipStreamWaitEvent(ctx->ms_stream2, ctx->ms_ev[ng], 0));
+        // from here on work is queued on the side streams: whatever way this function is left -- an error return of any
+        // launch below included -- the main stream waits for them, so the next entry point cannot reuse ctx->misc / tmp_*
+        // while a side stream still reads or writes them
+        struct Rejoin {
+            ansfm_ctx *c; int ng; bool done = false;
+            void now()
+            {
+                if (done) return;
+                done = true;
+                if (hipEventRecord(c->ms_ev[ng + 1], c->ms_stream) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->ms_ev[ng + 1], 0);
+                if (hipEventRecord(c->ms_ev[ng + 2], c->ms_stream2) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->ms_ev[ng + 2], 0);
+            }
+            ~Rejoin() { now(); }
+        } rejoin{ctx, ng};
+        for (int g = 0; g < ng; ++g) {
+            MsParams ph = p;
+            ph.ig0 = g; ph.ng_launch = 1;
+            launch_hansen(ctx->ms_stream, ph);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ctx->ms_ev[g], ctx->ms_stream));
+        }
+        for (int g = 0; g < ng; ++g) {
+            MsParams pc = p;
+            pc.ig0 = g; pc.ng_launch = 1;
+            // even g on the main stream, odd g beside it (a third stream adds nothing): a launch of 1e4 blocks ends with a
+            // tail of half-empty CUs (chains differ in length with the optical depth), which the next g-ordinate's blocks fill
+            hipStream_t cs = (g & 1) ? ctx->ms_stream2 : ctx->stream;
+            HIPCHK(hipStreamWaitEvent(cs, ctx->ms_ev[g], 0));
+            chain_of(cs, pc);
+            HIPCHK(hipGetLastError());
+        }
+        // the side streams must not run into the next call's buffers: they rejoin the main one here
+        rejoin.now();
+        return ANSFM_OK;
+    };
     if (prepare_only) {
         // the batch path (ansfm_cirsrad_ck_scatter_batch) launches its own chains: phase matrices above, and the whole Hansen
         // walk -- it depends on the phase functions only, not on the model -- in one launch
         if (ncomp_run > 0) {
-            hipLaunchKernelGGL(k_ms_hansen_seq<16>, dim3((unsigned)ncomp_run), dim3(64), 0, ctx->stream, p);
+            launch_hansen(ctx->stream, p);
             HIPCHK(hipGetLastError());
         }
         return ANSFM_OK;
@@ -2273,62 +2333,24 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
             else hipLaunchKernelGGL(k_ms_chain16<false>, dim3(grid), dim3(64), lds16, st, pp);
         };
         if (ncomp_run > 0) {
-            if (!ctx->ms_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->ms_stream, hipStreamNonBlocking));
-            if (!ctx->ms_stream2) HIPCHK(hipStreamCreateWithFlags(&ctx->ms_stream2, hipStreamNonBlocking));
-            while ((int)ctx->ms_ev.size() < ng + 3) {
-                hipEvent_t e;
-                HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                ctx->ms_ev.push_back(e);
-            }
-            HIPCHK(hipEventRecord(ctx->ms_ev[ng], ctx->stream));                    // phase matrices (and every input) ready
-            HIPCHK(hipStreamWaitEvent(ctx->ms_stream, ctx->ms_ev[ng], 0));
-            HIPCHK(hipStreamWaitEvent(ctx->ms_stream2, ctx->ms_ev[ng], 0));
-            // from here on work is queued on the side streams: whatever way this function is left -- an error return of any
-            // launch below included -- the main stream waits for them, so the next entry point cannot reuse ctx->misc / tmp_*
-            // while a side stream still reads or writes them
-            struct Rejoin {
-                ansfm_ctx *c; int ng; bool done = false;
-                void now()
-                {
-                    if (done) return;
-                    done = true;
-                    if (hipEventRecord(c->ms_ev[ng + 1], c->ms_stream) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->ms_ev[ng + 1], 0);
-                    if (hipEventRecord(c->ms_ev[ng + 2], c->ms_stream2) == hipSuccess) (void)hipStreamWaitEvent(c->stream, c->ms_ev[ng + 2], 0);
-                }
-                ~Rejoin() { now(); }
-            } rejoin{ctx, ng};
-            for (int g = 0; g < ng; ++g) {
-                MsParams ph = p;
-                ph.ig0 = g; ph.ng_launch = 1;
-                hipLaunchKernelGGL(k_ms_hansen_seq<16>, dim3((unsigned)ncomp_run), dim3(64), 0, ctx->ms_stream, ph);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipEventRecord(ctx->ms_ev[g], ctx->ms_stream));
-            }
-            for (int g = 0; g < ng; ++g) {
-                MsParams pc = p;
-                pc.ig0 = g; pc.ng_launch = 1;
-                // even g on the main stream, odd g beside it (a third stream adds nothing): a launch of 1e4 blocks ends with a
-                // tail of half-empty CUs
-                // (chains differ in length with the optical depth), which the next g-ordinate's blocks fill
-                hipStream_t cs = (g & 1) ? ctx->ms_stream2 : ctx->stream;
-                HIPCHK(hipStreamWaitEvent(cs, ctx->ms_ev[g], 0));
-                launch_chain((unsigned)nwave, cs, pc);
-                HIPCHK(hipGetLastError());
-            }
-            // the side streams must not run into the next call's buffers: they rejoin the main one here
-            rejoin.now();
+            const int rc = per_g_ordinate([&](hipStream_t cs, const MsParams &pc) { launch_chain((unsigned)nwave, cs, pc); });
+            if (rc != ANSFM_OK) return rc;
         } else {
             launch_chain((unsigned)((size_t)nwave * ng), ctx->stream, p);
             HIPCHK(hipGetLastError());
         }
     } else {
+        // any other stream count: one block per (wavenumber, g, Fourier order) on LDS matrices; the same pipeline per g-ordinate
+        const size_t ldsg = (12 * nn + 6 * kMsMaxMu + 2) * D;
         if (ncomp_run > 0) {
-            hipLaunchKernelGGL(k_ms_hansen_seq<0>, dim3((unsigned)ncomp_run), dim3(64), 0, ctx->stream, p);
+            const int rc = per_g_ordinate([&](hipStream_t cs, const MsParams &pc) {
+                hipLaunchKernelGGL(k_ms_chain, dim3((unsigned)((size_t)nwave * (nf + 1))), dim3(64), ldsg, cs, pc);
+            });
+            if (rc != ANSFM_OK) return rc;
+        } else {
+            hipLaunchKernelGGL(k_ms_chain, dim3((unsigned)((size_t)nwave * ng * (nf + 1))), dim3(64), ldsg, ctx->stream, p);
             HIPCHK(hipGetLastError());
         }
-        const dim3 cgrid((unsigned)((size_t)nwave * ng * (nf + 1)));
-        hipLaunchKernelGGL(k_ms_chain, cgrid, dim3(64), (12 * nn + 6 * kMsMaxMu + 2) * D, ctx->stream, p);
-        HIPCHK(hipGetLastError());
         const size_t tot = (size_t)nwave * ng * ngeom;
         hipLaunchKernelGGL(k_ms_fourier, dim3(nblk(tot, 128)), dim3(128), 0, ctx->stream, p);
         HIPCHK(hipGetLastError());

@@ -242,21 +242,24 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
     // forward model (the chain kernels of g-ordinate ig wait for the factors of ig).
     constexpr int D = NMU ? kMsHansenDepth : 2;
     constexpr bool FULL = NMU != 0 && (NMU * NMU) % 64 == 0;     // every lane holds NE elements: no bounds tests on the accesses
+    // a compile-time size that does not fill the lanes (5 x 5: the reference's default quadrature): the idle lanes repeat the
+    // last element's access -- the same value to the same address -- so that the number of loads and stores stays fixed
+    constexpr bool CLAMP = NMU != 0 && !FULL;
     double ring[D][2 * NE];
     auto fetch = [&](int d, int widx) {
         const double *gppl = p.ppl + (((size_t)widx * (p.nf + 1) + 0) * p.ncomp + comp) * nn;
         const double *gpmi = p.pmi + (((size_t)widx * (p.nf + 1) + 0) * p.ncomp + comp) * nn;
 #pragma unroll
         for (int r = 0; r < NE; ++r) {
-            const int e = tid + 64 * r;
-            if (FULL || e < nn) { ring[d][r] = gppl[e]; ring[d][NE + r] = gpmi[e]; }
+            const int e = CLAMP ? min(tid + 64 * r, nn - 1) : tid + 64 * r;
+            if (FULL || CLAMP || e < nn) { ring[d][r] = gppl[e]; ring[d][NE + r] = gpmi[e]; }
         }
     };
     auto stage = [&](int d) {
 #pragma unroll
         for (int r = 0; r < NE; ++r) {
-            const int e = tid + 64 * r;
-            if (FULL || e < nn) { ppl_s[e] = ring[d][r]; pmi_s[e] = ring[d][NE + r]; }
+            const int e = CLAMP ? min(tid + 64 * r, nn - 1) : tid + 64 * r;
+            if (FULL || CLAMP || e < nn) { ppl_s[e] = ring[d][r]; pmi_s[e] = ring[d][NE + r]; }
         }
     };
     // the walk of this launch: g-ordinates [ig0, ig0 + ng_launch), continuing from the factors the previous launch left
@@ -320,8 +323,8 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
         double *ofc = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp + comp) * nn;
 #pragma unroll
         for (int r = 0; r < NE; ++r) {           // a fixed number of stores per step (the waits before the ring's slots count them)
-            const int e = tid + 64 * r;
-            if (FULL || e < nn) ofc[e] = fc[e];
+            const int e = CLAMP ? min(tid + 64 * r, nn - 1) : tid + 64 * r;
+            if (FULL || CLAMP || e < nn) ofc[e] = fc[e];
         }
         if (++widx == p.nwave) { widx = 0; ++ig; }
         MS_WAVE_SYNC();
@@ -410,8 +413,8 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
     const int ld = n;
     const int msz = n * ld;
     const int ic = blockIdx.x % (p.nf + 1);
-    const int ig = (blockIdx.x / (p.nf + 1)) % p.ng;
-    const int widx = blockIdx.x / ((p.nf + 1) * p.ng);
+    const int ig = p.ig0 + (int)((blockIdx.x / (p.nf + 1)) % p.ng_launch);      // the g-ordinates [ig0, ig0 + ng_launch) of this launch
+    const int widx = blockIdx.x / ((p.nf + 1) * p.ng_launch);
     const double pi = 3.141592653589793;
     // LDS carve-up
     double *rc = sm, *tc = rc + msz, *r1 = tc + msz, *t1 = r1 + msz, *pp = t1 + msz, *pm = pp + msz;

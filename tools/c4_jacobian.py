@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--waves", type=int, default=10000)
     ap.add_argument("--check", action="store_true", help="compare every state with a call of its own (slow)")
     ap.add_argument("--forward", type=int, default=0, help="only time this many calls of ONE forward model (C4 size)")
+    ap.add_argument("--nmu", type=int, default=16, help="zenith quadrature points (16: the matrix-core chain; the reference's default is 5)")
+    ap.add_argument("--nf", type=int, default=8, help="Fourier orders - 1 (the reference's default is 2)")
     args = ap.parse_args()
     import torch
     import archnemesis_dist_amd as pkg
@@ -37,7 +39,7 @@ def main():
     from archnemesis_dist_amd.profile_state import ContinuousProfileState, BatchedCKThermalModel
     from bench import torch_ktable
     dev = torch.device("cuda", 0)
-    W, G, S, L, NP, NT, NMU, NF = args.waves, 20, 8, 100, 20, 15, 16, 8
+    W, G, S, L, NP, NT, NMU, NF = args.waves, 20, 8, 100, 20, 15, args.nmu, args.nf
     eng = pkg.AnsfmEngine(0)
     _, delg = syn.gauss_legendre_01(G, as_float32=True)
     PRESS, TEMP, K = torch_ktable(torch, dev, W, G, NP, NT, S, seed=20260704)
