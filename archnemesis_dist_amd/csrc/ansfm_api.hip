@@ -2342,13 +2342,20 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     } else {
         // any other stream count: one block per (wavenumber, g, Fourier order) on LDS matrices; the same pipeline per g-ordinate
         const size_t ldsg = (12 * nn + 6 * kMsMaxMu + 2) * D;
+        auto launch_chain_n = [&](dim3 grid, hipStream_t st, const MsParams &pp) {
+            switch (nmu) {
+            case 5: hipLaunchKernelGGL(k_ms_chain<5>, grid, dim3(64), ldsg, st, pp); break;
+            case 8: hipLaunchKernelGGL(k_ms_chain<8>, grid, dim3(64), ldsg, st, pp); break;
+            default: hipLaunchKernelGGL(k_ms_chain<0>, grid, dim3(64), ldsg, st, pp); break;
+            }
+        };
         if (ncomp_run > 0) {
             const int rc = per_g_ordinate([&](hipStream_t cs, const MsParams &pc) {
-                hipLaunchKernelGGL(k_ms_chain, dim3((unsigned)((size_t)nwave * (nf + 1))), dim3(64), ldsg, cs, pc);
+                launch_chain_n(dim3((unsigned)((size_t)nwave * (nf + 1))), cs, pc);
             });
             if (rc != ANSFM_OK) return rc;
         } else {
-            hipLaunchKernelGGL(k_ms_chain, dim3((unsigned)((size_t)nwave * ng * (nf + 1))), dim3(64), ldsg, ctx->stream, p);
+            launch_chain_n(dim3((unsigned)((size_t)nwave * ng * (nf + 1))), ctx->stream, p);
             HIPCHK(hipGetLastError());
         }
         const size_t tot = (size_t)nwave * ng * ngeom;

@@ -405,11 +405,16 @@ __device__ __forceinline__ void ms_inv(int n, int ld, double *A, double *Ainv, d
 }
 
 // ---- (R,T,J) chain of one (wave, g, ic) -------------------------------------------------------------------
+// N: the stream count at compile time (5 = the reference's default quadrature, Scatter_0.py:59; 8), 0 = any nmu <= kMsMaxMu at
+// run time.  With N known the element -> (row, column) divisions become multiplications and the k-loops of the small products
+// unroll (C4 size at 5 streams: 0.26 -> 0.21 s).  127 registers = four waves per SIMD; capped at 85 / 64 registers (six / eight
+// waves, 0 / 55 spilled) the kernel is no faster (0.21 / 0.24 s): it is not occupancy that binds it.
+template <int N>
 __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
 {
     extern __shared__ double sm[];
     const int lane = threadIdx.x;
-    const int n = p.nmu, nn = n * n;
+    const int n = N ? N : p.nmu, nn = n * n;
     const int ld = n;
     const int msz = n * ld;
     const int ic = blockIdx.x % (p.nf + 1);

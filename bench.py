@@ -155,6 +155,35 @@ def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, d
         ex["c4_scatter"]["oracle_sample"] = (f"{nq} (wavenumber, g) chains (first {nq} wavenumbers, first g-ordinate: 16 streams x {L} "
                                              f"layers x {NF + 1} orders each) through oracle/ansfm_oracle_ms.c, {time.perf_counter() - t0:.1f} s")
 
+    # ---- the same at the reference's DEFAULT quadrature (Scatter_0.py:59: NMU = 5, NF = 2): the stream-count-generic chain
+    #      (LDS matrices, one block per (wavenumber, g, order)), not the matrix-core one
+    n5, f5 = 5, 2
+    x5, w5 = np.polynomial.legendre.leggauss(n5)
+    MU5, WT5 = 0.5 * (x5 + 1.0), 0.5 * w5
+    radg5 = np.ascontiguousarray(radg[:, :n5])
+    fs5 = lambda **kw: eng.cirsrad_ck_scatter(0, lay_p, lay_t, am, None, TAUDUST, TAURAY, TAUSCAT, ph, np.ones((W, 1, L)), radg5,
+                                              [30.0], [20.0], [45.0], np.full(W, 1e-8), 0, np.zeros((W, n5, n5, f5 + 1)), MU5, WT5,
+                                              f5, 101, 1, 1, **kw)
+    t5 = med(fs5, 2)
+    ex["c4_scatter_default_streams"] = {"what": "the C4 configuration with the reference's default quadrature (5 streams, NF = 2) "
+                                                "instead of 16 streams / NF = 8", "wall_s": t5, "chains_per_s": W * G * (f5 + 1) / t5}
+    if do_cpu and K_sample is not None:
+        from oracle import oracle as orc
+        nq = 4
+        t0 = time.perf_counter()
+        _, sg5 = fs5(return_spec_g=True)
+        kk = orc.calc_k(K_sample[:nq], PRESS, TEMP, lay_p / 101325.0, lay_t)
+        tg = orc.k_overlap(delg, kk, am)
+        tautot = tg + TAUDUST[:nq, None, :] + TAURAY[:nq, None, :]
+        omega = np.where(tautot > 0, (TAURAY + TAUSCAT)[:nq, None, :] / np.where(tautot > 0, tautot, 1.0), 0.0)
+        bnu = c1 * WAVE[:nq, None] ** 3 / (np.exp(c2 * WAVE[:nq, None] / lay_t[None, :]) - 1.0)
+        rad5 = orc.scloud11wave_core(ph[:, :nq], radg5[:nq], [30.0], [20.0], np.full(nq, 1e-8), [45.0], 0, np.zeros((nq, n5, n5, f5 + 1)),
+                                     MU5, WT5, f5, WAVE[:nq], bnu, np.ascontiguousarray(tautot[:, 0:1, :]), TAURAY[:nq],
+                                     np.ascontiguousarray(omega[:, 0:1, :]), 101, 1, 1, np.ones((nq, 1, L)))
+        ref5 = rad5[0, 0, :]
+        ex["c4_scatter_default_streams"]["max_rel_err_vs_oracle"] = float(np.max(np.abs(sg5[:nq, 0, 0] - ref5) / np.abs(ref5)))
+        ex["c4_scatter_default_streams"]["oracle_sample"] = f"{nq} (wavenumber, g) chains as for c4_scatter, {time.perf_counter() - t0:.1f} s"
+
     # ---- numerical Jacobian of the scattering configuration at C4 size: jacobian_nemesis forces NX + 1 multiple-scattering
     #      forward models when ISCAT != THERMAL_EMISSION (ForwardModel_0.py:2251-2252) -- its most expensive case.  The state
     #      vector of the C3 row (T and ln VMR of one absorber at 100 levels through Curtis-Godson layer_average), 201 forward
