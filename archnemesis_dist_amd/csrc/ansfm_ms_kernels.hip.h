@@ -335,6 +335,8 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
 // ---- small dense helpers on LDS matrices (one wavefront = one block), any nmu <= kMsMaxMu = 32 -------------------
 typedef double ms_v4f64 __attribute__((ext_vector_type(4)));
 
+// (the blocks of k_ms_chain are ONE wavefront: a compiler fence orders its lanes' LDS accesses -- MS_WAVE_SYNC, as in the
+//  Hansen walk; __syncthreads() would also wait for every global access in flight at each of the ~30 points of a layer)
 __device__ __forceinline__ void ms_mm(int n, int ld, const double *A, const double *B, double *C, int lane)
 {   // C = A B   (C distinct from A and B)
     for (int e = lane; e < n * n; e += 64) {
@@ -343,7 +345,7 @@ __device__ __forceinline__ void ms_mm(int n, int ld, const double *A, const doub
         for (int k = 0; k < n; ++k) s += A[i * ld + k] * B[k * ld + j];
         C[i * ld + j] = s;
     }
-    __syncthreads();
+    MS_WAVE_SYNC();
 }
 __device__ __forceinline__ void ms_mv(int n, int ld, const double *A, const double *x, double *y, int lane)
 {   // y = A x   (y distinct from x)
@@ -352,7 +354,7 @@ __device__ __forceinline__ void ms_mv(int n, int ld, const double *A, const doub
         for (int k = 0; k < n; ++k) s += A[lane * ld + k] * x[k];
         y[lane] = s;
     }
-    __syncthreads();
+    MS_WAVE_SYNC();
 }
 __device__ __forceinline__ double ms_frob(int n, int ld, const double *r, int lane)
 {
@@ -366,7 +368,7 @@ __device__ __forceinline__ double ms_frob(int n, int ld, const double *r, int la
 __device__ __forceinline__ void ms_inv(int n, int ld, double *A, double *Ainv, double *col, int lane)
 {
     for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e % n; Ainv[i * ld + j] = (i == j) ? 1.0 : 0.0; }
-    __syncthreads();
+    MS_WAVE_SYNC();
     for (int c = 0; c < n; ++c) {
         double best = (lane >= c && lane < n) ? fabs(A[lane * ld + c]) : -1.0;
         int piv = lane;
@@ -389,9 +391,9 @@ __device__ __forceinline__ void ms_inv(int n, int ld, double *A, double *Ainv, d
             A[c * ld + lane] = ac * d;
             Ainv[c * ld + lane] = wc * d;
         }
-        __syncthreads();
+        MS_WAVE_SYNC();
         if (lane < n) col[lane] = A[lane * ld + c];
-        __syncthreads();
+        MS_WAVE_SYNC();
         for (int e = lane; e < n * n; e += 64) {
             const int r = e / n, j = e % n;
             if (r != c) {
@@ -400,7 +402,7 @@ __device__ __forceinline__ void ms_inv(int n, int ld, double *A, double *Ainv, d
                 Ainv[r * ld + j] -= f * Ainv[c * ld + j];
             }
         }
-        __syncthreads();
+        MS_WAVE_SYNC();
     }
 }
 
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
 #define MS_AT(M, i, j) M[(i) * ld + (j)]
 
     if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // radg[:, ::-1] :765
-    __syncthreads();
+    MS_WAVE_SYNC();
     bool defined = false;
     const bool lookup = p.lookup != 0;
     if (p.lowbc > 0 && !lookup) {  // surface operator first :824-836
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
         }
         if (lane < n) jc[lane] = radg[lane];
         defined = true;
-        __syncthreads();
+        MS_WAVE_SYNC();
     }
     const double *PPL = p.ppl + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
     const double *PMI = p.pmi + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * nn;
@@ -464,17 +466,17 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
         if (taut == 0) {
             MS_FOR_IJ { MS_AT(r1, i, j) = 0.0; MS_AT(t1, i, j) = (i == j) ? 1.0 : 0.0; }
             if (lane < n) j1[lane] = 0.0;
-            __syncthreads();
+            MS_WAVE_SYNC();
         } else if (omega == 0) {
             MS_FOR_IJ { MS_AT(r1, i, j) = 0.0; MS_AT(t1, i, j) = 0.0; }
-            __syncthreads();
+            MS_WAVE_SYNC();
             if (lane < n) {
                 const double tex = -(1. / p.mu[lane]) * taut;
                 const double tt = (tex > -200.0) ? exp(tex) : 0.0;
                 MS_AT(t1, lane, lane) = tt;
                 j1[lane] = bc * (1.0 - tt);
             }
-            __syncthreads();
+            MS_WAVE_SYNC();
         } else {
             iscl = 1;
             const double fr = taur / (tauscat + taur), fs = tauscat / (tauscat + taur);
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
                 MS_AT(pp, i, j) = a;
                 MS_AT(pm, i, j) = b;
             }
-            __syncthreads();
+            MS_WAVE_SYNC();
             // ---- double1 :321-362 --------------------------------------------------------------------------
             double con = omega * pi;
             con *= (ic == 0) ? 2.0 : 1.0;
@@ -503,16 +505,16 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
                 MS_AT(r1, i, j) = tau0 * gpm;
             }
             if (lane < n) j1[lane] = (ic == 0) ? (1.0 - omega) * bc * tau0 * (1. / p.mu[lane]) : 0.0;
-            __syncthreads();
+            MS_WAVE_SYNC();
             for (int it = 0; it < nd; ++it) {   // add :275-297
                 ms_mm(n, ld, r1, r1, m0, lane);               // bcom
                 if (ms_frob(n, ld, r1, lane) > 0.1) {
                     MS_FOR_IJ MS_AT(m1, i, j) = ((i == j) ? 1.0 : 0.0) - MS_AT(m0, i, j);
-                    __syncthreads();
+                    MS_WAVE_SYNC();
                     ms_inv(n, ld, m1, m2, col, lane);             // acom = inv(e - bcom)
                 } else {
                     MS_FOR_IJ MS_AT(m2, i, j) = ((i == j) ? 1.0 : 0.0) + MS_AT(m0, i, j);
-                    __syncthreads();
+                    MS_WAVE_SYNC();
                 }
                 ms_mm(n, ld, t1, m2, m3, lane);               // ccom = t1 acom
                 ms_mm(n, ld, m3, r1, m0, lane);               // rans = ccom r1
@@ -521,28 +523,28 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
                 if (ic == 0) {
                     ms_mv(n, ld, r1, j1, v0, lane);               // jcom = r1 j1 + j1
                     if (lane < n) v0[lane] = v0[lane] + j1[lane];
-                    __syncthreads();
+                    MS_WAVE_SYNC();
                     ms_mv(n, ld, m3, v0, v1, lane);               // jans = ccom jcom + j1
                     if (lane < n) j1[lane] = v1[lane] + j1[lane];
                 }
                 MS_FOR_IJ { MS_AT(r1, i, j) = MS_AT(r1, i, j) + MS_AT(m1, i, j); MS_AT(t1, i, j) = MS_AT(m4, i, j); }
-                __syncthreads();
+                MS_WAVE_SYNC();
             }
         }
         // ---- combine with the stack below :868-875 ------------------------------------------------------------
         if (l == 0 && !defined) {
             MS_FOR_IJ { MS_AT(rc, i, j) = MS_AT(r1, i, j); MS_AT(tc, i, j) = MS_AT(t1, i, j); }
             if (lane < n) jc[lane] = j1[lane];
-            __syncthreads();
+            MS_WAVE_SYNC();
         } else if (iscl == 1) {   // addp, scattering layer :486-511 (rsub,tsub,jsub) = (rc,tc,jc)
             ms_mm(n, ld, rc, r1, m0, lane);                   // rsq = rsub r1
             if (ms_frob(n, ld, m0, lane) > 0.01) {
                 MS_FOR_IJ MS_AT(m1, i, j) = ((i == j) ? 1.0 : 0.0) - MS_AT(m0, i, j);
-                __syncthreads();
+                MS_WAVE_SYNC();
                 ms_inv(n, ld, m1, m2, col, lane);
             } else {
                 MS_FOR_IJ MS_AT(m2, i, j) = ((i == j) ? 1.0 : 0.0) + MS_AT(m0, i, j);
-                __syncthreads();
+                MS_WAVE_SYNC();
             }
             ms_mm(n, ld, t1, m2, m3, lane);                   // ccom = t1 acom
             ms_mm(n, ld, m3, rc, m0, lane);                   // rans = ccom rsub
@@ -550,41 +552,41 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
             ms_mm(n, ld, m3, tc, m4, lane);                   // tans = ccom tsub
             ms_mv(n, ld, rc, j1, v0, lane);                       // jcom = rsub j1 + jsub
             if (lane < n) v0[lane] += jc[lane];
-            __syncthreads();
+            MS_WAVE_SYNC();
             ms_mv(n, ld, m3, v0, v1, lane);                       // jans = ccom jcom + j1
             if (lane < n) jc[lane] = v1[lane] + j1[lane];
             MS_FOR_IJ { MS_AT(rc, i, j) = MS_AT(r1, i, j) + MS_AT(m1, i, j); MS_AT(tc, i, j) = MS_AT(m4, i, j); }
-            __syncthreads();
+            MS_WAVE_SYNC();
         } else {                  // addp, non-scattering layer :513-530
             ms_mv(n, ld, rc, j1, v0, lane);
             if (lane < n) v0[lane] += jc[lane];
-            __syncthreads();
+            MS_WAVE_SYNC();
             MS_FOR_IJ {
                 const double ta = MS_AT(t1, i, i), tb = MS_AT(t1, j, j);
                 MS_AT(m0, i, j) = MS_AT(tc, i, j) * ta;
                 MS_AT(m1, i, j) = MS_AT(rc, i, j) * ta * tb;
             }
             if (lane < n) v1[lane] = j1[lane] + MS_AT(t1, lane, lane) * v0[lane];
-            __syncthreads();
+            MS_WAVE_SYNC();
             MS_FOR_IJ { MS_AT(tc, i, j) = MS_AT(m0, i, j); MS_AT(rc, i, j) = MS_AT(m1, i, j); }
             if (lane < n) jc[lane] = v1[lane];
-            __syncthreads();
+            MS_WAVE_SYNC();
         }
     }
     if (ic != 0 && lane < n) jc[lane] = 0.0;   // :881-882
-    __syncthreads();
+    MS_WAVE_SYNC();
     if (lookup && p.lowbc > 0) {
         // idown (:366-420) with rb = rs, tb = 0, jb = radg (js is set for every ic, :822):
         //   upl = (E - rc rs)^-1 (tc u0+ + (rc radg + jc));   m3 = the inverse, v0 = rc radg + jc
         MS_FOR_IJ MS_AT(m0, i, j) = (2. * (p.brdf[(((size_t)widx * n + i) * n + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
-        __syncthreads();
+        MS_WAVE_SYNC();
         ms_mm(n, ld, rc, m0, m1, lane);
         MS_FOR_IJ MS_AT(m2, i, j) = ((i == j) ? 1.0 : 0.0) - MS_AT(m1, i, j);
-        __syncthreads();
+        MS_WAVE_SYNC();
         ms_inv(n, ld, m2, m3, col, lane);
         ms_mv(n, ld, rc, radg, v0, lane);
         if (lane < n) v0[lane] = v0[lane] + jc[lane];
-        __syncthreads();
+        MS_WAVE_SYNC();
     }
     // ---- per path: the four (mu0, mu) samples and the bilinear interpolation :886-945 ---------------------------
     if (lane < p.ngeom) {
