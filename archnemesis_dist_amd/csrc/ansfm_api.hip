@@ -2,6 +2,7 @@
 // gfx950 only.  No CPU fallback: every entry point needs a live HIP device.
 #include "ansfm_kernels.hip.h"
 #include "ansfm_ms_kernels.hip.h"
+#include "ansfm_ms_lane.hip.h"
 #include "ansfm_lbl_kernels.hip.h"
 #include "ansfm_layer_kernels.hip.h"
 #include "ansfm_map_kernels.hip.h"
@@ -2342,7 +2343,22 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     } else {
         // any other stream count: one block per (wavenumber, g, Fourier order) on LDS matrices; the same pipeline per g-ordinate
         const size_t ldsg = (12 * nn + 6 * kMsMaxMu + 2) * D;
+        // few streams (the reference's default is 5): one LANE per chain, matrices in registers (ansfm_ms_lane.hip.h);
+        // ANSFM_MS_LANE=0: the wavefront-per-chain kernel for these sizes too
+        const char *lane_env = getenv("ANSFM_MS_LANE");            // read per call: the tests compare the two kernels
+        const bool lane_off = lane_env && lane_env[0] == '0';
+        const bool by_lane = !lane_off && (nmu == 4 || nmu == 5);      // (6 streams: 393 spilled registers, not offered)
+        const size_t ldsl = (size_t)(2 * nn + nmu) * 64 * D;
         auto launch_chain_n = [&](dim3 grid, hipStream_t st, const MsParams &pp) {
+            if (by_lane) {
+                const unsigned ngl = (unsigned)(grid.x / ((unsigned)nwave * (unsigned)(nf + 1)));      // g-ordinates of this launch
+                const dim3 gl((unsigned)((nwave + 63) / 64) * ngl * (unsigned)(nf + 1));
+                switch (nmu) {
+                case 4: hipLaunchKernelGGL(k_ms_chain_lane<4>, gl, dim3(64), ldsl, st, pp); break;
+                default: hipLaunchKernelGGL(k_ms_chain_lane<5>, gl, dim3(64), ldsl, st, pp); break;
+                }
+                return;
+            }
             switch (nmu) {
             case 5: hipLaunchKernelGGL(k_ms_chain<5>, grid, dim3(64), ldsg, st, pp); break;
             case 8: hipLaunchKernelGGL(k_ms_chain<8>, grid, dim3(64), ldsg, st, pp); break;

@@ -1,0 +1,357 @@
+// ansfm_ms_lane.hip.h -- the doubling / adding chain for SMALL stream counts: one LANE per (wavenumber, g, Fourier order).
+//
+// Multiple_Scattering_Core.scloud11wave_core at the reference's default quadrature (Scatter_0.py:59: NMU = 5, NF = 2) is a
+// chain of 5 x 5 products.  k_ms_chain<5> gives such a chain a whole wavefront and keeps its matrices in LDS: 25 lanes do
+// five multiply-adds per product behind ten LDS reads, and the LDS pipeline is what binds it.  Here a
+// chain is one lane's work: r1 / t1 and the temporaries are arrays of N * N registers (every loop unrolled, every index a
+// compile-time constant), a product is N^3 fused multiply-adds with no memory access at all, and the 64 lanes of a wave are 64
+// consecutive wavenumbers of one (g, order) -- neighbours take nearly the same number of doublings.  The stack below the
+// current layer (rc, tc, jc) is the only state that leaves the registers: [element][lane] in LDS, conflict-free.
+// Same operations in the same order as k_ms_chain (sums over k ascending from 0, the same Gauss-Jordan with partial pivoting
+// -- first largest |.| --, the reference's thresholds); the pivot row, which depends on the lane, is handled with selects over
+// compile-time rows, never with a run-time register index (that would send the matrices to scratch memory).
+// Output: p.drad like k_ms_chain; k_ms_fourier sums the orders.
+#pragma once
+#include "ansfm_ms_kernels.hip.h"
+
+namespace ansfm {
+
+template <int N> struct MsLane {
+    static constexpr int NN = N * N;
+    typedef double Mat[NN];
+    typedef double Vec[N];
+
+    __device__ __forceinline__ static void mm(const Mat &A, const Mat &B, Mat &C)      // C = A B (C distinct from A and B)
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) s += A[i * N + k] * B[k * N + j];
+                C[i * N + j] = s;
+            }
+    }
+    __device__ __forceinline__ static void mv(const Mat &A, const Vec &x, Vec &y)       // y = A x
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) s += A[i * N + k] * x[k];
+            y[i] = s;
+        }
+    }
+    __device__ __forceinline__ static double frob(const Mat &A)
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < NN; ++e) s += A[e] * A[e];
+        return sqrt(s);
+    }
+    // Ainv = inverse(A), Gauss-Jordan with partial pivoting (first largest |.| at or below the diagonal); A is destroyed
+    __device__ __forceinline__ static void inv(Mat &A, Mat &Ainv)
+    {
+#pragma unroll
+        for (int e = 0; e < NN; ++e) Ainv[e] = ((e / N) == (e % N)) ? 1.0 : 0.0;
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            double best = fabs(A[c * N + c]);
+            int piv = c;
+#pragma unroll
+            for (int r = c + 1; r < N; ++r) {
+                const double v = fabs(A[r * N + c]);
+                if (v > best) { best = v; piv = r; }
+            }
+            // rows c and piv change places: piv differs from lane to lane, the rows it may be are compile-time candidates
+#pragma unroll
+            for (int r = c + 1; r < N; ++r) {
+                const bool sw = (piv == r);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const double ac = A[c * N + j], ar = A[r * N + j];
+                    A[c * N + j] = sw ? ar : ac; A[r * N + j] = sw ? ac : ar;
+                    const double wc = Ainv[c * N + j], wr = Ainv[r * N + j];
+                    Ainv[c * N + j] = sw ? wr : wc; Ainv[r * N + j] = sw ? wc : wr;
+                }
+            }
+            const double d = 1.0 / A[c * N + c];
+#pragma unroll
+            for (int j = 0; j < N; ++j) { A[c * N + j] = A[c * N + j] * d; Ainv[c * N + j] = Ainv[c * N + j] * d; }
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                if (r == c) continue;
+                const double f = A[r * N + c];
+#pragma unroll
+                for (int j = 0; j < N; ++j) { A[r * N + j] -= f * A[c * N + j]; Ainv[r * N + j] -= f * Ainv[c * N + j]; }
+            }
+        }
+    }
+    // acom of add / addp: inv(E - B) where |X|_F > thr, E + B otherwise (Multiple_Scattering_Core.py :283-287, :492-496)
+    __device__ __forceinline__ static void acom(const Mat &B, bool full, Mat &tmp, Mat &out)
+    {
+        if (full) {
+#pragma unroll
+            for (int e = 0; e < NN; ++e) tmp[e] = (((e / N) == (e % N)) ? 1.0 : 0.0) - B[e];
+            inv(tmp, out);
+        } else {
+#pragma unroll
+            for (int e = 0; e < NN; ++e) out[e] = (((e / N) == (e % N)) ? 1.0 : 0.0) + B[e];
+        }
+    }
+};
+
+// grid: ((wavenumber tiles of 64) * ng_launch * (nf + 1)) blocks of 64 lanes; dynamic LDS (2 N^2 + N) * 64 doubles
+template <int N>
+__global__ __launch_bounds__(64) void k_ms_chain_lane(MsParams p)
+{
+    typedef MsLane<N> M;
+    constexpr int NN = N * N;
+    extern __shared__ double sm[];
+    const int lane = threadIdx.x;
+    const int ic = blockIdx.x % (p.nf + 1);
+    const int ig = p.ig0 + (int)((blockIdx.x / (p.nf + 1)) % p.ng_launch);
+    const int tile = blockIdx.x / ((p.nf + 1) * p.ng_launch);
+    const int widx = tile * 64 + lane;
+    if (widx >= p.nwave) return;                 // (no barrier below: every lane is a chain of its own)
+    const double pi = 3.141592653589793;
+    // the stack below the current layer, [element][lane]
+    double *rc = sm + lane, *tc = rc + NN * 64, *jc = tc + NN * 64;
+#define LS(Mx, e) Mx[(e) * 64]
+    const bool lookup = p.lookup != 0;
+    typename M::Vec radg;
+#pragma unroll
+    for (int i = 0; i < N; ++i) radg[i] = p.radg[(size_t)widx * N + (N - 1 - i)];   // radg[:, ::-1] :765
+    bool defined = false;
+    if (p.lowbc > 0 && !lookup) {  // surface operator first :824-836
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                LS(rc, i * N + j) = (2. * (p.brdf[(((size_t)widx * N + i) * N + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
+                LS(tc, i * N + j) = 0.0;
+            }
+#pragma unroll
+        for (int i = 0; i < N; ++i) LS(jc, i) = radg[i];
+        defined = true;
+    }
+    const double *PPL = p.ppl + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * NN;
+    const double *PMI = p.pmi + (((size_t)widx * (p.nf + 1) + ic) * p.ncomp) * NN;
+    const double *FC = p.fc + (((size_t)ig * p.nwave + widx) * p.ncomp) * NN;   // ppl *= fc (:232)
+
+    typename M::Mat r1, t1, m0, m2, m3;
+    typename M::Vec j1, v0, v1;
+    for (int l = 0; l < p.nlay; ++l) {
+        const int k = lookup ? p.nlay - 1 - l : l;  // look-down: bottom layer first (:842-845)
+        const double taut = p.taus[((size_t)widx * p.ng + ig) * p.nlay + k];
+        const double bc = p.bnu[(size_t)widx * p.nlay + k];
+        double omega = p.omegas[((size_t)widx * p.ng + ig) * p.nlay + k];
+        if (omega < 0) omega = 0.0;
+        if (omega > 1) omega = 1.0;
+        double tauscat = taut * omega;
+        const double taur = p.tauray[(size_t)widx * p.nlay + k];
+        tauscat = tauscat - taur;
+        if (tauscat < 0) tauscat = 0.0;
+        // ---- calc_rtj_matrix :566-647 -> (r1, t1, j1), iscl ------------------------------------------------
+        int iscl = 0;
+        omega = (tauscat + taur) / taut;
+        if (taut == 0) {
+#pragma unroll
+            for (int e = 0; e < NN; ++e) { r1[e] = 0.0; t1[e] = ((e / N) == (e % N)) ? 1.0 : 0.0; }
+#pragma unroll
+            for (int i = 0; i < N; ++i) j1[i] = 0.0;
+        } else if (omega == 0) {
+#pragma unroll
+            for (int e = 0; e < NN; ++e) { r1[e] = 0.0; t1[e] = 0.0; }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double tex = -(1. / p.mu[i]) * taut;
+                const double tt = (tex > -200.0) ? exp(tex) : 0.0;
+                t1[i * N + i] = tt;
+                j1[i] = bc * (1.0 - tt);
+            }
+        } else {
+            iscl = 1;
+            const double fr = taur / (tauscat + taur), fs = tauscat / (tauscat + taur);
+            // ---- double1 :321-362 --------------------------------------------------------------------------
+            double con = omega * pi;
+            con *= (ic == 0) ? 2.0 : 1.0;
+            const int nd = (int)(log2(taut) + 12);   // python int(): truncation toward zero
+            const double tau0 = taut * ((nd >= 1) ? 1.0 / exp2((double)nd) : 1.0);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const int e = i * N + j;
+                    double a = (p.iray > 0) ? fr * (PPL[(size_t)p.ncont * NN + e] * FC[(size_t)p.ncont * NN + e]) : 0.0;
+                    double b = (p.iray > 0) ? fr * PMI[(size_t)p.ncont * NN + e] : 0.0;
+                    for (int c = 0; c < p.ncont; ++c) {
+                        const double f = p.lfrac[((size_t)widx * p.ncont + c) * p.nlay + k];
+                        a += fs * (PPL[(size_t)c * NN + e] * FC[(size_t)c * NN + e]) * f;
+                        b += fs * PMI[(size_t)c * NN + e] * f;
+                    }
+                    // Gamma++ = M^-1 (E - con P++ C) ;  Gamma+- = M^-1 con P+- C   (C, M^-1 diagonal)
+                    const double gpp = (1. / p.mu[i]) * (((i == j) ? 1.0 : 0.0) - (a * p.wtmu[j]) * con);
+                    const double gpm = (1. / p.mu[i]) * ((b * p.wtmu[j]) * con);
+                    t1[e] = ((i == j) ? 1.0 : 0.0) - tau0 * gpp;
+                    r1[e] = tau0 * gpm;
+                }
+#pragma unroll
+            for (int i = 0; i < N; ++i) j1[i] = (ic == 0) ? (1.0 - omega) * bc * tau0 * (1. / p.mu[i]) : 0.0;
+            for (int it = 0; it < nd; ++it) {   // add :275-297
+                M::mm(r1, r1, m0);                                    // bcom
+                M::acom(m0, M::frob(r1) > 0.1, m3, m2);               // acom = inv(e - bcom) or e + bcom
+                M::mm(t1, m2, m3);                                    // ccom = t1 acom
+                M::mm(m3, r1, m0);                                    // rans = ccom r1
+                M::mm(m0, t1, m2);                                    // acom = rans t1
+                M::mm(m3, t1, m0);                                    // tans = ccom t1
+                if (ic == 0) {
+                    M::mv(r1, j1, v0);                                // jcom = r1 j1 + j1
+#pragma unroll
+                    for (int i = 0; i < N; ++i) v0[i] = v0[i] + j1[i];
+                    M::mv(m3, v0, v1);                                // jans = ccom jcom + j1
+#pragma unroll
+                    for (int i = 0; i < N; ++i) j1[i] = v1[i] + j1[i];
+                }
+#pragma unroll
+                for (int e = 0; e < NN; ++e) { r1[e] = r1[e] + m2[e]; t1[e] = m0[e]; }
+            }
+        }
+        // ---- combine with the stack below :868-875 ------------------------------------------------------------
+        if (l == 0 && !defined) {
+#pragma unroll
+            for (int e = 0; e < NN; ++e) { LS(rc, e) = r1[e]; LS(tc, e) = t1[e]; }
+#pragma unroll
+            for (int i = 0; i < N; ++i) LS(jc, i) = j1[i];
+        } else if (iscl == 1) {   // addp, scattering layer :486-511 (rsub,tsub,jsub) = (rc,tc,jc)
+            typename M::Mat sub;
+#pragma unroll
+            for (int e = 0; e < NN; ++e) sub[e] = LS(rc, e);
+            M::mm(sub, r1, m0);                                       // rsq = rsub r1
+            M::acom(m0, M::frob(m0) > 0.01, m3, m2);
+            M::mm(t1, m2, m3);                                        // ccom = t1 acom
+            M::mm(m3, sub, m0);                                       // rans = ccom rsub
+            M::mm(m0, t1, m2);                                        // bcom = rans t1
+            M::mv(sub, j1, v0);                                       // jcom = rsub j1 + jsub
+#pragma unroll
+            for (int i = 0; i < N; ++i) v0[i] += LS(jc, i);
+            M::mv(m3, v0, v1);                                        // jans = ccom jcom + j1
+#pragma unroll
+            for (int i = 0; i < N; ++i) LS(jc, i) = v1[i] + j1[i];
+#pragma unroll
+            for (int e = 0; e < NN; ++e) { LS(rc, e) = r1[e] + m2[e]; sub[e] = LS(tc, e); }
+            M::mm(m3, sub, m0);                                       // tans = ccom tsub
+#pragma unroll
+            for (int e = 0; e < NN; ++e) LS(tc, e) = m0[e];
+        } else {                  // addp, non-scattering layer :513-530
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < N; ++kk) s += LS(rc, i * N + kk) * j1[kk];
+                v0[i] = s + LS(jc, i);
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const double ta = t1[i * N + i], tb = t1[j * N + j];
+                    LS(tc, i * N + j) = LS(tc, i * N + j) * ta;
+                    LS(rc, i * N + j) = LS(rc, i * N + j) * ta * tb;
+                }
+#pragma unroll
+            for (int i = 0; i < N; ++i) LS(jc, i) = j1[i] + t1[i * N + i] * v0[i];
+        }
+    }
+    typename M::Vec jcv;
+#pragma unroll
+    for (int i = 0; i < N; ++i) jcv[i] = (ic != 0) ? 0.0 : LS(jc, i);   // :881-882
+    // the stack of the whole atmosphere back into registers (r1 / t1 are free)
+#pragma unroll
+    for (int e = 0; e < NN; ++e) { r1[e] = LS(rc, e); t1[e] = LS(tc, e); }
+    const bool surface_up = lookup && p.lowbc > 0;
+    if (surface_up) {
+        // idown (:366-420) with rb = rs, tb = 0, jb = radg (js is set for every ic, :822):
+        //   upl = (E - rc rs)^-1 (tc u0+ + (rc radg + jc));   m3 = the inverse, v0 = rc radg + jc
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                m0[i * N + j] = (2. * (p.brdf[(((size_t)widx * N + i) * N + j) * (p.nf + 1) + ic] * pi) * p.mu[j] * p.wtmu[j]) * p.xfac;
+        M::mm(r1, m0, m2);
+#pragma unroll
+        for (int e = 0; e < NN; ++e) m2[e] = (((e / N) == (e % N)) ? 1.0 : 0.0) - m2[e];
+        M::inv(m2, m3);
+        M::mv(r1, radg, v0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v0[i] = v0[i] + jcv[i];
+    }
+    // (T radg)[imu] / (R radg)[imu] of the ic == 0 terms below
+    typename M::Vec trad, rrad;
+    M::mv(t1, radg, trad);
+    M::mv(r1, radg, rrad);
+    // ---- per path: the four (mu0, mu) samples and the bilinear interpolation :886-945 ---------------------------
+    for (int ipath = 0; ipath < p.ngeom; ++ipath) {
+        const double sol_ang = p.sol_ang[ipath];
+        const double emiss_ang = lookup ? 180. - p.emiss_ang[ipath] : p.emiss_ang[ipath];   // new_emi :900-903
+        double zmu0, solar1;
+        if (sol_ang > 90.0) { zmu0 = cos((180 - sol_ang) * pi / 180.0); solar1 = p.solar[widx] * 0.0; }
+        else { zmu0 = cos(sol_ang * pi / 180.0); solar1 = p.solar[widx]; }
+        const double zmu = cos(emiss_ang * pi / 180.0);
+        int isol = 0, iemm = 0;
+#pragma unroll
+        for (int j = 0; j < N - 1; ++j) if (zmu0 <= p.mu[j] && zmu0 > p.mu[j + 1]) isol = j;
+        if (zmu0 <= p.mu[N - 1]) isol = N - 2;
+#pragma unroll
+        for (int j = 0; j < N - 1; ++j) if (zmu <= p.mu[j] && zmu > p.mu[j + 1]) iemm = j;
+        if (zmu <= p.mu[N - 1]) iemm = N - 2;
+        // the quadrature points are compile-time positions: pick mu[isol], mu[isol + 1], ... with selects
+        double mus0 = 0, mus1 = 0, mue0 = 0, mue1 = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j == isol) mus0 = p.mu[j];
+            if (j == isol + 1) mus1 = p.mu[j];
+            if (j == iemm) mue0 = p.mu[j];
+            if (j == iemm + 1) mue1 = p.mu[j];
+        }
+        const double u = (mus0 - zmu0) / (mus0 - mus1);
+        const double t = (mue0 - zmu) / (mue0 - mue1);
+        double yx[4] = {0.0, 0.0, 0.0, 0.0};       // ico = 2 * (imu0 - isol) + (imu - iemm)
+#pragma unroll
+        for (int imu0 = 0; imu0 < N; ++imu0) {
+            const int a = imu0 - isol;
+            const double s0 = solar1 / (2.0 * pi * p.wtmu[imu0]);
+#pragma unroll
+            for (int imu = 0; imu < N; ++imu) {
+                const int b = imu - iemm;
+                double val;
+                if (!lookup) {
+                    const double bcom = (ic == 0) ? trad[imu] : 0.0;
+                    val = (r1[imu * N + imu0] * s0 + bcom) + jcv[imu];
+                } else if (p.lowbc == 0) {   // bottom of the atmosphere: T u0+ + R u- + J  (:929-933)
+                    const double bcom = (ic == 0) ? rrad[imu] : 0.0;
+                    val = (t1[imu * N + imu0] * s0 + bcom) + jcv[imu];
+                } else {
+                    double upl = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < N; ++kk) upl += m3[imu * N + kk] * (t1[kk * N + imu0] * s0 + v0[kk]);
+                    val = upl;
+                }
+                const bool in = (a == 0 || a == 1) && (b == 0 || b == 1);
+                const int ico = 2 * a + b;
+                if (in && ico == 0) yx[0] = val;
+                if (in && ico == 1) yx[1] = val;
+                if (in && ico == 2) yx[2] = val;
+                if (in && ico == 3) yx[3] = val;
+            }
+        }
+        double drad = ((1 - t) * (1 - u) * yx[0] + t * (1 - u) * yx[1] + t * u * yx[3] + (1 - t) * u * yx[2]) *
+                      cos(ic * p.aphi[ipath] * pi / 180.0);
+        if (ic > 0) drad *= 2;
+        p.drad[(((size_t)widx * p.ng + ig) * (p.nf + 1) + ic) * p.ngeom + ipath] = drad;
+    }
+#undef LS
+}
+
+}  // namespace ansfm

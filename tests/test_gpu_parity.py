@@ -1369,6 +1369,47 @@ def test_scloud11wave_core_deep_golden(eng, golden_dir, name):
     assert np.max(np.abs(rad - z["rad"])) / np.max(np.abs(z["rad"])) < 1e-8
 
 
+@pytest.mark.parametrize("nmu,lookup,lowbc", [(5, False, 0), (5, False, 1), (5, True, 0), (5, True, 1), (4, False, 1), (4, True, 1)])
+def test_few_streams_one_lane_per_chain_equals_one_wavefront_per_chain(eng, monkeypatch, nmu, lookup, lowbc):
+    """The reference's default quadrature (5 streams) runs one LANE per (wavenumber, g, order) chain with the matrices in
+    registers (k_ms_chain_lane); the wavefront-per-chain kernel (k_ms_chain<N>, LDS matrices; ANSFM_MS_LANE=0) does the same
+    operations in the same order: the same radiances -- bit for bit in most configurations, within one unit in the last place
+    where the compiler fuses the closing interpolation of the two kernels differently -- look-down and look-up, with and
+    without a Lambert surface, two aerosols + Rayleigh, three paths, layers without scattering and without opacity, a
+    wavenumber count that does not fill the last tile of 64."""
+    rng = np.random.default_rng(50 + nmu + 2 * int(lookup) + lowbc)
+    W, G, L, NF, ncont, nth = 150, 3, 14, 3, 2, 31
+    MU, WT = _c4_quadrature(nmu)
+    TH = np.linspace(0.0, 180.0, nth); cth = np.cos(np.deg2rad(TH))
+    ph = np.zeros((ncont, W, 2, nth))
+    for c in range(ncont):
+        g = 0.3 + 0.35 * c + 0.1 * np.sin(np.arange(W) / 9.0)
+        ph[c, :, 0, :] = (1 - g[:, None] ** 2) / (1 + g[:, None] ** 2 - 2 * g[:, None] * cth[None, :]) ** 1.5 / (4 * np.pi)
+        ph[c, :, 1, :] = cth[None, :]
+    ph = np.ascontiguousarray(ph[:, :, :, ::-1])
+    taus = 10.0 ** rng.uniform(-4, 1.2, (W, G, L))
+    omegas = rng.uniform(0.05, 0.98, (W, G, L))
+    tauray = 0.2 * taus[:, 0, :] * omegas[:, 0, :] * rng.uniform(0, 1, (W, L))
+    omegas[:, :, 3] = 0.0; tauray[:, 3] = 0.0              # a layer that only absorbs
+    taus[:, :, 7] = 0.0; tauray[:, 7] = 0.0                # an empty layer
+    lfrac = rng.uniform(0.1, 1.0, (W, ncont, L)); lfrac /= lfrac.sum(axis=1, keepdims=True)
+    WAVE = 500.0 + np.arange(W)
+    bnu = 1e-7 * rng.uniform(0.5, 1.5, (W, L))
+    radg = 1e-7 * rng.uniform(0.5, 1.5, (W, nmu))
+    emi = np.array([20.0, 47.0, 71.0]); emi = 180.0 - emi if lookup else emi
+    sol = np.array([30.0, 60.0, 100.0]); aph = np.array([0.0, 45.0, 130.0])
+    brdf = np.zeros((W, nmu, nmu, NF + 1)); brdf[:, :, :, 0] = 0.3 / np.pi
+    args = (ph, radg, sol, emi, np.full(W, 1e-6), aph, lowbc, brdf, MU, WT, NF, WAVE, bnu, taus, tauray, omegas, 101, 1, 1, lfrac)
+    monkeypatch.delenv("ANSFM_MS_LANE", raising=False)
+    by_lane = eng.scloud11wave_core(*args)
+    monkeypatch.setenv("ANSFM_MS_LANE", "0")
+    by_wave = eng.scloud11wave_core(*args)
+    monkeypatch.delenv("ANSFM_MS_LANE", raising=False)
+    assert by_lane.shape == (3, G, W) and np.all(np.isfinite(by_lane)) and np.abs(by_lane).max() > 0
+    np.testing.assert_allclose(by_lane, by_wave, rtol=4 * np.finfo(float).eps, atol=0)
+    assert np.mean(by_lane == by_wave) > 0.98
+
+
 def _c4_quadrature(nmu):
     x, w = np.polynomial.legendre.leggauss(nmu)              # Gauss-Legendre on (0, 1): sum(mu w) = 1/2 exactly
     return 0.5 * (x + 1.0), 0.5 * w
