@@ -2246,13 +2246,15 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
         HIPCHK(hipGetLastError());
     }
     p.hansen_comp0 = 0;
-    // the walk's kernel by quadrature size: 16 (the matrix-core chain's), 5 (the reference's default, Scatter_0.py:59), 8; any
-    // other size takes the run-time build
+    // the walk's kernel by quadrature size: 16 (the matrix-core chain's), 5 (the reference's default, Scatter_0.py:59), 4, 6, 8;
+    // any other size takes the run-time build
     auto launch_hansen = [&](hipStream_t st, const MsParams &pp) {
         const dim3 hg((unsigned)ncomp_run), hb(64);
         switch (nmu) {
         case 16: hipLaunchKernelGGL(k_ms_hansen_seq<16>, hg, hb, 0, st, pp); break;
+        case 4: hipLaunchKernelGGL(k_ms_hansen_seq<4>, hg, hb, 0, st, pp); break;
         case 5: hipLaunchKernelGGL(k_ms_hansen_seq<5>, hg, hb, 0, st, pp); break;
+        case 6: hipLaunchKernelGGL(k_ms_hansen_seq<6>, hg, hb, 0, st, pp); break;
         case 8: hipLaunchKernelGGL(k_ms_hansen_seq<8>, hg, hb, 0, st, pp); break;
         default: hipLaunchKernelGGL(k_ms_hansen_seq<0>, hg, hb, 0, st, pp); break;
         }
@@ -2347,7 +2349,7 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
         // ANSFM_MS_LANE=0: the wavefront-per-chain kernel for these sizes too
         const char *lane_env = getenv("ANSFM_MS_LANE");            // read per call: the tests compare the two kernels
         const bool lane_off = lane_env && lane_env[0] == '0';
-        const bool by_lane = !lane_off && (nmu == 4 || nmu == 5);      // (6 streams: 393 spilled registers, not offered)
+        const bool by_lane = !lane_off && (nmu == 4 || nmu == 5 || nmu == 6);
         const size_t ldsl = (size_t)(2 * nn + nmu) * 64 * D;
         auto launch_chain_n = [&](dim3 grid, hipStream_t st, const MsParams &pp) {
             if (by_lane) {
@@ -2355,7 +2357,8 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
                 const dim3 gl((unsigned)((nwave + 63) / 64) * ngl * (unsigned)(nf + 1));
                 switch (nmu) {
                 case 4: hipLaunchKernelGGL(k_ms_chain_lane<4>, gl, dim3(64), ldsl, st, pp); break;
-                default: hipLaunchKernelGGL(k_ms_chain_lane<5>, gl, dim3(64), ldsl, st, pp); break;
+                case 5: hipLaunchKernelGGL(k_ms_chain_lane<5>, gl, dim3(64), ldsl, st, pp); break;
+                default: hipLaunchKernelGGL(k_ms_chain_lane<6>, gl, dim3(64), ldsl, st, pp); break;
                 }
                 return;
             }

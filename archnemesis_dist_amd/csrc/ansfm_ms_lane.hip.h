@@ -11,6 +11,10 @@
 // -- first largest |.| --, the reference's thresholds); the pivot row, which depends on the lane, is handled with selects over
 // compile-time rows, never with a run-time register index (that would send the matrices to scratch memory).
 // Output: p.drad like k_ms_chain; k_ms_fourier sums the orders.
+// Registers: 4 streams 392 (no spills), 5 streams 512 with 68 spilled, 6 streams 512 with 393 spilled -- one wave per SIMD in
+// every case.  C4 size (1e4 wavenumbers x 20 g x 100 layers, NF = 2), this kernel / k_ms_chain<N>: 4 streams 0.095 / 0.24 s,
+// 5 streams 0.12 / 0.21 s, 6 streams 0.20 / 0.28 s; at 5 streams what is left is the sequential Hansen walk (4.7 ms per
+// g-ordinate: 94 of the 113 ms).
 #pragma once
 #include "ansfm_ms_kernels.hip.h"
 

@@ -1369,7 +1369,8 @@ def test_scloud11wave_core_deep_golden(eng, golden_dir, name):
     assert np.max(np.abs(rad - z["rad"])) / np.max(np.abs(z["rad"])) < 1e-8
 
 
-@pytest.mark.parametrize("nmu,lookup,lowbc", [(5, False, 0), (5, False, 1), (5, True, 0), (5, True, 1), (4, False, 1), (4, True, 1)])
+@pytest.mark.parametrize("nmu,lookup,lowbc", [(5, False, 0), (5, False, 1), (5, True, 0), (5, True, 1), (4, False, 1), (4, True, 1),
+                                              (6, False, 1), (6, True, 0)])
 def test_few_streams_one_lane_per_chain_equals_one_wavefront_per_chain(eng, monkeypatch, nmu, lookup, lowbc):
     """The reference's default quadrature (5 streams) runs one LANE per (wavenumber, g, order) chain with the matrices in
     registers (k_ms_chain_lane); the wavefront-per-chain kernel (k_ms_chain<N>, LDS matrices; ANSFM_MS_LANE=0) does the same
