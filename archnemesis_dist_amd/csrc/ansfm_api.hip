@@ -73,6 +73,7 @@ struct ansfm_ctx {
     DevBuf li, tau, scratch, cont_t, tmp_in, tmp_out, misc;
     DevBuf dspec_ref, map_out, map_b, map_batch;
     DevBuf dd_slot, dd_work, dd_in;      // layer de-duplication: row map [n][L], work list, packed inputs
+    int ms_reuse_walk = 0;               // scattering, model-by-model batches: phase matrices + Hansen factors of the previous call stand
     DevBuf rt_prefix, rt_same;           // thermal RT of a batch: state 0's records along every path; same flags [n][L] + jstart [n][P]
     int last_rt_shared = 0;
     int dedup = 1;                       // ansfm_set_layer_dedup
@@ -2225,7 +2226,11 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     HIPCHK(ctx->misc.reserve((2 * nph + nfc) * D));
     HIPCHK(ctx->tmp_in2.reserve((size_t)nwave * ng * (nf + 1) * ngeom * D));
     HIPCHK(ctx->tmp_out.reserve((size_t)ngeom * ng * nwave * D));
-    HIPCHK(hipMemsetAsync(ctx->misc.p, 0, (2 * nph + nfc) * D, ctx->stream));
+    // reuse: the models of a batch run one by one (ansfm_cirsrad_ck_scatter_batch without the layer cache) share the phase
+    // functions, so the phase matrices and the Hansen factors the first model left in ctx->misc stand for the others -- the
+    // walk is sequential and, at few streams, most of a call
+    const bool reuse = ctx->ms_reuse_walk != 0 && !prepare_only;
+    if (!reuse) HIPCHK(hipMemsetAsync(ctx->misc.p, 0, (2 * nph + nfc) * D, ctx->stream));
     p.ppl = ctx->misc.as<double>(); p.pmi = p.ppl + nph; p.fc = p.pmi + nph;
     p.drad = ctx->tmp_in2.as<double>();
     p.rad = ctx->tmp_out.as<double>();
@@ -2234,7 +2239,7 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     size_t phase_lds_bytes = (size_t)(nf + 2) * (nphi + 1) * D;       // cos(ic phi_k) for every order and azimuth point
     p.phase_tab = phase_lds_bytes <= 48 * 1024 ? 1 : 0;
     if (!p.phase_tab) phase_lds_bytes = 0;
-    if (ncomp_run > 0) {
+    if (ncomp_run > 0 && !reuse) {
         // Rayleigh lives in slot ncont even when there are no aerosols
         if (ncont > 0)
             hipLaunchKernelGGL(k_ms_phase, dim3((unsigned)nwave, (unsigned)ncont), dim3(256), phase_lds_bytes, ctx->stream, p);
@@ -2335,7 +2340,7 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
             if (pp.phase_lds) hipLaunchKernelGGL(k_ms_chain16<true>, dim3(grid), dim3(64), lds16, st, pp);
             else hipLaunchKernelGGL(k_ms_chain16<false>, dim3(grid), dim3(64), lds16, st, pp);
         };
-        if (ncomp_run > 0) {
+        if (ncomp_run > 0 && !reuse) {
             const int rc = per_g_ordinate([&](hipStream_t cs, const MsParams &pc) { launch_chain((unsigned)nwave, cs, pc); });
             if (rc != ANSFM_OK) return rc;
         } else {
@@ -2368,7 +2373,7 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
             default: hipLaunchKernelGGL(k_ms_chain<0>, grid, dim3(64), ldsg, st, pp); break;
             }
         };
-        if (ncomp_run > 0) {
+        if (ncomp_run > 0 && !reuse) {
             const int rc = per_g_ordinate([&](hipStream_t cs, const MsParams &pc) {
                 launch_chain_n(dim3((unsigned)((size_t)nwave * (nf + 1))), cs, pc);
             });
@@ -2549,12 +2554,14 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
         // other stream counts, a single model, or de-duplication switched off (ansfm_set_layer_dedup): model by model
         for (int m = 0; m < n_models; ++m) {
             auto at = [&](const double *a, size_t per) { return a ? a + (size_t)m * per : nullptr; };
+            ctx->ms_reuse_walk = (m > 0) ? 1 : 0;       // same phase functions, quadrature, orders: model 0's walk stands
             const int rc = ansfm_cirsrad_ck_scatter(ctx, ISPACE, L, lay_press_pa + (size_t)m * L, lay_temp + (size_t)m * L,
                                                     amount + (size_t)m * S * L, at(taucia, WL), at(taudust, WL), at(tauray, WL),
                                                     at(tauscat, WL), ncont, nth, phasarr, at(lfrac, WL * ncont),
                                                     radg + (size_t)m * W * nmu, ngeom, sol_angs, emiss_angs, aphis, solar, lowbc,
                                                     brdf_matrix, nmu, mu1, wt1, nf, nphi, iray, imie, xfac,
                                                     SPECOUT + (size_t)m * W * ngeom, nullptr);
+            ctx->ms_reuse_walk = 0;
             if (rc) return rc;
         }
         ctx->last_n = n_models; ctx->last_L = L; ctx->last_rows = n_models * L; ctx->last_dedup = 0;

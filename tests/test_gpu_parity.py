@@ -1301,6 +1301,33 @@ def test_cirsrad_scatter_batch_equals_separate_calls(eng, monkeypatch, ncont, im
     assert np.array_equal(again, ref)
 
 
+@pytest.mark.parametrize("NMU", [5, 8, 12])
+def test_cirsrad_scatter_batch_other_stream_counts_equal_separate_calls(eng, NMU):
+    """Other stream counts than 16 (5 = the reference's default: the lane-per-chain kernel; 8: the wavefront-per-chain kernel
+    with compile-time sizes; 12: its run-time build): the models of a batch run one after the other, models 1.. on the phase
+    matrices and Hansen factors model 0 left behind (they depend on the phase functions, not on the model) -- every spectrum
+    equal to a call of its own bit for bit, also when a single call came in between and the batch is repeated."""
+    rng = np.random.default_rng(9100 + NMU)
+    W, G, L, S, NF = 70, 4, 8, 3, 2
+    z = _scatter_inputs(rng, W, G, L, S, NMU, NF, 2, 1, 1, 1)
+    sol = np.array([30.0, 75.0]); emi = np.array([20.0, 50.0]); azi = np.array([45.0, 10.0])
+    eng.upload_ktable(z["K"], z["TPRESS"], z["TTEMP"], z["WAVE"], z["DELG"])
+    n = 4
+    rep = lambda a: np.repeat(np.asarray(a)[None], n, 0).copy()
+    lp, lt, am = rep(z["lay_p"]), rep(z["lay_t"]), rep(z["amount"])
+    cia, dust, ray, sca = rep(z["TAUCIA"]), rep(z["TAUDUST"]), rep(z["TAURAY"]), rep(z["TAUSCAT"])
+    lf, rg = rep(z["lfrac"]), rep(z["radg"])
+    lt[1, 4] *= 1.05; am[2, 1, 6] *= 1.05; sca[3, :, 3] *= 1.05; dust[3, :, 3] *= 1.05
+    tail = (sol, emi, azi, z["solar"], 1, z["brdf"], z["MU"], z["WT"], NF, 101, 1, 1)
+    one = lambda m: eng.cirsrad_ck_scatter(0, lp[m], lt[m], am[m], cia[m], dust[m], ray[m], sca[m], z["phasarr"], lf[m], rg[m], *tail)
+    ref = np.stack([one(m) for m in range(n)])
+    got = eng.cirsrad_ck_scatter_batch(0, lp, lt, am, cia, dust, ray, sca, z["phasarr"], lf, rg, *tail)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(one(2), ref[2])                       # a single call afterwards starts from its own walk again
+    assert np.array_equal(eng.cirsrad_ck_scatter_batch(0, lp, lt, am, cia, dust, ray, sca, z["phasarr"], lf, rg, *tail), ref)
+    assert not np.array_equal(ref[1], ref[0]) and not np.array_equal(ref[3], ref[0])
+
+
 def test_cirsrad_scatter_more_than_sixteen_paths(eng):
     """Twenty paths -- four more than one call of the chain kernels takes (one path per lane of a 16-lane row): the engine
     runs them in groups, each path's spectrum equal to the one it gets in a call of its own group of <= 16."""
