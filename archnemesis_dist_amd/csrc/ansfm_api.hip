@@ -2549,7 +2549,9 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
     const size_t D = sizeof(double), WL = (size_t)W * L;
     ctx->ms_cache_hits = 0; ctx->ms_cache_layers = (long)n_models * L;
     const char *ev_off = getenv("ANSFM_MS_LAYER_CACHE");
-    const bool use_cache = nmu == 16 && n_models > 1 && ctx->dedup && !(ev_off && atoi(ev_off) == 0);
+    const char *ev_lane = getenv("ANSFM_MS_LANE");
+    const bool lane_n = (nmu == 4 || nmu == 5 || nmu == 6) && !(ev_lane && ev_lane[0] == '0');   // k_ms_chain_lane<N, CACHE>
+    const bool use_cache = (nmu == 16 || lane_n) && n_models > 1 && ctx->dedup && !(ev_off && atoi(ev_off) == 0);
     if (!use_cache) {
         // other stream counts, a single model, or de-duplication switched off (ansfm_set_layer_dedup): model by model
         for (int m = 0; m < n_models; ++m) {
@@ -2685,6 +2687,89 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
     if ((rc = ms_launch(ctx, p, ncont, W, nth, ngeom, sol_angs, emiss_angs, aphis, lowbc, nmu, mu1, wt1, nf, G, L, nphi, iray,
                         imie, true)))
         return rc;
+    if (lane_n) {
+        // ---- few streams: one lane per chain (ansfm_ms_lane.hip.h).  Model 0's doubled layers per (tile of 64 wavenumbers, g,
+        //      order, layer), the other models run the adding sweep over them; every Fourier order is worked through and
+        //      k_ms_fourier applies the reference's convergence break per model.  No prefix stacks: the adding sweep is a few
+        //      per cent of a chain here.
+        const int nn = nmu * nmu;
+        const size_t entry_w = (size_t)(2 * nn + nmu);                              // doubles per (wavenumber, g, order, layer)
+        const size_t per_tile = (size_t)G * (nf + 1) * L * entry_w * 64 * D;
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        free_b += ctx->ms_cache.bytes;
+        const size_t budget = std::min<size_t>(free_b / 2, (size_t)96 << 30);
+        long tiles = (long)(budget / per_tile);
+        if (const char *ev = getenv("ANSFM_MS_SLAB")) { const long v = atol(ev); if (v >= 1) tiles = std::min(tiles, (v + 63) / 64); }
+        if (tiles < 1) FAIL(ANSFM_ERR_HIP, "cirsrad_ck_scatter_batch: no memory for the layer cache of one tile of wavenumbers");
+        const long Ws = std::min<long>((long)W, tiles * 64);
+        int mchunk = std::min(n_models - 1, 64);
+        if (const char *ev = getenv("ANSFM_MS_CHUNK")) { const int v = atoi(ev); if (v >= 1) mchunk = std::min(n_models - 1, v); }
+        HIPCHK(ctx->ms_cache.reserve((size_t)((Ws + 63) / 64) * per_tile));
+        const size_t opt_models = (size_t)std::max(1, mchunk);
+        HIPCHK(ctx->ms_taus.reserve(opt_models * Ws * G * L * D));
+        HIPCHK(ctx->ms_omegas.reserve(opt_models * Ws * G * L * D));
+        HIPCHK(ctx->ms_bnu.reserve(opt_models * Ws * L * D));
+        const size_t st_drad = (size_t)W * G * (nf + 1) * ngeom;
+        HIPCHK(ctx->tmp_in2.reserve((size_t)n_models * st_drad * D));
+        HIPCHK(ctx->tmp_out.reserve((size_t)n_models * ngeom * G * W * D));
+        p.drad = ctx->tmp_in2.as<double>(); p.st_drad = st_drad;
+        p.rad = ctx->tmp_out.as<double>();
+        p.taus = ctx->ms_taus.as<double>(); p.omegas = ctx->ms_omegas.as<double>(); p.bnu = ctx->ms_bnu.as<double>();
+        p.cache = ctx->ms_cache.as<double>(); p.same = same;
+        p.model_ids = ctx->ms_lstart.as<int>() + n_models;
+        p.st_wl = st_wl; p.st_wcl = (size_t)W * ncont * L; p.st_wm = (size_t)W * nmu; p.st_rad = (size_t)ngeom * G * W;
+        p.ig0 = 0; p.ng_launch = G;
+        MsOpticsBatchParams o;
+        memset(&o, 0, sizeof o);
+        o.taugas = ctx->tau.as<double>(); o.slot = ctx->dd_slot.as<int32_t>();
+        o.taucia = (const double *)d[3]; o.taudust = (const double *)d[4]; o.tauray = (const double *)d[5]; o.tauscat = (const double *)d[6];
+        o.wave = ctx->d_wave.as<double>(); o.lay_temp = (const double *)d[1];
+        o.taus = ctx->ms_taus.as<double>(); o.omegas = ctx->ms_omegas.as<double>(); o.bnu = ctx->ms_bnu.as<double>();
+        o.W = W; o.Wpad = Wpad; o.G = G; o.L = L; o.ispace = ISPACE;
+        const size_t ldsl = (size_t)(2 * nn + nmu) * 64 * D;
+        auto lane_launch = [&](int cache, unsigned grid) {
+            const dim3 g(grid), b(64);
+            if (nmu == 4) { if (cache == 1) hipLaunchKernelGGL((k_ms_chain_lane<4, 1>), g, b, ldsl, ctx->stream, p); else hipLaunchKernelGGL((k_ms_chain_lane<4, 2>), g, b, ldsl, ctx->stream, p); }
+            else if (nmu == 5) { if (cache == 1) hipLaunchKernelGGL((k_ms_chain_lane<5, 1>), g, b, ldsl, ctx->stream, p); else hipLaunchKernelGGL((k_ms_chain_lane<5, 2>), g, b, ldsl, ctx->stream, p); }
+            else { if (cache == 1) hipLaunchKernelGGL((k_ms_chain_lane<6, 1>), g, b, ldsl, ctx->stream, p); else hipLaunchKernelGGL((k_ms_chain_lane<6, 2>), g, b, ldsl, ctx->stream, p); }
+        };
+        for (long w0 = 0; w0 < W; w0 += Ws) {
+            const int wc = (int)std::min<long>(Ws, W - w0);
+            const size_t per_model = (size_t)((wc + 63) / 64) * G * (nf + 1);
+            p.w0 = (int)w0; p.wcount = wc;
+            o.w0 = (int)w0; o.wcount = wc;
+            o.m0 = 0; o.nm = 1; o.model_ids = nullptr;
+            hipLaunchKernelGGL(k_ms_optics_batch, dim3(nblk((size_t)wc, 128), (unsigned)L, 1), dim3(128), 0, ctx->stream, o);
+            p.m0 = 0; p.n_launch = 1;
+            lane_launch(1, (unsigned)per_model);
+            HIPCHK(hipGetLastError());
+            for (int m0 = 1; m0 < n_models; m0 += mchunk) {
+                const int nm = std::min(mchunk, n_models - m0);
+                o.m0 = m0; o.nm = nm; o.model_ids = p.model_ids;
+                hipLaunchKernelGGL(k_ms_optics_batch, dim3(nblk((size_t)wc, 128), (unsigned)L, (unsigned)nm), dim3(128), 0, ctx->stream, o);
+                p.m0 = m0; p.n_launch = nm;
+                if (per_model * (size_t)nm > 0x7FFFFFFFull) FAIL(ANSFM_ERR_UNSUPPORTED, "cirsrad_ck_scatter_batch: slab x models too large for one launch");
+                lane_launch(2, (unsigned)(per_model * (size_t)nm));
+                HIPCHK(hipGetLastError());
+            }
+        }
+        // Fourier sum with the reference's convergence break, model by model, then the g-quadrature
+        const size_t nspec = (size_t)W * ngeom;
+        HIPCHK(ctx->tmp_out2.reserve((size_t)n_models * nspec * D));
+        for (int m = 0; m < n_models; ++m) {
+            MsParams pf = p;
+            pf.drad = p.drad + (size_t)m * st_drad; pf.rad = p.rad + (size_t)m * p.st_rad;
+            hipLaunchKernelGGL(k_ms_fourier, dim3(nblk((size_t)W * G * ngeom, 128)), dim3(128), 0, ctx->stream, pf);
+            hipLaunchKernelGGL(k_ms_gquad, dim3(nblk(nspec, 128)), dim3(128), 0, ctx->stream,
+                               ctx->tmp_out.as<double>() + (size_t)m * p.st_rad, ctx->d_delg.as<double>(), (const double *)d[12],
+                               ctx->tmp_out2.as<double>() + (size_t)m * nspec, (double *)nullptr, W, G, ngeom);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(SPECOUT, ctx->tmp_out2.p, (size_t)n_models * nspec * D, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return ANSFM_OK;
+    }
     // ---- slabs of the spectral axis sized by the layer cache ----------------------------------------------------------------
     const size_t per_w_layers = (size_t)G * (nf + 1) * L * kMsCacheEntry * D, per_w_pre = (size_t)G * (nf + 1) * npre * kMsCacheEntry * D;
     const size_t per_w = per_w_layers + per_w_pre;

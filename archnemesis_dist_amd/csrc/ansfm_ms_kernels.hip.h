@@ -66,6 +66,7 @@ struct MsParams {
                              // layers at about the same time and find model 0's cache lines in L2); model of block ml = ids[m0 + ml]
     int npre;
     size_t st_wl, st_wcl, st_wm, st_rad;   // strides between models: tauray [W][L], lfrac [W][ncont][L], radg [W][nmu], rad
+    size_t st_drad;                        // ... and drad (k_ms_chain_lane<N, CACHE> leaves the orders to k_ms_fourier)
 };
 constexpr int kMsCacheEntry = 528;   // doubles per cached layer: r (256) and t (256) in the MFMA accumulator layout, j (16)
 constexpr int kMsPrefixStep = 4;     // the stack below is kept after sweep layers 3, 7, 11, ...

@@ -107,18 +107,30 @@ template <int N> struct MsLane {
 };
 
 // grid: ((wavenumber tiles of 64) * ng_launch * (nf + 1)) blocks of 64 lanes; dynamic LDS (2 N^2 + N) * 64 doubles
-template <int N>
+// CACHE (the batched numerical Jacobian, ansfm_cirsrad_ck_scatter_batch; see k_ms_chain16): 1 = model 0's pass over the slab
+// [w0, w0 + wcount) stores the doubled (r1, t1, j1) of every scattering layer, [tile][g][order][layer][2 N^2 + N][64 lanes];
+// 2 = the models [m0, m0 + n_launch) of a launch (grid x n_launch) take the layers that are flagged `same` from there and
+// run the adding sweep only.  Same numbers either way.
+template <int N> constexpr int kMsLaneEntry = (2 * N * N + N) * 64;      // doubles per cached (tile, g, order, layer)
+
+template <int N, int CACHE = 0>
 __global__ __launch_bounds__(64) void k_ms_chain_lane(MsParams p)
 {
     typedef MsLane<N> M;
     constexpr int NN = N * N;
     extern __shared__ double sm[];
     const int lane = threadIdx.x;
-    const int ic = blockIdx.x % (p.nf + 1);
-    const int ig = p.ig0 + (int)((blockIdx.x / (p.nf + 1)) % p.ng_launch);
-    const int tile = blockIdx.x / ((p.nf + 1) * p.ng_launch);
-    const int widx = tile * 64 + lane;
-    if (widx >= p.nwave) return;                 // (no barrier below: every lane is a chain of its own)
+    const int ntile = (p.wcount + 63) / 64;
+    const int per_model = ntile * p.ng_launch * (p.nf + 1);
+    const int ml = (CACHE == 2) ? (int)(blockIdx.x / per_model) : 0;           // position in the launch
+    const int rest = (CACHE == 2) ? (int)(blockIdx.x % per_model) : (int)blockIdx.x;
+    const int mg = (CACHE == 2) ? p.model_ids[p.m0 + ml] : p.m0;               // model (0 outside the batch path)
+    const int ic = rest % (p.nf + 1);
+    const int ig = p.ig0 + (int)((rest / (p.nf + 1)) % p.ng_launch);
+    const int tile = rest / ((p.nf + 1) * p.ng_launch);
+    const int wl = tile * 64 + lane;                                           // wavenumber within the slab
+    const int widx = p.w0 + wl;
+    if (wl >= p.wcount) return;                  // (no barrier below: every lane is a chain of its own)
     const double pi = 3.141592653589793;
     // the stack below the current layer, [element][lane]
     double *rc = sm + lane, *tc = rc + NN * 64, *jc = tc + NN * 64;
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(64) void k_ms_chain_lane(MsParams p)
     const bool lookup = p.lookup != 0;
     typename M::Vec radg;
 #pragma unroll
-    for (int i = 0; i < N; ++i) radg[i] = p.radg[(size_t)widx * N + (N - 1 - i)];   // radg[:, ::-1] :765
+    for (int i = 0; i < N; ++i) radg[i] = p.radg[(size_t)mg * p.st_wm + (size_t)widx * N + (N - 1 - i)];   // radg[:, ::-1] :765
     bool defined = false;
     if (p.lowbc > 0 && !lookup) {  // surface operator first :824-836
 #pragma unroll
@@ -146,15 +158,20 @@ __global__ __launch_bounds__(64) void k_ms_chain_lane(MsParams p)
 
     typename M::Mat r1, t1, m0, m2, m3;
     typename M::Vec j1, v0, v1;
+    // taus / omegas / bnu: [model of the launch][wavenumber of the slab]; the other per-wavenumber arrays keep the whole axis
+    const size_t wrow = (size_t)ml * p.wcount + wl;
+    const double *taus_w = p.taus + (wrow * p.ng + ig) * p.nlay, *omegas_w = p.omegas + (wrow * p.ng + ig) * p.nlay;
+    const double *bnu_w = p.bnu + wrow * p.nlay, *tauray_w = p.tauray + (size_t)mg * p.st_wl + (size_t)widx * p.nlay;
+    const double *lfrac_m = p.lfrac + (size_t)mg * p.st_wcl;
     for (int l = 0; l < p.nlay; ++l) {
         const int k = lookup ? p.nlay - 1 - l : l;  // look-down: bottom layer first (:842-845)
-        const double taut = p.taus[((size_t)widx * p.ng + ig) * p.nlay + k];
-        const double bc = p.bnu[(size_t)widx * p.nlay + k];
-        double omega = p.omegas[((size_t)widx * p.ng + ig) * p.nlay + k];
+        const double taut = taus_w[k];
+        const double bc = bnu_w[k];
+        double omega = omegas_w[k];
         if (omega < 0) omega = 0.0;
         if (omega > 1) omega = 1.0;
         double tauscat = taut * omega;
-        const double taur = p.tauray[(size_t)widx * p.nlay + k];
+        const double taur = tauray_w[k];
         tauscat = tauscat - taur;
         if (tauscat < 0) tauscat = 0.0;
         // ---- calc_rtj_matrix :566-647 -> (r1, t1, j1), iscl ------------------------------------------------
@@ -175,6 +192,14 @@ __global__ __launch_bounds__(64) void k_ms_chain_lane(MsParams p)
                 t1[i * N + i] = tt;
                 j1[i] = bc * (1.0 - tt);
             }
+        } else if (CACHE == 2 && p.same[(size_t)mg * p.nlay + k]) {
+            // the layer of model 0, as its own pass left it (the flag is uniform over the wave: it belongs to the model's layer)
+            iscl = 1;
+            const double *ce = p.cache + ((((size_t)tile * p.ng + ig) * (p.nf + 1) + ic) * p.nlay + k) * kMsLaneEntry<N> + lane;
+#pragma unroll
+            for (int e = 0; e < NN; ++e) { r1[e] = ce[(size_t)e * 64]; t1[e] = ce[(size_t)(NN + e) * 64]; }
+#pragma unroll
+            for (int i = 0; i < N; ++i) j1[i] = ce[(size_t)(2 * NN + i) * 64];
         } else {
             iscl = 1;
             const double fr = taur / (tauscat + taur), fs = tauscat / (tauscat + taur);
@@ -191,7 +216,7 @@ __global__ __launch_bounds__(64) void k_ms_chain_lane(MsParams p)
                     double a = (p.iray > 0) ? fr * (PPL[(size_t)p.ncont * NN + e] * FC[(size_t)p.ncont * NN + e]) : 0.0;
                     double b = (p.iray > 0) ? fr * PMI[(size_t)p.ncont * NN + e] : 0.0;
                     for (int c = 0; c < p.ncont; ++c) {
-                        const double f = p.lfrac[((size_t)widx * p.ncont + c) * p.nlay + k];
+                        const double f = lfrac_m[((size_t)widx * p.ncont + c) * p.nlay + k];
                         a += fs * (PPL[(size_t)c * NN + e] * FC[(size_t)c * NN + e]) * f;
                         b += fs * PMI[(size_t)c * NN + e] * f;
                     }
@@ -220,6 +245,13 @@ __global__ __launch_bounds__(64) void k_ms_chain_lane(MsParams p)
                 }
 #pragma unroll
                 for (int e = 0; e < NN; ++e) { r1[e] = r1[e] + m2[e]; t1[e] = m0[e]; }
+            }
+            if constexpr (CACHE == 1) {
+                double *ce = p.cache + ((((size_t)tile * p.ng + ig) * (p.nf + 1) + ic) * p.nlay + k) * kMsLaneEntry<N> + lane;
+#pragma unroll
+                for (int e = 0; e < NN; ++e) { ce[(size_t)e * 64] = r1[e]; ce[(size_t)(NN + e) * 64] = t1[e]; }
+#pragma unroll
+                for (int i = 0; i < N; ++i) ce[(size_t)(2 * NN + i) * 64] = j1[i];
             }
         }
         // ---- combine with the stack below :868-875 ------------------------------------------------------------
@@ -353,7 +385,7 @@ __global__ __launch_bounds__(64) void k_ms_chain_lane(MsParams p)
         double drad = ((1 - t) * (1 - u) * yx[0] + t * (1 - u) * yx[1] + t * u * yx[3] + (1 - t) * u * yx[2]) *
                       cos(ic * p.aphi[ipath] * pi / 180.0);
         if (ic > 0) drad *= 2;
-        p.drad[(((size_t)widx * p.ng + ig) * (p.nf + 1) + ic) * p.ngeom + ipath] = drad;
+        p.drad[(size_t)mg * p.st_drad + (((size_t)widx * p.ng + ig) * (p.nf + 1) + ic) * p.ngeom + ipath] = drad;
     }
 #undef LS
 }
