@@ -227,7 +227,22 @@ def run_extras(torch, dev, eng, syn, atm, NLAYIN, LAYINC, SCALE, EMTEMP, WAVE, d
             "layers_from_cache": int(hits), "layers_of_models_1_to_n": int(tot), "layers_doubled": int(tot - hits + L),
             "layers_total": int(nj * L), "gas_opacity_rows_computed": int(rows_g[0]), "gas_opacity_rows_all": int(rows_g[1]),
             "bit_identical_to_separate_calls": bool(same), "models_compared": pick}
-        del spec_j, aj, radg_j
+        # ... and at the reference's default quadrature (5 streams, NF = 2): the lane-per-chain kernel with its own layer cache
+        radg5_j = np.ascontiguousarray(radg_j[:, :, :n5])
+        tail5 = ([30.0], [20.0], [45.0], np.full(W, 1e-8), 0, np.zeros((W, n5, n5, f5 + 1)), MU5, WT5, f5, 101, 1, 1)
+        aj5 = aj[:10] + (radg5_j,)
+        t0 = time.perf_counter(); spec5 = eng.cirsrad_ck_scatter_batch(*aj5, *tail5); t5_first = time.perf_counter() - t0
+        t0 = time.perf_counter(); spec5 = eng.cirsrad_ck_scatter_batch(*aj5, *tail5); t5j = time.perf_counter() - t0
+        hits5, tot5 = eng.last_scatter_cache()
+        fs5m = lambda m: eng.cirsrad_ck_scatter(0, layj["PRESS"][m], layj["TEMP"][m], layj["amount"][m], None, TAUDUST, TAURAY, TAUSCAT, ph,
+                                                np.ones((W, 1, L)), radg5_j[m], *tail5)
+        same5 = all(np.array_equal(fs5m(m), spec5[m]) for m in pick)
+        ex["c4_jacobian_default_streams"] = {
+            "what": "the same numerical Jacobian (%d multiple-scattering forward models) at the reference's default quadrature: 5 streams, "
+                    "NF = 2 (k_ms_chain_lane<5, CACHE>)" % nj,
+            "wall_s": t5j, "wall_s_first_call": t5_first, "s_per_forward_model": t5j / nj, "layers_from_cache": int(hits5),
+            "layers_of_models_1_to_n": int(tot5), "bit_identical_to_separate_calls": bool(same5), "models_compared": pick}
+        del spec_j, aj, radg_j, spec5, aj5, radg5_j
 
     # ---- C5: runtime line-by-line, 1e6 wavenumbers x 50 layers x 1e5 lines (Voigt, windows 25 / 75 cm-1) --------------
     nw, N, Ll = 1000000, 100000, 50
