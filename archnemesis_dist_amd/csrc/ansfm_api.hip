@@ -2551,7 +2551,7 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
     const char *ev_off = getenv("ANSFM_MS_LAYER_CACHE");
     const char *ev_lane = getenv("ANSFM_MS_LANE");
     const bool lane_n = (nmu == 4 || nmu == 5 || nmu == 6) && !(ev_lane && ev_lane[0] == '0');   // k_ms_chain_lane<N, CACHE>
-    const bool use_cache = (nmu == 16 || lane_n) && n_models > 1 && ctx->dedup && !(ev_off && atoi(ev_off) == 0);
+    const bool use_cache = n_models > 1 && ctx->dedup && !(ev_off && atoi(ev_off) == 0);      // any stream count
     if (!use_cache) {
         // other stream counts, a single model, or de-duplication switched off (ansfm_set_layer_dedup): model by model
         for (int m = 0; m < n_models; ++m) {
@@ -2687,14 +2687,15 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
     if ((rc = ms_launch(ctx, p, ncont, W, nth, ngeom, sol_angs, emiss_angs, aphis, lowbc, nmu, mu1, wt1, nf, G, L, nphi, iray,
                         imie, true)))
         return rc;
-    if (lane_n) {
-        // ---- few streams: one lane per chain (ansfm_ms_lane.hip.h).  Model 0's doubled layers per (tile of 64 wavenumbers, g,
-        //      order, layer), the other models run the adding sweep over them; every Fourier order is worked through and
-        //      k_ms_fourier applies the reference's convergence break per model.  No prefix stacks: the adding sweep is a few
-        //      per cent of a chain here.
+    if (nmu != 16) {
+        // ---- other stream counts.  Few streams (4 / 5 / 6): one lane per chain (ansfm_ms_lane.hip.h), the cache per tile of
+        //      64 wavenumbers; otherwise the wavefront-per-chain kernel (k_ms_chain<N, CACHE>), the cache per wavenumber.
+        //      Model 0's doubled layers per (g, order, layer), the other models run the adding sweep over them; every Fourier
+        //      order is worked through and k_ms_fourier applies the reference's convergence break per model.  No prefix
+        //      stacks: the adding sweep is a few per cent of a chain here.
         const int nn = nmu * nmu;
         const size_t entry_w = (size_t)(2 * nn + nmu);                              // doubles per (wavenumber, g, order, layer)
-        const size_t per_tile = (size_t)G * (nf + 1) * L * entry_w * 64 * D;
+        const size_t per_tile = (size_t)G * (nf + 1) * L * entry_w * 64 * D;        // 64 wavenumbers
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         free_b += ctx->ms_cache.bytes;
@@ -2727,16 +2728,21 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
         o.wave = ctx->d_wave.as<double>(); o.lay_temp = (const double *)d[1];
         o.taus = ctx->ms_taus.as<double>(); o.omegas = ctx->ms_omegas.as<double>(); o.bnu = ctx->ms_bnu.as<double>();
         o.W = W; o.Wpad = Wpad; o.G = G; o.L = L; o.ispace = ISPACE;
-        const size_t ldsl = (size_t)(2 * nn + nmu) * 64 * D;
+        const size_t ldsl = (size_t)(2 * nn + nmu) * 64 * D, ldsg = (12 * (size_t)nn + 6 * kMsMaxMu + 2) * D;
         auto lane_launch = [&](int cache, unsigned grid) {
             const dim3 g(grid), b(64);
-            if (nmu == 4) { if (cache == 1) hipLaunchKernelGGL((k_ms_chain_lane<4, 1>), g, b, ldsl, ctx->stream, p); else hipLaunchKernelGGL((k_ms_chain_lane<4, 2>), g, b, ldsl, ctx->stream, p); }
+            if (!lane_n) {
+                if (nmu == 5) { if (cache == 1) hipLaunchKernelGGL((k_ms_chain<5, 1>), g, b, ldsg, ctx->stream, p); else hipLaunchKernelGGL((k_ms_chain<5, 2>), g, b, ldsg, ctx->stream, p); }
+                else if (nmu == 8) { if (cache == 1) hipLaunchKernelGGL((k_ms_chain<8, 1>), g, b, ldsg, ctx->stream, p); else hipLaunchKernelGGL((k_ms_chain<8, 2>), g, b, ldsg, ctx->stream, p); }
+                else { if (cache == 1) hipLaunchKernelGGL((k_ms_chain<0, 1>), g, b, ldsg, ctx->stream, p); else hipLaunchKernelGGL((k_ms_chain<0, 2>), g, b, ldsg, ctx->stream, p); }
+            }
+            else if (nmu == 4) { if (cache == 1) hipLaunchKernelGGL((k_ms_chain_lane<4, 1>), g, b, ldsl, ctx->stream, p); else hipLaunchKernelGGL((k_ms_chain_lane<4, 2>), g, b, ldsl, ctx->stream, p); }
             else if (nmu == 5) { if (cache == 1) hipLaunchKernelGGL((k_ms_chain_lane<5, 1>), g, b, ldsl, ctx->stream, p); else hipLaunchKernelGGL((k_ms_chain_lane<5, 2>), g, b, ldsl, ctx->stream, p); }
             else { if (cache == 1) hipLaunchKernelGGL((k_ms_chain_lane<6, 1>), g, b, ldsl, ctx->stream, p); else hipLaunchKernelGGL((k_ms_chain_lane<6, 2>), g, b, ldsl, ctx->stream, p); }
         };
         for (long w0 = 0; w0 < W; w0 += Ws) {
             const int wc = (int)std::min<long>(Ws, W - w0);
-            const size_t per_model = (size_t)((wc + 63) / 64) * G * (nf + 1);
+            const size_t per_model = (lane_n ? (size_t)((wc + 63) / 64) : (size_t)wc) * G * (nf + 1);
             p.w0 = (int)w0; p.wcount = wc;
             o.w0 = (int)w0; o.wcount = wc;
             o.m0 = 0; o.nm = 1; o.model_ids = nullptr;

@@ -412,7 +412,11 @@ __device__ __forceinline__ void ms_inv(int n, int ld, double *A, double *Ainv, d
 // run time.  With N known the element -> (row, column) divisions become multiplications and the k-loops of the small products
 // unroll (C4 size at 5 streams: 0.26 -> 0.21 s).  127 registers = four waves per SIMD; capped at 85 / 64 registers (six / eight
 // waves, 0 / 55 spilled) the kernel is no faster (0.21 / 0.24 s): it is not occupancy that binds it.
-template <int N>
+// CACHE (the batched numerical Jacobian, ansfm_cirsrad_ck_scatter_batch; see k_ms_chain16): 1 = model 0's pass over the slab
+// [w0, w0 + wcount) stores the doubled (r1, t1, j1) of every scattering layer, [wavenumber of the slab][g][order][layer]
+// [2 n^2 + n]; 2 = the models [m0, m0 + n_launch) of a launch (grid x n_launch) take the layers flagged `same` from there and
+// run the adding sweep only.  Same numbers either way.
+template <int N, int CACHE = 0>
 __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
 {
     extern __shared__ double sm[];
@@ -420,10 +424,22 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
     const int n = N ? N : p.nmu, nn = n * n;
     const int ld = n;
     const int msz = n * ld;
-    const int ic = blockIdx.x % (p.nf + 1);
-    const int ig = p.ig0 + (int)((blockIdx.x / (p.nf + 1)) % p.ng_launch);      // the g-ordinates [ig0, ig0 + ng_launch) of this launch
-    const int widx = blockIdx.x / ((p.nf + 1) * p.ng_launch);
+    const unsigned per_model = (unsigned)p.wcount * (unsigned)p.ng_launch * (unsigned)(p.nf + 1);
+    const int ml = (CACHE == 2) ? (int)(blockIdx.x / per_model) : 0;           // position in the launch
+    const unsigned rest = (CACHE == 2) ? blockIdx.x % per_model : blockIdx.x;
+    const int mg = (CACHE == 2) ? p.model_ids[p.m0 + ml] : p.m0;               // model (0 outside the batch path)
+    const int ic = rest % (p.nf + 1);
+    const int ig = p.ig0 + (int)((rest / (p.nf + 1)) % p.ng_launch);      // the g-ordinates [ig0, ig0 + ng_launch) of this launch
+    const int wl = rest / ((p.nf + 1) * p.ng_launch);                      // wavenumber within the slab (w0 = 0 outside the batch path)
+    const int widx = p.w0 + wl;
     const double pi = 3.141592653589793;
+    // taus / omegas / bnu: [model of the launch][wavenumber of the slab]; the other per-wavenumber arrays keep the whole axis
+    const size_t wrow = (size_t)ml * p.wcount + wl;
+    const double *taus_w = p.taus + (wrow * p.ng + ig) * p.nlay, *omegas_w = p.omegas + (wrow * p.ng + ig) * p.nlay;
+    const double *bnu_w = p.bnu + wrow * p.nlay, *tauray_w = p.tauray + (size_t)mg * p.st_wl + (size_t)widx * p.nlay;
+    const double *lfrac_m = p.lfrac + (size_t)mg * p.st_wcl;
+    const double *radg_m = p.radg + (size_t)mg * p.st_wm;
+    const size_t centry = (size_t)(2 * nn + n);
     // LDS carve-up
     double *rc = sm, *tc = rc + msz, *r1 = tc + msz, *t1 = r1 + msz, *pp = t1 + msz, *pm = pp + msz;
     double *m0 = pm + msz, *m1 = m0 + msz, *m2 = m1 + msz, *m3 = m2 + msz, *m4 = m3 + msz, *m5 = m4 + msz;
@@ -433,7 +449,7 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
 #define MS_FOR_IJ for (int e = lane, i = e / n, j = e % n; e < nn; e += 64, i = e / n, j = e % n)
 #define MS_AT(M, i, j) M[(i) * ld + (j)]
 
-    if (lane < n) radg[lane] = p.radg[(size_t)widx * n + (n - 1 - lane)];   // radg[:, ::-1] :765
+    if (lane < n) radg[lane] = radg_m[(size_t)widx * n + (n - 1 - lane)];   // radg[:, ::-1] :765
     MS_WAVE_SYNC();
     bool defined = false;
     const bool lookup = p.lookup != 0;
@@ -452,13 +468,13 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
 
     for (int l = 0; l < p.nlay; ++l) {
         const int k = lookup ? p.nlay - 1 - l : l;  // look-down: bottom layer first (:842-845)
-        const double taut = p.taus[((size_t)widx * p.ng + ig) * p.nlay + k];
-        const double bc = p.bnu[(size_t)widx * p.nlay + k];
-        double omega = p.omegas[((size_t)widx * p.ng + ig) * p.nlay + k];
+        const double taut = taus_w[k];
+        const double bc = bnu_w[k];
+        double omega = omegas_w[k];
         if (omega < 0) omega = 0.0;
         if (omega > 1) omega = 1.0;
         double tauscat = taut * omega;
-        const double taur = p.tauray[(size_t)widx * p.nlay + k];
+        const double taur = tauray_w[k];
         tauscat = tauscat - taur;
         if (tauscat < 0) tauscat = 0.0;
         // ---- calc_rtj_matrix :566-647 -> (r1, t1, j1), iscl ------------------------------------------------
@@ -478,6 +494,13 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
                 j1[lane] = bc * (1.0 - tt);
             }
             MS_WAVE_SYNC();
+        } else if (CACHE == 2 && p.same[(size_t)mg * p.nlay + k]) {
+            // the layer of model 0, as its own pass left it (block-uniform branch)
+            iscl = 1;
+            const double *ce = p.cache + ((((size_t)wl * p.ng + ig) * (p.nf + 1) + ic) * p.nlay + k) * centry;
+            MS_FOR_IJ { MS_AT(r1, i, j) = ce[e]; MS_AT(t1, i, j) = ce[nn + e]; }
+            if (lane < n) j1[lane] = ce[2 * nn + lane];
+            MS_WAVE_SYNC();
         } else {
             iscl = 1;
             const double fr = taur / (tauscat + taur), fs = tauscat / (tauscat + taur);
@@ -485,7 +508,7 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
                 double a = (p.iray > 0) ? fr * (PPL[(size_t)p.ncont * nn + e] * FC[(size_t)p.ncont * nn + e]) : 0.0;
                 double b = (p.iray > 0) ? fr * PMI[(size_t)p.ncont * nn + e] : 0.0;
                 for (int c = 0; c < p.ncont; ++c) {
-                    const double f = p.lfrac[((size_t)widx * p.ncont + c) * p.nlay + k];
+                    const double f = lfrac_m[((size_t)widx * p.ncont + c) * p.nlay + k];
                     a += fs * (PPL[(size_t)c * nn + e] * FC[(size_t)c * nn + e]) * f;
                     b += fs * PMI[(size_t)c * nn + e] * f;
                 }
@@ -530,6 +553,11 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
                 }
                 MS_FOR_IJ { MS_AT(r1, i, j) = MS_AT(r1, i, j) + MS_AT(m1, i, j); MS_AT(t1, i, j) = MS_AT(m4, i, j); }
                 MS_WAVE_SYNC();
+            }
+            if constexpr (CACHE == 1) {
+                double *ce = p.cache + ((((size_t)wl * p.ng + ig) * (p.nf + 1) + ic) * p.nlay + k) * centry;
+                MS_FOR_IJ { ce[e] = MS_AT(r1, i, j); ce[nn + e] = MS_AT(t1, i, j); }
+                if (lane < n) ce[2 * nn + lane] = j1[lane];
             }
         }
         // ---- combine with the stack below :868-875 ------------------------------------------------------------
@@ -628,7 +656,7 @@ __global__ __launch_bounds__(64) void k_ms_chain(MsParams p)
         double drad = ((1 - t) * (1 - u) * yx[0] + t * (1 - u) * yx[1] + t * u * yx[3] + (1 - t) * u * yx[2]) *
                       cos(ic * p.aphi[ipath] * pi / 180.0);
         if (ic > 0) drad *= 2;
-        p.drad[(((size_t)widx * p.ng + ig) * (p.nf + 1) + ic) * p.ngeom + ipath] = drad;
+        p.drad[(size_t)mg * p.st_drad + (((size_t)widx * p.ng + ig) * (p.nf + 1) + ic) * p.ngeom + ipath] = drad;
     }
 #undef MS_FOR_IJ
 #undef MS_AT

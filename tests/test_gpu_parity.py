@@ -1301,12 +1301,16 @@ def test_cirsrad_scatter_batch_equals_separate_calls(eng, monkeypatch, ncont, im
     assert np.array_equal(again, ref)
 
 
-@pytest.mark.parametrize("NMU", [5, 8, 12])
-def test_cirsrad_scatter_batch_other_stream_counts_equal_separate_calls(eng, NMU):
-    """Other stream counts than 16 (5 = the reference's default: the lane-per-chain kernel; 8: the wavefront-per-chain kernel
-    with compile-time sizes; 12: its run-time build): the models of a batch run one after the other, models 1.. on the phase
-    matrices and Hansen factors model 0 left behind (they depend on the phase functions, not on the model) -- every spectrum
-    equal to a call of its own bit for bit, also when a single call came in between and the batch is repeated."""
+@pytest.mark.parametrize("NMU,lane,dedup", [(5, True, True), (5, False, True), (4, True, True), (8, True, True), (12, True, True),
+                                            (20, True, True), (5, True, False), (8, True, False)])
+def test_cirsrad_scatter_batch_other_stream_counts_equal_separate_calls(eng, monkeypatch, NMU, lane, dedup):
+    """Other stream counts than 16 (5 = the reference's default: the lane-per-chain kernel, or with ANSFM_MS_LANE=0 the
+    wavefront-per-chain one; 8: that kernel with compile-time sizes; 12, 20: its run-time build): model 0's doubled layers are
+    cached, the other models run the adding sweep over them (k_ms_chain_lane<N, CACHE> / k_ms_chain<N, CACHE>) -- every spectrum
+    equal to a call of its own bit for bit, also when a single call came in between and the batch is repeated.  With the
+    de-duplication off the models run one after the other on the phase matrices and Hansen factors model 0 left behind."""
+    if not lane:
+        monkeypatch.setenv("ANSFM_MS_LANE", "0")
     rng = np.random.default_rng(9100 + NMU)
     W, G, L, S, NF = 70, 4, 8, 3, 2
     z = _scatter_inputs(rng, W, G, L, S, NMU, NF, 2, 1, 1, 1)
@@ -1321,10 +1325,19 @@ def test_cirsrad_scatter_batch_other_stream_counts_equal_separate_calls(eng, NMU
     tail = (sol, emi, azi, z["solar"], 1, z["brdf"], z["MU"], z["WT"], NF, 101, 1, 1)
     one = lambda m: eng.cirsrad_ck_scatter(0, lp[m], lt[m], am[m], cia[m], dust[m], ray[m], sca[m], z["phasarr"], lf[m], rg[m], *tail)
     ref = np.stack([one(m) for m in range(n)])
-    got = eng.cirsrad_ck_scatter_batch(0, lp, lt, am, cia, dust, ray, sca, z["phasarr"], lf, rg, *tail)
-    assert np.array_equal(got, ref)
-    assert np.array_equal(one(2), ref[2])                       # a single call afterwards starts from its own walk again
-    assert np.array_equal(eng.cirsrad_ck_scatter_batch(0, lp, lt, am, cia, dust, ray, sca, z["phasarr"], lf, rg, *tail), ref)
+    eng.set_layer_dedup(dedup)
+    try:
+        got = eng.cirsrad_ck_scatter_batch(0, lp, lt, am, cia, dust, ray, sca, z["phasarr"], lf, rg, *tail)
+        assert np.array_equal(got, ref)
+        hits, total = eng.last_scatter_cache()
+        if dedup:
+            assert total == (n - 1) * L and hits == total - 3                     # three changed layers in all
+        else:
+            assert hits == 0
+        assert np.array_equal(one(2), ref[2])                   # a single call afterwards starts from its own walk again
+        assert np.array_equal(eng.cirsrad_ck_scatter_batch(0, lp, lt, am, cia, dust, ray, sca, z["phasarr"], lf, rg, *tail), ref)
+    finally:
+        eng.set_layer_dedup(True)
     assert not np.array_equal(ref[1], ref[0]) and not np.array_equal(ref[3], ref[0])
 
 
