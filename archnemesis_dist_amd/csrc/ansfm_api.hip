@@ -73,6 +73,7 @@ struct ansfm_ctx {
     DevBuf li, tau, scratch, cont_t, tmp_in, tmp_out, misc;
     DevBuf dspec_ref, map_out, map_b, map_batch;
     DevBuf dd_slot, dd_work, dd_in;      // layer de-duplication: row map [n][L], work list, packed inputs
+    DevBuf ms_radg16, ms_brdf16;         // 7 .. 15 streams padded to the 16-stream kernels' layout
     int ms_reuse_walk = 0;               // scattering, model-by-model batches: phase matrices + Hansen factors of the previous call stand
     DevBuf rt_prefix, rt_same;           // thermal RT of a batch: state 0's records along every path; same flags [n][L] + jstart [n][P]
     int last_rt_shared = 0;
@@ -2201,6 +2202,30 @@ int ansfm_kdist_bins(ansfm_ctx *ctx, int ncalc, const double *wavecalc, const do
 /* ------------------------------------------------------------------------------------------ */
 // The kernels of scloud11wave_core on device-resident inputs: p holds the nine input pointers; dims, quadrature and
 // angles are filled in here.  Leaves rad[ngeom][ng][nwave] in ctx->tmp_out (asynchronous).
+// 7 .. 15 streams run on the 16-stream kernels (matrix-core chain, its layer cache, its walk) with the quadrature padded:
+// mu = 1 / weight = 0 beyond it, phase matrices, surface operator and boundary radiance zero there, so that every operator is
+// block diagonal and the quadrature's block never sees the rest.  The run-time LDS kernels those sizes used to take need
+// 1.6 s for the C4 configuration at 12 streams / NF 2, the padded path 0.2 s.  ANSFM_MS_PAD16=0: the LDS kernels.
+static bool ms_pad16(int nmu)
+{
+    const char *e = getenv("ANSFM_MS_PAD16");
+    return nmu >= 7 && nmu <= 15 && !(e && e[0] == '0');
+}
+// radg [rows][nmu] and brdf [W][nmu][nmu][nf + 1] (device) -> the padded copies the 16-stream kernels read
+static int ms_pad_inputs(ansfm_ctx *ctx, int nmu, size_t radg_rows, size_t W, int nf, const double **radg, const double **brdf)
+{
+    const size_t D = sizeof(double);
+    HIPCHK(ctx->ms_radg16.reserve(radg_rows * 16 * D));
+    HIPCHK(ctx->ms_brdf16.reserve(W * 256 * (nf + 1) * D));
+    hipLaunchKernelGGL(k_ms_pad_radg, dim3(nblk(radg_rows * 16, 256)), dim3(256), 0, ctx->stream, radg_rows, nmu, *radg,
+                       ctx->ms_radg16.as<double>());
+    hipLaunchKernelGGL(k_ms_pad_brdf, dim3(nblk(W * 256 * (size_t)(nf + 1), 256)), dim3(256), 0, ctx->stream, W, nmu, nf + 1, *brdf,
+                       ctx->ms_brdf16.as<double>());
+    HIPCHK(hipGetLastError());
+    *radg = ctx->ms_radg16.as<double>(); *brdf = ctx->ms_brdf16.as<double>();
+    return ANSFM_OK;
+}
+
 static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth, int ngeom, const double *sol_angs,
                      const double *emiss_angs, const double *aphis, int lowbc, int nmu, const double *mu1, const double *wt1,
                      int nf, int ng, int nlay, int nphi, int iray, int imie, bool prepare_only = false)
@@ -2212,12 +2237,17 @@ static int ms_launch(ansfm_ctx *ctx, MsParams &p, int ncont, int nwave, int nth,
     if (nless != ngeom && nmore != ngeom)
         FAIL(ANSFM_ERR_INVALID, "Emission angles are a mix of values above and below 90 degrees.");   // :776
     const size_t D = sizeof(double);
+    const int nmu_in = nmu;                                     // the quadrature's size; p.radg / p.brdf are padded by the caller
+    const bool pad16 = ms_pad16(nmu_in);
+    if (pad16) nmu = 16;
     p.ncont = ncont; p.ncomp = ncont + 1; p.nwave = nwave; p.nth = nth; p.ngeom = ngeom; p.lowbc = lowbc; p.nmu = nmu;
+    p.nmu_real = pad16 ? nmu_in : 0;
     p.nf = nf; p.ng = ng; p.nlay = nlay; p.nphi = nphi; p.iray = iray; p.imie = imie;
     p.lookup = (nmore == ngeom) ? 1 : 0;
     p.w0 = 0; p.wcount = nwave; p.m0 = 0; p.n_launch = 1;      // one model, the whole spectral axis
     double xs = 0.0;
-    for (int k = 0; k < nmu; ++k) { xs += mu1[k] * wt1[k]; p.mu[k] = mu1[nmu - 1 - k]; p.wtmu[k] = wt1[nmu - 1 - k]; }
+    for (int k = 0; k < nmu_in; ++k) { xs += mu1[k] * wt1[k]; p.mu[k] = mu1[nmu_in - 1 - k]; p.wtmu[k] = wt1[nmu_in - 1 - k]; }
+    for (int k = nmu_in; k < nmu; ++k) { p.mu[k] = 1.0; p.wtmu[k] = 0.0; }
     p.xfac = 0.5 / xs;                                          // :720-722
     for (int k = 0; k < ngeom; ++k) { p.sol_ang[k] = sol_angs[k]; p.emiss_ang[k] = emiss_angs[k]; p.aphi[k] = aphis[k]; }
     const size_t nn = (size_t)nmu * nmu;
@@ -2421,6 +2451,7 @@ int ansfm_scloud11wave_core(ansfm_ctx *ctx, int ncont, int nwave, int nth, const
     p.phasarr = (const double *)d[0]; p.radg = (const double *)d[1]; p.solar = (const double *)d[2];
     p.brdf = (const double *)d[3]; p.bnu = (const double *)d[4]; p.taus = (const double *)d[5];
     p.tauray = (const double *)d[6]; p.omegas = (const double *)d[7]; p.lfrac = (const double *)d[8];
+    if (ms_pad16(nmu) && (rc = ms_pad_inputs(ctx, nmu, (size_t)nwave, (size_t)nwave, nf, &p.radg, &p.brdf))) return rc;
     if ((rc = ms_launch(ctx, p, ncont, nwave, nth, ngeom, sol_angs, emiss_angs, aphis, lowbc, nmu, mu1, wt1, nf, ng, nlay,
                         nphi, iray, imie)))
         return rc;
@@ -2510,6 +2541,7 @@ int ansfm_cirsrad_ck_scatter(ansfm_ctx *ctx, int ISPACE, int L, const double *la
     p.phasarr = (const double *)d[7]; p.radg = (const double *)d[9]; p.solar = (const double *)d[10];
     p.brdf = (const double *)d[11]; p.bnu = o.bnu; p.taus = o.taus; p.tauray = d_tauray; p.omegas = o.omegas;
     p.lfrac = (const double *)d[8];
+    if (ms_pad16(nmu) && (rc = ms_pad_inputs(ctx, nmu, (size_t)W, (size_t)W, nf, &p.radg, &p.brdf))) return rc;
     if ((rc = ms_launch(ctx, p, ncont, W, nth, ngeom, sol_angs, emiss_angs, aphis, lowbc, nmu, mu1, wt1, nf, G, L, nphi,
                         iray, imie)))
         return rc;
@@ -2684,10 +2716,13 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
     memset(&p, 0, sizeof p);
     p.phasarr = (const double *)d[7]; p.radg = (const double *)d[9]; p.solar = (const double *)d[10];
     p.brdf = (const double *)d[11]; p.tauray = d_tauray; p.lfrac = (const double *)d[8];
+    const bool pad16 = ms_pad16(nmu);
+    if (pad16 && (rc = ms_pad_inputs(ctx, nmu, (size_t)n_models * W, (size_t)W, nf, &p.radg, &p.brdf))) return rc;
     if ((rc = ms_launch(ctx, p, ncont, W, nth, ngeom, sol_angs, emiss_angs, aphis, lowbc, nmu, mu1, wt1, nf, G, L, nphi, iray,
                         imie, true)))
         return rc;
-    if (nmu != 16) {
+    const int nmu_k = pad16 ? 16 : nmu;                         // the stream count the kernels run with
+    if (nmu_k != 16) {
         // ---- other stream counts.  Few streams (4 / 5 / 6): one lane per chain (ansfm_ms_lane.hip.h), the cache per tile of
         //      64 wavenumbers; otherwise the wavefront-per-chain kernel (k_ms_chain<N, CACHE>), the cache per wavenumber.
         //      Model 0's doubled layers per (g, order, layer), the other models run the adding sweep over them; every Fourier
@@ -2802,7 +2837,7 @@ int ansfm_cirsrad_ck_scatter_batch(ansfm_ctx *ctx, int ISPACE, int n_models, int
     p.cache = ctx->ms_cache.as<double>(); p.cache_orders = ctx->ms_orders.as<int>(); p.same = same;
     p.pcache = ctx->ms_pcache.as<double>(); p.lstart = ctx->ms_lstart.as<int>(); p.npre = npre;
     p.model_ids = ctx->ms_lstart.as<int>() + n_models;
-    p.st_wl = st_wl; p.st_wcl = (size_t)W * ncont * L; p.st_wm = (size_t)W * nmu; p.st_rad = (size_t)ngeom * G * W;
+    p.st_wl = st_wl; p.st_wcl = (size_t)W * ncont * L; p.st_wm = (size_t)W * nmu_k; p.st_rad = (size_t)ngeom * G * W;
     p.phase_lds = 0; p.ig0 = 0; p.ng_launch = G;
     MsOpticsBatchParams o;
     memset(&o, 0, sizeof o);

@@ -67,7 +67,30 @@ struct MsParams {
     int npre;
     size_t st_wl, st_wcl, st_wm, st_rad;   // strides between models: tauray [W][L], lfrac [W][ncont][L], radg [W][nmu], rad
     size_t st_drad;                        // ... and drad (k_ms_chain_lane<N, CACHE> leaves the orders to k_ms_fourier)
+    // 7 .. 15 streams on the 16-stream kernels: nmu = 16, nmu_real = the quadrature's size (0 = nmu).  mu / wtmu beyond it are
+    // 1 / 0, the phase matrices, the surface operator and the boundary radiance zero there: every operator is block diagonal with
+    // the quadrature's block in front and a block that couples to nothing behind it
+    int nmu_real;
 };
+
+// radg [rows][nr] -> [rows][16]: the chain kernels read it back to front (radg[:, ::-1], :765), so the quadrature's values go to
+// the END of a padded row.  brdf [W][nr][nr][nf1] -> [W][16][16][nf1], zero outside the block.
+__global__ void k_ms_pad_radg(size_t rows, int nr, const double *__restrict__ src, double *__restrict__ dst)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * 16) return;
+    const int k = (int)(idx % 16);
+    const size_t r = idx / 16;
+    dst[idx] = (k >= 16 - nr) ? src[r * nr + (k - (16 - nr))] : 0.0;
+}
+__global__ void k_ms_pad_brdf(size_t W, int nr, int nf1, const double *__restrict__ src, double *__restrict__ dst)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= W * 256 * nf1) return;
+    const int ic = (int)(idx % nf1), j = (int)((idx / nf1) % 16), i = (int)((idx / ((size_t)nf1 * 16)) % 16);
+    const size_t w = idx / ((size_t)nf1 * 256);
+    dst[idx] = (i < nr && j < nr) ? src[((w * nr + i) * nr + j) * nf1 + ic] : 0.0;
+}
 constexpr int kMsCacheEntry = 528;   // doubles per cached layer: r (256) and t (256) in the MFMA accumulator layout, j (16)
 constexpr int kMsPrefixStep = 4;     // the stack below is kept after sweep layers 3, 7, 11, ...
 constexpr int kMsHansenDepth = 8;    // steps the Hansen walk fetches its matrices ahead (k_ms_hansen_seq)
@@ -110,8 +133,16 @@ __global__ __launch_bounds__(256) void k_ms_phase(MsParams p)
         __syncthreads();
     }
     const double *cphi_row = ctab + (size_t)(p.nf + 1) * nk;
+    const int nr = p.nmu_real ? p.nmu_real : n;
     for (int e = tid; e < nn; e += blockDim.x) {
         const int i = e / n, j = e % n;
+        if (i >= nr || j >= nr) {               // beyond the quadrature (a smaller one padded to 16 streams): nothing scatters there
+            for (int ic = 0; ic <= p.nf; ++ic) {
+                p.ppl[(((size_t)widx * (p.nf + 1) + ic) * p.ncomp + comp) * nn + e] = 0.0;
+                p.pmi[(((size_t)widx * (p.nf + 1) + ic) * p.ncomp + comp) * nn + e] = 0.0;
+            }
+            continue;
+        }
         const double sthi = sqrt(1.0 - p.mu[i] * p.mu[i]), sthj = sqrt(1.0 - p.mu[j] * p.mu[j]);
         const double ss = sthi * sthj, mmu = p.mu[i] * p.mu[j];
         for (int ic0 = 0; ic0 <= p.nf; ic0 += kMsPhaseOrders) {
@@ -234,6 +265,7 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
     const int comp = blockIdx.x + p.hansen_comp0;
     const int n = NMU ? NMU : p.nmu, nn = n * n, tid = threadIdx.x;
     const double x1 = 2.0 * 3.141592653589793;
+    const int nr = p.nmu_real ? p.nmu_real : n;              // the quadrature's size (a smaller one padded to 16 streams)
     constexpr int NE = NMU ? (NMU * NMU + 63) / 64 : (kMsMaxMu * kMsMaxMu + 63) / 64;   // matrix elements per lane
     // The walk is a chain of short steps (a converged start needs one pass over a 16 x 16 matrix) and every step needs two
     // matrices from HBM / L2: a microsecond away.  They are fetched kMsHansenDepth steps ahead into a ring of registers (the
@@ -288,7 +320,7 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
         if (++wf == p.nwave) wf = 0;
         MS_WAVE_SYNC();
         double rs = 0.0;
-        if (tid < n) {
+        if (tid < nr) {
             double s = 0.0;
 #pragma unroll
             for (int i = 0; i < n; ++i) s += pmi[i * n + tid] * p.wtmu[i];
@@ -297,7 +329,7 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
         }
         for (int niter = 0; niter < 10000; ++niter) {
             double dev = 0.0;
-            if (tid < n) {
+            if (tid < nr) {
                 double s = 0.0;
 #pragma unroll
                 for (int i = 0; i < n; ++i) s += ppl[i * n + tid] * p.wtmu[i] * fc[i * n + tid];
@@ -308,7 +340,8 @@ __global__ __launch_bounds__(64) void k_ms_hansen_seq(MsParams p)
             dev = ms_wave_max(dev);                  // VALU lane exchanges (six dependent ds_bpermute stages before)
             MS_WAVE_SYNC();
             if (dev < 1e-14) break;
-            if (tid < n) xs[tid] = (1.0 - rsum[tid]) / tsum[tid];   // one division per column instead of two per element
+            if (tid < nr) xs[tid] = (1.0 - rsum[tid]) / tsum[tid];   // one division per column instead of two per element
+            else if (tid < n) xs[tid] = 1.0;                         // columns beyond the quadrature keep their factor of 1
             MS_WAVE_SYNC();
             for (int e = tid; e < nn; e += 64) {
                 const int i = e / n, j = e % n;
@@ -1179,10 +1212,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         else { zmu0 = ms_cos_ni(sol_ang * pi / 180.0); solar1 = p.solar[widx]; }
         const double zmu = ms_cos_ni(emiss_ang * pi / 180.0);
         int isol = 0, iemm = 0;
-        for (int j = 0; j < n - 1; ++j) if (zmu0 <= mus[j] && zmu0 > mus[j + 1]) isol = j;
-        if (zmu0 <= mus[n - 1]) isol = n - 2;
-        for (int j = 0; j < n - 1; ++j) if (zmu <= mus[j] && zmu > mus[j + 1]) iemm = j;
-        if (zmu <= mus[n - 1]) iemm = n - 2;
+        const int nq = p.nmu_real ? p.nmu_real : n;     // the quadrature's points (a smaller quadrature padded to 16 streams)
+        for (int j = 0; j < nq - 1; ++j) if (zmu0 <= mus[j] && zmu0 > mus[j + 1]) isol = j;
+        if (zmu0 <= mus[nq - 1]) isol = nq - 2;
+        for (int j = 0; j < nq - 1; ++j) if (zmu <= mus[j] && zmu > mus[j + 1]) iemm = j;
+        if (zmu <= mus[nq - 1]) iemm = nq - 2;
         const double u = (mus[isol] - zmu0) / (mus[isol] - mus[isol + 1]);
         const double t = (mus[iemm] - zmu) / (mus[iemm] - mus[iemm + 1]);
         double yx[4];

@@ -1227,7 +1227,11 @@ def _scatter_oracle(oracle, z, sol, emi, azi, lowbc, NF, nphi, iray, imie):
                                                              (24, 2, 1, 1, 1, 1, False), (32, 1, 1, 0, 1, 0, True),   # beyond the old cap of 20
                                                              (5, 1, 1, 1, 0, 0, True), (16, 2, 0, 0, 1, 0, False),
                                                              (16, 2, 2, 0, 1, 0, False),      # three components: phase matrices stay in HBM
-                                                             (16, 1, 2, 1, 0, 1, True)])
+                                                             (16, 1, 2, 1, 0, 1, True),
+                                                             # 7 .. 15 streams: padded to the 16-stream matrix-core kernels
+                                                             (7, 2, 1, 1, 1, 0, False), (8, 3, 2, 0, 1, 1, False), (10, 2, 1, 1, 1, 1, True),
+                                                             (12, 2, 2, 1, 1, 0, True), (15, 1, 1, 0, 0, 1, False),
+                                                             (4, 2, 1, 1, 1, 1, False), (6, 2, 2, 0, 1, 1, True)])
 def test_cirsrad_scatter_vs_oracle(eng, oracle, NMU, NF, ncont, imie, iray, lowbc, up):
     """ansfm_cirsrad_ck_scatter (gas opacities, TAUTOT, OMEGA, BB formed on the device, straight into the doubling /
     adding kernels) vs the same chain through the oracle: radiances before and after the g-quadrature and TAUGAS."""
