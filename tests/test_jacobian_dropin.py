@@ -495,6 +495,64 @@ def test_primary_transit_jacobian_staged_equals_the_reference_loop(c1_cut):
         fm.jacobian_nemesis(NCores=1, nemesisPT=True, analytical_gradient=False)
 
 
+@pytest.mark.needs_reference
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "archnemesis")), reason="reference tree not present")
+@pytest.mark.parametrize("route", ["staged", "loop", "profile"])
+def test_dropin_jacobian_sharded_over_two_ranks_gloo(tmp_path, route):
+    """`ansfm_jacobian_group = (rank, world, group)`: every route of the drop-in jacobian_nemesis gives rank r the reference's
+    contiguous chunk of the forward models (:2322-2330; the staged and profile routes put the unperturbed state in front of a
+    chunk that does not start with it) and ONE all_gather puts YNtot together -- two gloo ranks on the CPU (the engine
+    answered by the oracle double) return the KK of a single process on every rank."""
+    import subprocess, textwrap
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent(f'''
+        import os, sys, tempfile, warnings
+        import numpy as np
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        from oracle.ref_import import import_reference
+        from oracle import gen_golden_jacobian as gj
+        from oracle import oracle as orc
+        from test_dropin_reference import OracleEngineDouble
+        import archnemesis_dist_amd.forward_model as fmod
+        orc.build()
+        ans = import_reference()
+        work = tempfile.mkdtemp(prefix="ansfm_w2_%d_" % rank)
+        gj.setup_c1(ans, work)
+        os.chdir(work)
+        double = OracleEngineDouble(orc)
+        fmod.get_engine = lambda device=0: double
+        FMGPU = fmod.make_gpu_forward_model(ans.ForwardModel_0)
+        free = (10, 30, 50, 70, 75)
+        def run(group):
+            fm = gj.cut_case(ans, cls=FMGPU, nkeep=10, free=free)
+            fm.ansfm_jacobian_route = {route!r}
+            fm.ansfm_jacobian_group = group
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                YN, KK = fm.jacobian_nemesis(NCores=1, analytical_gradient=False)
+            assert fm.ansfm_last_jacobian["route"] == {route!r}
+            return YN, KK
+        one = run(None)
+        two = run((rank, world, None))
+        assert np.array_equal(one[0], two[0]) and np.array_equal(one[1], two[1]), rank
+        assert all(np.abs(two[1][:, ix]).max() > 0 for ix in free)
+        dist.destroy_process_group()
+        print("rank", rank, "ok")
+    ''')
+    f = tmp_path / "w.py"
+    f.write_text(script)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    port = {"staged": "29641", "loop": "29642", "profile": "29643"}[route]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(f)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
+
+
 def test_limb_spectra_are_brought_to_the_tangent_heights_as_the_reference_does():
     """nemesisLfm :1322-1344 restated (JacobianGPU._ansfm_limb_to_tangent_heights): weights between the neighbouring tangent
     paths, the nearest base compared after a second division by 1e3, the lower neighbour -1 wrapping to the last path, the
